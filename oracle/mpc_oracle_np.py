@@ -1,0 +1,449 @@
+"""NumPy restatement of the Avoid-MPC NLP and of the solver contract.  TEST INFRASTRUCTURE ONLY.
+
+This file is part of the oracle: only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import it.  The product path (HIP kernels behind include/avoid_mpc_amd.h)
+never touches it.
+
+PARITY UNPINNED: the reference's MPC arithmetic lives in CasADi 3.6.4 + IPOPT + MUMPS
+(README.md:41-43), none of which is in /root/reference or in this image.  What is restated here is
+the *specification* of the NLP as written in
+    AM/tools/mpc_obstacle_casadi.py   (AM = roswrapper/ros/src/avoid_mpc)
+and the packing / bounds / options in AM/src/HighLvlMpc.cpp.  It is pinned by substitutes only:
+finite differences, a scipy.optimize converged optimum, and the reference's own smoke scenario
+(mpc_obstacle_casadi.py:448-498) -- see tests/test_mpc_oracle.py.
+
+Layouts:
+  P  = [x_init(10) | ref_k(10)*N | obstacles(3*K*N) | target(10) | gain(4) | tau(4) | weights(25) | r]
+  w  = [X_0, U_0, X_1, U_1, ..., U_{N-1}, X_N]      (nx = 10 + 14 N)
+  g  = [X_0 - x_init ; F(X_k,U_k) - X_{k+1}]        (ng = 10 + 10 N)
+"""
+import numpy as np
+
+S_DIM = 10
+U_DIM = 4
+GZ = 9.81  # mpc_obstacle_casadi.py:39
+
+
+# ----------------------------------------------------------------------------------------------
+# parameter vector helpers
+# ----------------------------------------------------------------------------------------------
+def p_len(N, K):
+    # mpc_obstacle_casadi.py:76-85
+    return S_DIM + S_DIM * N + K * 3 * N + S_DIM + U_DIM * 2 + 25 + 1
+
+
+def split_p(P, N, K):
+    """Slices of P exactly as mpc_obstacle_casadi.py:88-149 takes them."""
+    P = np.asarray(P, dtype=np.float64)
+    assert P.shape[0] == p_len(N, K)
+    o0 = S_DIM + S_DIM * N
+    t0 = o0 + 3 * K * N
+    out = dict(
+        x_init=P[0:S_DIM],
+        ref=P[S_DIM:o0].reshape(N, S_DIM),
+        obs=P[o0:t0].reshape(N, K, 3),
+        target=P[t0:t0 + S_DIM],
+        gain=P[-34:-30],
+        tau=P[-30:-26],
+        weights=P[-26:-1],
+        radius=P[-1],
+    )
+    w = out["weights"]
+    out["q_goal"] = w[0:10]
+    out["q_pen"] = w[10:20]
+    out["q_u"] = w[20:24]
+    out["lam"] = w[24]
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# dynamics  (mpc_obstacle_casadi.py:106-122 ode, :338-357 RK4 x 4)
+# ----------------------------------------------------------------------------------------------
+def ode(x, u, tau):
+    return np.array([
+        x[4], x[5], x[6],
+        u[3],
+        x[7], x[8], x[9],
+        (u[0] - x[7]) * tau[0],
+        (u[1] - x[8]) * tau[1],
+        (u[2] - GZ - x[9]) * tau[2],
+    ])
+
+
+def rk4_step(x, u, tau, dt):
+    M = 4
+    DT = dt / M
+    X = np.array(x, dtype=np.float64)
+    for _ in range(M):
+        k1 = DT * ode(X, u, tau)
+        k2 = DT * ode(X + 0.5 * k1, u, tau)
+        k3 = DT * ode(X + 0.5 * k2, u, tau)
+        k4 = DT * ode(X + k3, u, tau)
+        X = X + (k1 + 2 * k2 + 2 * k3 + k4) / 6
+    return X
+
+
+def affine_dynamics(tau, dt):
+    """F(x,u) = A x + B u + c  (drag off => exactly affine).  Returned by probing rk4_step."""
+    z10, z4 = np.zeros(S_DIM), np.zeros(U_DIM)
+    c = rk4_step(z10, z4, tau, dt)
+    A = np.zeros((S_DIM, S_DIM))
+    B = np.zeros((S_DIM, U_DIM))
+    for j in range(S_DIM):
+        e = z10.copy(); e[j] = 1.0
+        A[:, j] = rk4_step(e, z4, tau, dt) - c
+    for j in range(U_DIM):
+        e = z4.copy(); e[j] = 1.0
+        B[:, j] = rk4_step(z10, e, tau, dt) - c
+    return A, B, c
+
+
+# ----------------------------------------------------------------------------------------------
+# objective pieces
+# ----------------------------------------------------------------------------------------------
+def softplus(x):
+    return np.log(1.0 + np.exp(x))  # naive form, mpc_obstacle_casadi.py:250-251
+
+
+def sigmoid(x):
+    return 1.0 / (1.0 + np.exp(-x))
+
+
+def rot_of_ref(yaw_ref):
+    """mpc_obstacle_casadi.py:174-185: identity with 2x2 blocks on (px,py) and (vx,vy)."""
+    c = np.cos(yaw_ref)
+    s = np.sin(-yaw_ref)
+    R = np.eye(S_DIM)
+    for a in (0, 4):
+        R[a, a] = c
+        R[a, a + 1] = -s
+        R[a + 1, a] = s
+        R[a + 1, a + 1] = c
+    return R
+
+
+def collide_terms(p, v, obs, lam, radius, want_derivs):
+    """Sum over the K obstacle points of one stage (mpc_obstacle_casadi.py:186-204).
+
+    returns cost, grad(6: p then v), hess(6x6)"""
+    cost = 0.0
+    g6 = np.zeros(6)
+    H6 = np.zeros((6, 6))
+    I3 = np.eye(3)
+    for o in obs:
+        d = o - p
+        rho = np.sqrt(d @ d)
+        n = d / rho
+        s = v @ n
+        x = -32.0 * (rho - radius)
+        g = softplus(x)
+        cost += lam * g * abs(s)
+        if not want_derivs:
+            continue
+        sg = sigmoid(x)
+        gp = -32.0 * sg
+        gpp = 1024.0 * sg * (1.0 - sg)
+        sgn = np.sign(s)
+        t = v - s * n
+        # gradient
+        gp_vec = lam * sgn * (gp * (-n) * s + g * (-t / rho))
+        gv_vec = lam * sgn * g * n
+        g6[0:3] += gp_vec
+        g6[3:6] += gv_vec
+        # hessian
+        Pn = I3 - np.outer(n, n)
+        Hpp = (gpp * np.outer(n, n) * s
+               + gp * (Pn / rho) * s
+               + gp * (np.outer(-n, -t / rho) + np.outer(-t / rho, -n))
+               + g * (-(np.outer(t, n) + np.outer(n, t)) / rho ** 2 - s * Pn / rho ** 2))
+        Hpv = -gp * np.outer(n, n) - g * Pn / rho
+        H6[0:3, 0:3] += lam * sgn * Hpp
+        H6[0:3, 3:6] += lam * sgn * Hpv
+        H6[3:6, 0:3] += lam * sgn * Hpv.T
+    return cost, g6, H6
+
+
+PV = np.array([0, 1, 2, 4, 5, 6])  # positions then velocities inside the 10-state
+
+
+def stage_cost(k, N, xk1, uk, pp, want_derivs=True):
+    """Cost attached to (U_k, X_{k+1}); returns (cost, q(10), Q(10x10), r(4), Rdiag(4))."""
+    u_ref = np.array([0.0, 0.0, GZ, 0.0])
+    du = uk - u_ref
+    cost = float(du @ (pp["q_u"] * du))                       # :209-210
+    r = 2.0 * pp["q_u"] * du
+    Rd = 2.0 * pp["q_u"]
+    q = np.zeros(S_DIM)
+    Q = np.zeros((S_DIM, S_DIM))
+    if k >= N - 1:                                             # :168-170 goal stage
+        d = xk1 - pp["target"]
+        cost += float(d @ (pp["q_goal"] * d))
+        q = 2.0 * pp["q_goal"] * d
+        Q = np.diag(2.0 * pp["q_goal"])
+    else:                                                      # :171-208
+        ref = pp["ref"][k]
+        R = rot_of_ref(ref[3])
+        d = xk1 - ref
+        y = R @ d
+        cost += float(y @ (pp["q_pen"] * y))
+        q = 2.0 * R.T @ (pp["q_pen"] * y)
+        Q = 2.0 * R.T @ np.diag(pp["q_pen"]) @ R
+        c, g6, H6 = collide_terms(xk1[0:3], xk1[4:7], pp["obs"][k], pp["lam"], pp["radius"],
+                                  want_derivs)
+        cost += c
+        if want_derivs:
+            q = q.copy()
+            q[PV] += g6
+            Q = Q.copy()
+            Q[np.ix_(PV, PV)] += H6
+    return cost, q, Q, r, Rd
+
+
+# ----------------------------------------------------------------------------------------------
+# the five plugin functions (multiple-shooting form) -- dense, for testing
+# ----------------------------------------------------------------------------------------------
+def unpack_w(w, N):
+    w = np.asarray(w, dtype=np.float64)
+    X = np.zeros((N + 1, S_DIM))
+    U = np.zeros((N, U_DIM))
+    for k in range(N):
+        X[k] = w[14 * k:14 * k + 10]
+        U[k] = w[14 * k + 10:14 * k + 14]
+    X[N] = w[14 * N:14 * N + 10]
+    return X, U
+
+
+def pack_w(X, U):
+    N = U.shape[0]
+    w = np.zeros(10 + 14 * N)
+    for k in range(N):
+        w[14 * k:14 * k + 10] = X[k]
+        w[14 * k + 10:14 * k + 14] = U[k]
+    w[14 * N:] = X[N]
+    return w
+
+
+def nlp_f(w, P, N, K):
+    pp = split_p(P, N, K)
+    X, U = unpack_w(w, N)
+    return sum(stage_cost(k, N, X[k + 1], U[k], pp, False)[0] for k in range(N))
+
+
+def nlp_grad_f(w, P, N, K):
+    pp = split_p(P, N, K)
+    X, U = unpack_w(w, N)
+    gX = np.zeros_like(X)
+    gU = np.zeros_like(U)
+    for k in range(N):
+        _, q, _, r, _ = stage_cost(k, N, X[k + 1], U[k], pp)
+        gX[k + 1] = q
+        gU[k] = r
+    return pack_w(gX, gU)
+
+
+def nlp_hess_f(w, P, N, K):
+    pp = split_p(P, N, K)
+    X, U = unpack_w(w, N)
+    nx = 10 + 14 * N
+    H = np.zeros((nx, nx))
+    for k in range(N):
+        _, _, Q, _, Rd = stage_cost(k, N, X[k + 1], U[k], pp)
+        ix = slice(14 * (k + 1), 14 * (k + 1) + 10)
+        iu = slice(14 * k + 10, 14 * k + 14)
+        H[ix, ix] = Q
+        H[iu, iu] = np.diag(Rd)
+    return H
+
+
+def nlp_g(w, P, N, K, dt):
+    pp = split_p(P, N, K)
+    X, U = unpack_w(w, N)
+    g = [X[0] - pp["x_init"]]
+    for k in range(N):
+        g.append(rk4_step(X[k], U[k], pp["tau"], dt) - X[k + 1])
+    return np.concatenate(g)
+
+
+def nlp_jac_g(w, P, N, K, dt):
+    pp = split_p(P, N, K)
+    A, B, _ = affine_dynamics(pp["tau"], dt)
+    nx = 10 + 14 * N
+    J = np.zeros((10 + 10 * N, nx))
+    J[0:10, 0:10] = np.eye(10)
+    for k in range(N):
+        rows = slice(10 + 10 * k, 20 + 10 * k)
+        J[rows, 14 * k:14 * k + 10] = A
+        J[rows, 14 * k + 10:14 * k + 14] = B
+        J[rows, 14 * (k + 1):14 * (k + 1) + 10] = -np.eye(10)
+    return J
+
+
+# ----------------------------------------------------------------------------------------------
+# solver: feasible-start primal-dual interior point with a Riccati (stage-wise) Newton solve.
+#
+# The reference hands the NLP to IPOPT (HighLvlMpc.cpp:17-23: tol 1e-4, max_iter 10, primal warm
+# start).  The only solver-independent contract is the KKT point; this solver is the algorithm the
+# HIP kernel implements line by line (avoid_mpc_amd/csrc/mpc_solve.hip) so that GPU-vs-oracle
+# parity is tight.  Because F is affine, the shooting defects are eliminated exactly
+# (X = rollout(U)); the remaining problem is box-constrained in U and each Newton system is an LQR
+# problem solved by a backward/forward Riccati sweep.
+# ----------------------------------------------------------------------------------------------
+class IpmOptions:
+    def __init__(self, tol=1e-4, max_iter=10, mu_init=0.1, bound_push=1e-3, bound_frac=1e-3,
+                 kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, eta_phi=1e-8,
+                 max_ls=12, s_max=100.0, kappa_sigma=1e10):
+        self.__dict__.update(locals())
+        del self.__dict__["self"]
+
+
+def rollout(x0, U, A, B, c):
+    N = U.shape[0]
+    X = np.zeros((N + 1, S_DIM))
+    X[0] = x0
+    for k in range(N):
+        X[k + 1] = A @ X[k] + B @ U[k] + c
+    return X
+
+
+def total_cost(X, U, pp, N, derivs):
+    J = 0.0
+    q = np.zeros((N + 1, S_DIM)); Q = np.zeros((N + 1, S_DIM, S_DIM))
+    r = np.zeros((N, U_DIM)); Rd = np.zeros((N, U_DIM))
+    for k in range(N):
+        ck, qk, Qk, rk, Rdk = stage_cost(k, N, X[k + 1], U[k], pp, derivs)
+        J += ck
+        q[k + 1], Q[k + 1], r[k], Rd[k] = qk, Qk, rk, Rdk
+    return J, q, Q, r, Rd
+
+
+def riccati(A, B, q, Q, r, Rdiag, delta):
+    """Solve  min 1/2 dU'(R)dU + r'dU + 1/2 dX'Q dX + q'dX,  dX_0=0, dX_{k+1}=A dX_k+B dU_k.
+    Returns (ok, dU, dX, pvec) -- ok False when some Quu_k is not positive definite."""
+    N = r.shape[0]
+    P = Q[N] + delta * np.eye(S_DIM)
+    p = q[N].copy()
+    Ks = np.zeros((N, U_DIM, S_DIM)); ds = np.zeros((N, U_DIM))
+    for k in range(N - 1, -1, -1):
+        PB = P @ B
+        Quu = np.diag(Rdiag[k] + delta) + B.T @ PB
+        Qux = PB.T @ A
+        qu = r[k] + B.T @ p
+        try:
+            L = np.linalg.cholesky(Quu)
+        except np.linalg.LinAlgError:
+            return False, None, None
+        Kk = -np.linalg.solve(L.T, np.linalg.solve(L, Qux))
+        dk = -np.linalg.solve(L.T, np.linalg.solve(L, qu))
+        Ks[k], ds[k] = Kk, dk
+        if k > 0:
+            Pn = Q[k] + delta * np.eye(S_DIM) + A.T @ P @ A + Qux.T @ Kk
+            pn = q[k] + A.T @ p + Qux.T @ dk
+            P = 0.5 * (Pn + Pn.T)
+            p = pn
+    dU = np.zeros((N, U_DIM)); dX = np.zeros((N + 1, S_DIM))
+    for k in range(N):
+        dU[k] = Ks[k] @ dX[k] + ds[k]
+        dX[k + 1] = A @ dX[k] + B @ dU[k]
+    return True, dU, dX
+
+
+def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
+    """Returns (w, info).  w0 is the primal warm start in the reference's layout (only its U part
+    matters: X is the rollout of U from x_init).  lbu/ubu: (4,) control bounds
+    (HighLvlMpc.cpp:70-92)."""
+    opt = opt or IpmOptions()
+    pp = split_p(P, N, K)
+    A, B, c = affine_dynamics(pp["tau"], dt)
+    _, U = unpack_w(w0, N)
+    lb = np.tile(np.asarray(lbu, float), (N, 1)); ub = np.tile(np.asarray(ubu, float), (N, 1))
+    # push the warm start into the interior (IPOPT warm_start_bound_push/frac = 1e-3)
+    pl = np.minimum(opt.bound_push * np.maximum(1.0, np.abs(lb)), opt.bound_frac * (ub - lb))
+    pu = np.minimum(opt.bound_push * np.maximum(1.0, np.abs(ub)), opt.bound_frac * (ub - lb))
+    U = np.minimum(np.maximum(U, lb + pl), ub - pu)
+    mu = opt.mu_init
+    zl = mu / (U - lb); zu = mu / (ub - U)
+    delta_last = 0.0
+    X = rollout(pp["x_init"], U, A, B, c)
+    info = dict(iters=0, status=1, mu=mu, err=np.inf, n_reg=0, ls_fail=0)
+    nvar = U.size
+
+    def barrier(Uc, Jc, mu_):
+        return Jc - mu_ * np.sum(np.log(Uc - lb)) - mu_ * np.sum(np.log(ub - Uc))
+
+    for it in range(opt.max_iter + 1):
+        J, q, Q, r, Rd = total_cost(X, U, pp, N, True)
+        # reduced gradient by the adjoint sweep
+        lam = q[N].copy()
+        gU = np.zeros_like(U)
+        for k in range(N - 1, -1, -1):
+            gU[k] = r[k] + B.T @ lam
+            if k > 0:
+                lam = q[k] + A.T @ lam
+        sl = U - lb; su = ub - U
+
+        def kkt_err(mu_):
+            s_d = max(opt.s_max, (np.sum(zl) + np.sum(zu)) / (2 * nvar)) / opt.s_max
+            e_d = np.max(np.abs(gU - zl + zu)) / s_d
+            e_c = max(np.max(np.abs(sl * zl - mu_)), np.max(np.abs(su * zu - mu_))) / s_d
+            return max(e_d, e_c)
+
+        err0 = kkt_err(0.0)
+        info.update(iters=it, err=err0, mu=mu, cost=J)
+        if trace is not None:
+            trace.append(dict(it=it, J=J, err=err0, mu=mu))
+        if err0 <= opt.tol:
+            info["status"] = 0
+            break
+        if it == opt.max_iter:
+            break
+        # barrier update (monotone, IPOPT eq. (7))
+        while kkt_err(mu) <= opt.kappa_eps * mu and mu > opt.tol / 10.0:
+            mu = max(opt.tol / 10.0, min(opt.kappa_mu * mu, mu ** opt.theta_mu))
+        tau = max(opt.tau_min, 1.0 - mu)
+        Sig = zl / sl + zu / su
+        rbar = gU_bar = None
+        # Newton rhs in stage form: r_k - mu/sl + mu/su  (q unchanged)
+        rb = r - mu / sl + mu / su
+        delta = 0.0
+        ok, dU, dX = riccati(A, B, q, Q, rb, Rd + Sig, delta)
+        while not ok:
+            if delta == 0.0:
+                delta = 1e-4 if delta_last == 0.0 else max(1e-20, delta_last / 3.0)
+            else:
+                delta = delta * (100.0 if delta_last == 0.0 else 8.0)
+            info["n_reg"] += 1
+            if delta > 1e20:
+                raise RuntimeError("regularisation blew up")
+            ok, dU, dX = riccati(A, B, q, Q, rb, Rd + Sig, delta)
+        if delta > 0.0:
+            delta_last = delta
+        dzl = mu / sl - zl - (zl / sl) * dU
+        dzu = mu / su - zu + (zu / su) * dU
+        # fraction to the boundary
+        def max_step(v, dv):
+            m = dv < 0
+            return min(1.0, np.min(-tau * v[m] / dv[m])) if np.any(m) else 1.0
+        a_pr = min(max_step(sl, dU), max_step(su, -dU))
+        a_du = min(max_step(zl, dzl), max_step(zu, dzu))
+        # backtracking Armijo on the barrier function (always feasible => no filter needed)
+        phi0 = barrier(U, J, mu)
+        dphi = np.sum((gU - mu / sl + mu / su) * dU)
+        a = a_pr
+        accepted = False
+        for _ in range(opt.max_ls):
+            Ut = U + a * dU
+            Xt = rollout(pp["x_init"], Ut, A, B, c)
+            Jt = total_cost(Xt, Ut, pp, N, False)[0]
+            if barrier(Ut, Jt, mu) <= phi0 + opt.eta_phi * a * dphi:
+                accepted = True
+                break
+            a *= 0.5
+        if not accepted:
+            info["ls_fail"] += 1
+        U, X = Ut, Xt
+        zl = zl + a_du * dzl; zu = zu + a_du * dzu
+        # keep duals in the IPOPT safeguard box (eq. (16))
+        sl = U - lb; su = ub - U
+        zl = np.maximum(np.minimum(zl, opt.kappa_sigma * mu / sl), mu / (opt.kappa_sigma * sl))
+        zu = np.maximum(np.minimum(zu, opt.kappa_sigma * mu / su), mu / (opt.kappa_sigma * su))
+    return pack_w(X, U), info
