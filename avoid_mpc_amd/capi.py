@@ -1,0 +1,119 @@
+"""ctypes binding of include/avoid_mpc_amd.h (the C ABI of libavoid_mpc_amd.so).
+
+This is the only way Python reaches the hot path; there is no Python/torch/CPU fallback: if the
+HIP library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libavoid_mpc_amd.so")
+
+AMK_OK = 0
+AMK_MAX_K = 64
+AMK_MAX_QUERIES = 64
+AMK_MAX_HORIZON = 32
+AMK_MAX_OUTER_ITER = 8
+
+# every symbol include/avoid_mpc_amd.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "amk_version", "amk_status_string", "amk_last_hip_error", "amk_device_count",
+    "amk_kd_create", "amk_kd_destroy", "amk_kd_build", "amk_kd_sizes", "amk_kd_search",
+    "amk_kd_build_host", "amk_kd_search_host",
+    "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
+    "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
+    "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_solve",
+    "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
+    "amk_mpc_solve_host", "amk_step_batch",
+]
+
+
+class AmkError(RuntimeError):
+    pass
+
+
+class StepParams(C.Structure):
+    _fields_ = [("speed", C.c_double), ("safety_distance", C.c_double),
+                ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the HIP library; raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AmkError(f"{LIB_PATH} is missing: build it with `python -m avoid_mpc_amd.build` "
+                       "(hipcc, gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i, d, ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
+    sig = {
+        "amk_version": (i, []),
+        "amk_status_string": (C.c_char_p, [i]),
+        "amk_last_hip_error": (i, []),
+        "amk_device_count": (i, []),
+        "amk_kd_create": (i, [i, i, C.POINTER(vp)]),
+        "amk_kd_destroy": (i, [vp]),
+        "amk_kd_build": (i, [vp, vp, i, ll, vp, vp]),
+        "amk_kd_sizes": (i, [vp, vp, vp]),
+        "amk_kd_search": (i, [vp, vp, i, i, vp, vp, vp, vp, vp]),
+        "amk_kd_build_host": (i, [vp, vp, i, ll, vp]),
+        "amk_kd_search_host": (i, [vp, vp, i, i, vp, vp, vp, vp]),
+        "amk_mpc_create": (i, [d, d, i, i, C.POINTER(vp)]),
+        "amk_mpc_destroy": (i, [vp]),
+        "amk_mpc_horizon": (i, [vp]),
+        "amk_mpc_nx": (i, [vp]),
+        "amk_mpc_ref_len": (i, [vp]),
+        "amk_mpc_setup_weights": (i, [vp, vp]),
+        "amk_mpc_setup_tau": (i, [vp, vp]),
+        "amk_mpc_setup_gains": (i, [vp, vp]),
+        "amk_mpc_set_drone_radius": (i, [vp, d]),
+        "amk_mpc_set_drone_accel_limits": (i, [vp, d, d, d, d]),
+        "amk_mpc_set_solver_options": (i, [vp, d, i]),
+        "amk_mpc_solve": (i, [vp, vp, vp, vp, vp, i, vp]),
+        "amk_mpc_get_warm_start": (i, [vp, vp, vp]),
+        "amk_mpc_set_warm_start": (i, [vp, vp, vp]),
+        "amk_mpc_reset_warm_start": (i, [vp, vp]),
+        "amk_mpc_solve_host": (i, [vp, vp, vp, vp, vp, i]),
+        "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            continue  # reported by check_symbols()
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def missing_symbols():
+    lib = load()
+    return [s for s in SYMBOLS if not hasattr(lib, s)]
+
+
+def check(status, what=""):
+    if status != AMK_OK:
+        lib = load()
+        msg = lib.amk_status_string(status).decode()
+        raise AmkError(f"{what}: {msg} (status {status}, hipError {lib.amk_last_hip_error()})")
+
+
+def dptr(t):
+    """Device pointer of a torch tensor (None -> NULL).  Tensor must be contiguous and on the GPU."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AmkError("expected a device tensor")
+    if not t.is_contiguous():
+        raise AmkError("expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)

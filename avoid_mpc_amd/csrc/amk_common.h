@@ -1,0 +1,67 @@
+// Internal helpers shared by the HIP translation units of libavoid_mpc_amd.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+
+#include "../../include/avoid_mpc_amd.h"
+
+namespace amk {
+
+extern thread_local int g_last_hip_error;
+
+inline int hip_fail(hipError_t e) {
+    g_last_hip_error = (int)e;
+    return AMK_ERR_HIP;
+}
+
+#define AMK_HIP(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return amk::hip_fail(_e); \
+    } while (0)
+
+constexpr int kWave = 64;  // CDNA4 wavefront
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// A device buffer that frees itself (handles own their storage; no allocation on the hot path).
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return hipSuccess;
+        return hipMalloc((void **)&p, count * sizeof(T));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    ~DevBuf() { release(); }
+};
+
+}  // namespace amk
+
+// ------------------------------------------------------------------------------------------------
+// handle layouts (shared between kd_index.hip, mpc_solve.hip and step.hip)
+// ------------------------------------------------------------------------------------------------
+struct amk_kd {
+    int n_scenes = 0;
+    int max_points = 0;
+    int cap = 0;  // per-scene SoA capacity, multiple of 256 with >= 256 floats of NaN padding
+    amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded
+    amk::DevBuf<int> size;       // [S] cloud.pts.size() after the NaN-x filter
+    // staging for the *_host conveniences
+    amk::DevBuf<float> stage_xyz;
+    amk::DevBuf<int> stage_counts;
+    amk::DevBuf<double> stage_q, stage_d2;
+    amk::DevBuf<int> stage_idx, stage_cnt;
+    amk::DevBuf<float> stage_pts;
+};

@@ -1,0 +1,346 @@
+// KD index of the Avoid-MPC hot path for gfx950 (MI355X): batch of KDTreeTwo<double> objects.
+//
+// Replaces (AM = roswrapper/ros/src/avoid_mpc in the reference tree):
+//   amk_kd_build   <- KDTreeTwo::InitializeNew      AM/include/kd_tree_two.h:76-78,88-106
+//                     (+ nanoflann buildIndex       AM/include/nanoflann_two.hpp:1518-1541)
+//   amk_kd_search  <- KDTreeTwo::SearchForNearest   AM/include/kd_tree_two.h:108-133
+//                     (+ nanoflann findNeighbors    AM/include/nanoflann_two.hpp:1563-1586)
+//
+// Design: the reference asks <= 3*(N+2) ~ 100 queries of a freshly built tree per
+// depth frame.  On a GPU the cheapest exact "index" for that query count is the cloud itself in a
+// scan-friendly layout: build = one streaming pass (NaN-x filter, order-preserving compaction,
+// AoS -> SoA, NaN padding), search = one wavefront per (scene, query group) streaming the SoA cloud
+// with coalesced 16-byte loads, a wave-uniform k-th-best threshold held in scalar registers, a
+// ballot to find the (rare) lanes that beat it and a shuffle-based insertion into a sorted top-k
+// list that lives in lanes 0..k-1.  Only *results* must equal the reference's;
+// the tree shape is free.
+#include "amk_common.h"
+
+namespace amk {
+thread_local int g_last_hip_error = 0;
+}
+
+using amk::kWave;
+
+// ------------------------------------------------------------------------------------------------
+// build: order-preserving compaction of the points whose x is not NaN (kd_tree_two.h:96-101)
+// ------------------------------------------------------------------------------------------------
+constexpr int kCompactThreads = 1024;
+
+__global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
+    const float *__restrict__ xyz, int point_stride, long long scene_stride,
+    const int *__restrict__ counts, int max_points, float *__restrict__ X, float *__restrict__ Y,
+    float *__restrict__ Z, int cap, int *__restrict__ size_out) {
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, w = tid >> 6;
+    const float *src = xyz + (long long)s * scene_stride;
+    float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+    int n = counts ? counts[s] : max_points;
+    n = n < 0 ? 0 : (n > max_points ? max_points : n);
+
+    __shared__ int wave_tot[kCompactThreads / kWave];
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
+        const int i = c0 + tid;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        bool valid = false;
+        if (i < n) {
+            const float *p = src + (size_t)i * point_stride;
+            px = p[0];
+            py = p[1];
+            pz = p[2];
+            valid = !(px != px);  // only x is tested by the reference
+        }
+        const unsigned long long m = __ballot(valid);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < kCompactThreads / kWave; ++j) {
+            const int t = wave_tot[j];
+            woff += (j < w) ? t : 0;
+            tot += t;
+        }
+        if (valid) {
+            const int o = base + woff + prefix;
+            xs[o] = px;
+            ys[o] = py;
+            zs[o] = pz;
+        }
+        base += tot;
+        __syncthreads();
+    }
+    const float qnan = __builtin_nanf("");
+    for (int i = base + tid; i < cap; i += kCompactThreads) {
+        xs[i] = qnan;
+        ys[i] = qnan;
+        zs[i] = qnan;
+    }
+    if (tid == 0) size_out[s] = base;
+}
+
+// ------------------------------------------------------------------------------------------------
+// search: streaming exact kNN, one wavefront per (scene, group of QPW queries)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sq_dist(double qx, double qy, double qz, float px, float py, float pz) {
+    // kd_tree_two.h:24-27 / nanoflann_two.hpp:590-598: r = d0*d0; r += d1*d1; r += d2*d2.  Contraction
+    // into FMAs must stay off here (HIP's __dmul_rn/__dadd_rn do contract): the squared distances are
+    // part of the bit-exact contract.
+#pragma clang fp contract(off)
+    const double d0 = qx - (double)px;
+    const double d1 = qy - (double)py;
+    const double d2 = qz - (double)pz;
+    double r = d0 * d0;
+    r = r + d1 * d1;
+    r = r + d2 * d2;
+    return r;
+}
+
+__device__ __forceinline__ double shfl_up1_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_up(lo, 1);
+    hi = __shfl_up(hi, 1);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
+template <int QPW>
+__global__ __launch_bounds__(kWave) void kd_scan_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
+    const int *__restrict__ sizes, int n_scenes, const double *__restrict__ queries, int n_queries,
+    int k, int *__restrict__ out_idx, double *__restrict__ out_d2, float *__restrict__ out_pts,
+    int *__restrict__ out_cnt) {
+    // XCD-aware placement: the dispatcher puts block b on XCD b % 8, so all query groups of one
+    // scene are mapped to the same XCD and share that XCD's L2 copy of the scene's cloud.
+    const int groups = (n_queries + QPW - 1) / QPW;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / groups) * 8 + xcd;
+    const int g = j % groups;
+    if (s >= n_scenes) return;
+    const int lane = threadIdx.x;
+    const int size = sizes[s];
+    const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+
+    double qx[QPW], qy[QPW], qz[QPW], tau[QPW];
+    double ld[QPW];  // lane i < k: i-th best squared distance
+    int li[QPW];     //             and its index
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq) {
+        int q = g * QPW + qq;
+        q = q < n_queries ? q : n_queries - 1;  // tail group recomputes the last query; not stored
+        const double *qp = queries + ((size_t)s * n_queries + q) * 3;
+        qx[qq] = qp[0];
+        qy[qq] = qp[1];
+        qz[qq] = qp[2];
+        tau[qq] = DBL_MAX;  // KNNResultSet::init, nanoflann_two.hpp:196-202
+        ld[qq] = DBL_MAX;
+        li[qq] = 0x7fffffff;
+    }
+
+    for (int base = 0; base < size; base += 4 * kWave) {
+        const int i0 = base + 4 * lane;
+        const float4 x4 = *reinterpret_cast<const float4 *>(xs + i0);
+        const float4 y4 = *reinterpret_cast<const float4 *>(ys + i0);
+        const float4 z4 = *reinterpret_cast<const float4 *>(zs + i0);
+        const float px[4] = {x4.x, x4.y, x4.z, x4.w};
+        const float py[4] = {y4.x, y4.y, y4.z, y4.w};
+        const float pz[4] = {z4.x, z4.y, z4.z, z4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+#pragma unroll
+            for (int qq = 0; qq < QPW; ++qq) {
+                const double d = sq_dist(qx[qq], qy[qq], qz[qq], px[e], py[e], pz[e]);
+                // NaN padding / NaN coordinates compare false, as in the reference's dist < worst
+                unsigned long long m = __ballot(d <= tau[qq]);
+                while (m) {  // rare: a lane beats (or ties) the current k-th best
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double dc = readlane_f64(d, src);
+                    const int ic = base + 4 * src + e;
+                    // rank of the candidate in (distance, index) order among the kept entries
+                    const bool lt = (lane < k) && (ld[qq] < dc || (ld[qq] == dc && li[qq] < ic));
+                    const int pos = __popcll(__ballot(lt));
+                    if (pos < k && dc < DBL_MAX) {
+                        const double up_d = shfl_up1_f64(ld[qq]);
+                        const int up_i = __shfl_up(li[qq], 1);
+                        if (lane > pos) {
+                            ld[qq] = up_d;
+                            li[qq] = up_i;
+                        } else if (lane == pos) {
+                            ld[qq] = dc;
+                            li[qq] = ic;
+                        }
+                        tau[qq] = readlane_f64(ld[qq], k - 1);
+                    }
+                }
+            }
+        }
+    }
+
+    // KDTreeTwo::SearchForNearest count rule, kd_tree_two.h:119-124
+    const int cnt = size < k ? size : (size > k ? k : 0);
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq) {
+        const int q = g * QPW + qq;
+        if (q >= n_queries) break;
+        const size_t row = (size_t)s * n_queries + q;
+        if (lane == 0 && out_cnt) out_cnt[row] = cnt;
+        if (lane < k) {
+            const bool ok = lane < cnt && li[qq] != 0x7fffffff;
+            const int idx = ok ? li[qq] : -1;
+            if (out_idx) out_idx[row * k + lane] = idx;
+            if (out_d2) out_d2[row * k + lane] = ok ? ld[qq] : DBL_MAX;
+            if (out_pts) {
+                float *o = out_pts + (row * k + lane) * 3;
+                o[0] = ok ? xs[idx] : 0.f;
+                o[1] = ok ? ys[idx] : 0.f;
+                o[2] = ok ? zs[idx] : 0.f;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+int amk_version(void) { return 100; }
+
+const char *amk_status_string(int status) {
+    switch (status) {
+        case AMK_OK: return "ok";
+        case AMK_ERR_INVALID_ARG: return "invalid argument";
+        case AMK_ERR_HIP: return "HIP runtime error";
+        case AMK_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
+        case AMK_ERR_UNSUPPORTED: return "unsupported size";
+        default: return "unknown status";
+    }
+}
+
+int amk_last_hip_error(void) { return amk::g_last_hip_error; }
+
+int amk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
+    if (!out || n_scenes <= 0 || max_points < 0) return AMK_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
+    amk_kd *kd = new amk_kd();
+    kd->n_scenes = n_scenes;
+    kd->max_points = max_points;
+    kd->cap = amk::round_up(max_points, 256) + 256;
+    const size_t tot = (size_t)n_scenes * kd->cap;
+    hipError_t e;
+    if ((e = kd->x.alloc(tot)) != hipSuccess || (e = kd->y.alloc(tot)) != hipSuccess ||
+        (e = kd->z.alloc(tot)) != hipSuccess || (e = kd->size.alloc(n_scenes)) != hipSuccess) {
+        delete kd;
+        return amk::hip_fail(e);
+    }
+    if ((e = hipMemset(kd->size.p, 0, sizeof(int) * n_scenes)) != hipSuccess) {
+        delete kd;
+        return amk::hip_fail(e);
+    }
+    *out = kd;
+    return AMK_OK;
+}
+
+int amk_kd_destroy(amk_kd *kd) {
+    if (!kd) return AMK_ERR_INVALID_ARG;
+    delete kd;
+    return AMK_OK;
+}
+
+int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
+                 const int *d_counts, void *stream) {
+    if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kd_compact_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
+                       point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
+                       kd->size.p);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+int amk_kd_sizes(amk_kd *kd, int *h_sizes, void *stream) {
+    if (!kd || !h_sizes) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipMemcpyAsync(h_sizes, kd->size.p, sizeof(int) * kd->n_scenes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    AMK_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return AMK_OK;
+}
+
+int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int *d_indices, double *d_sqdist,
+                  float *d_pts, int *d_counts, void *stream) {
+    if (!kd || !d_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
+    if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
+    // Two queries per wavefront halve the cloud traffic and the f32->f64 conversions per distance;
+    // single queries (GetNearestDistance, the edge snap) run one per wavefront.
+    const int qpw = n_queries >= 2 ? 2 : 1;
+    const int groups = (n_queries + qpw - 1) / qpw;
+    const int blocks = (kd->n_scenes + 7) / 8 * 8 * groups;
+    if (qpw == 2)
+        hipLaunchKernelGGL(kd_scan_kernel<2>, dim3(blocks), dim3(kWave), 0, (hipStream_t)stream, kd->x.p, kd->y.p,
+                           kd->z.p, kd->cap, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist,
+                           d_pts, d_counts);
+    else
+        hipLaunchKernelGGL(kd_scan_kernel<1>, dim3(blocks), dim3(kWave), 0, (hipStream_t)stream, kd->x.p, kd->y.p,
+                           kd->z.p, kd->cap, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist,
+                           d_pts, d_counts);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+int amk_kd_build_host(amk_kd *kd, const float *h_xyz, int point_stride, long long scene_stride, const int *h_counts) {
+    if (!kd || (!h_xyz && kd->max_points > 0) || point_stride < 3) return AMK_ERR_INVALID_ARG;
+    const long long min_stride = (long long)kd->max_points * point_stride;
+    if (scene_stride < min_stride && kd->n_scenes > 1) return AMK_ERR_INVALID_ARG;
+    const size_t tot = (size_t)(kd->n_scenes - 1) * scene_stride + (size_t)min_stride;
+    if (kd->stage_xyz.n < tot) AMK_HIP(kd->stage_xyz.alloc(tot > 0 ? tot : 1));
+    if (tot) AMK_HIP(hipMemcpy(kd->stage_xyz.p, h_xyz, tot * sizeof(float), hipMemcpyHostToDevice));
+    const int *d_counts = nullptr;
+    if (h_counts) {
+        if (kd->stage_counts.n < (size_t)kd->n_scenes) AMK_HIP(kd->stage_counts.alloc(kd->n_scenes));
+        AMK_HIP(hipMemcpy(kd->stage_counts.p, h_counts, sizeof(int) * kd->n_scenes, hipMemcpyHostToDevice));
+        d_counts = kd->stage_counts.p;
+    }
+    int st = amk_kd_build(kd, kd->stage_xyz.p, point_stride, scene_stride, d_counts, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    return AMK_OK;
+}
+
+int amk_kd_search_host(amk_kd *kd, const double *h_queries, int n_queries, int k, int *h_indices, double *h_sqdist,
+                       float *h_pts, int *h_counts) {
+    if (!kd || !h_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
+    if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
+    const size_t rows = (size_t)kd->n_scenes * n_queries;
+    if (kd->stage_q.n < rows * 3) AMK_HIP(kd->stage_q.alloc(rows * 3));
+    if (kd->stage_idx.n < rows * k) AMK_HIP(kd->stage_idx.alloc(rows * k));
+    if (kd->stage_d2.n < rows * k) AMK_HIP(kd->stage_d2.alloc(rows * k));
+    if (kd->stage_pts.n < rows * k * 3) AMK_HIP(kd->stage_pts.alloc(rows * k * 3));
+    if (kd->stage_cnt.n < rows) AMK_HIP(kd->stage_cnt.alloc(rows));
+    AMK_HIP(hipMemcpy(kd->stage_q.p, h_queries, rows * 3 * sizeof(double), hipMemcpyHostToDevice));
+    int st = amk_kd_search(kd, kd->stage_q.p, n_queries, k, kd->stage_idx.p, kd->stage_d2.p, kd->stage_pts.p,
+                           kd->stage_cnt.p, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    if (h_indices) AMK_HIP(hipMemcpy(h_indices, kd->stage_idx.p, rows * k * sizeof(int), hipMemcpyDeviceToHost));
+    if (h_sqdist) AMK_HIP(hipMemcpy(h_sqdist, kd->stage_d2.p, rows * k * sizeof(double), hipMemcpyDeviceToHost));
+    if (h_pts) AMK_HIP(hipMemcpy(h_pts, kd->stage_pts.p, rows * k * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    if (h_counts) AMK_HIP(hipMemcpy(h_counts, kd->stage_cnt.p, rows * sizeof(int), hipMemcpyDeviceToHost));
+    return AMK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""Thin Python objects over the C ABI (include/avoid_mpc_amd.h) used by tests and bench.py.
+
+torch is plumbing here (device buffers, streams); every computation happens in the HIP library.
+The reference-shaped C++ adapters (KDTreeTwo<double>, FrameKDMap, ObstacleAvoidanceMPC) live in
+include/avoid_mpc_amd/*.hpp; these classes are their batched Python twins:
+
+  KdBatch   <- S x KDTreeTwo<double>          AM/include/kd_tree_two.h:53-144
+  MpcBatch  <- S x ObstacleAvoidanceMPC       AM/include/HighLvlMpc.h:4-33
+  step_batch<- TASK branch of Step            AM/src/AvoidanceStateMachine.cpp:322-355
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        raise capi.AmkError("no GPU visible: the hot path has no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class KdBatch:
+    def __init__(self, n_scenes, max_points):
+        self.lib = capi.load()
+        self.S, self.max_points = int(n_scenes), int(max_points)
+        h = C.c_void_p()
+        capi.check(self.lib.amk_kd_create(self.S, self.max_points, C.byref(h)), "amk_kd_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amk_kd_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def build(self, xyz, counts=None, stream=None):
+        """InitializeNew: xyz float32 device tensor [S, max_points, 3|4]; counts int32 [S] or None."""
+        assert xyz.dtype == torch.float32 and xyz.dim() == 3 and xyz.shape[0] == self.S
+        assert xyz.shape[1] >= self.max_points or self.max_points == 0
+        if counts is not None:
+            assert counts.dtype == torch.int32 and counts.numel() == self.S
+        capi.check(self.lib.amk_kd_build(self.h, capi.dptr(xyz), int(xyz.shape[2]),
+                                         int(xyz.shape[1] * xyz.shape[2]), capi.dptr(counts),
+                                         capi.stream_ptr(stream)), "amk_kd_build")
+
+    def sizes(self, stream=None):
+        out = np.zeros(self.S, np.int32)
+        capi.check(self.lib.amk_kd_sizes(self.h, out.ctypes.data_as(C.c_void_p), capi.stream_ptr(stream)),
+                   "amk_kd_sizes")
+        return out
+
+    def search(self, queries, k, want_pts=True, stream=None, out=None):
+        """SearchForNearest for queries float64 [S, Q, 3] -> dict(indices, sqdist, pts, counts)."""
+        assert queries.dtype == torch.float64 and queries.shape[0] == self.S and queries.shape[2] == 3
+        Q = int(queries.shape[1])
+        dev = queries.device
+        if out is None:
+            out = dict(indices=torch.empty((self.S, Q, k), dtype=torch.int32, device=dev),
+                       sqdist=torch.empty((self.S, Q, k), dtype=torch.float64, device=dev),
+                       pts=torch.empty((self.S, Q, k, 3), dtype=torch.float32, device=dev) if want_pts else None,
+                       counts=torch.empty((self.S, Q), dtype=torch.int32, device=dev))
+        capi.check(self.lib.amk_kd_search(self.h, capi.dptr(queries), Q, int(k), capi.dptr(out["indices"]),
+                                          capi.dptr(out["sqdist"]), capi.dptr(out["pts"]),
+                                          capi.dptr(out["counts"]), capi.stream_ptr(stream)), "amk_kd_search")
+        return out
+
+    # host-buffer conveniences ---------------------------------------------------------------
+    def build_host(self, xyz, counts=None):
+        xyz = np.ascontiguousarray(xyz, np.float32)
+        assert xyz.ndim == 3 and xyz.shape[0] == self.S
+        cp = None
+        if counts is not None:
+            counts = np.ascontiguousarray(counts, np.int32)
+            cp = counts.ctypes.data_as(C.c_void_p)
+        capi.check(self.lib.amk_kd_build_host(self.h, xyz.ctypes.data_as(C.c_void_p), int(xyz.shape[2]),
+                                              int(xyz.shape[1] * xyz.shape[2]), cp), "amk_kd_build_host")
+
+    def search_host(self, queries, k):
+        q = np.ascontiguousarray(queries, np.float64)
+        assert q.ndim == 3 and q.shape[0] == self.S and q.shape[2] == 3
+        Q = q.shape[1]
+        idx = np.zeros((self.S, Q, k), np.int32); d2 = np.zeros((self.S, Q, k), np.float64)
+        pts = np.zeros((self.S, Q, k, 3), np.float32); cnt = np.zeros((self.S, Q), np.int32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(self.lib.amk_kd_search_host(self.h, vp(q), Q, int(k), vp(idx), vp(d2), vp(pts), vp(cnt)),
+                   "amk_kd_search_host")
+        return dict(indices=idx, sqdist=d2, pts=pts, counts=cnt)
+
+
+class MpcBatch:
+    def __init__(self, T, dt, nearest_point_num, n_scenes):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        capi.check(self.lib.amk_mpc_create(float(T), float(dt), int(nearest_point_num), int(n_scenes),
+                                           C.byref(h)), "amk_mpc_create")
+        self.h = h
+        self.S, self.K = int(n_scenes), int(nearest_point_num)
+        self.N = self.lib.amk_mpc_horizon(h)
+        self.nx = self.lib.amk_mpc_nx(h)
+        self.ref_len = self.lib.amk_mpc_ref_len(h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amk_mpc_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _arr(self, v, n):
+        a = np.ascontiguousarray(v, np.float64)
+        assert a.size == n
+        return a.ctypes.data_as(C.c_void_p), a
+
+    def SetupWeights(self, w):
+        p, _k = self._arr(w, 25); capi.check(self.lib.amk_mpc_setup_weights(self.h, p), "SetupWeights")
+
+    def SetupTau(self, tau):
+        p, _k = self._arr(tau, 4); capi.check(self.lib.amk_mpc_setup_tau(self.h, p), "SetupTau")
+
+    def SetupGains(self, g):
+        p, _k = self._arr(g, 4); capi.check(self.lib.amk_mpc_setup_gains(self.h, p), "SetupGains")
+
+    def SetDroneRadius(self, r):
+        capi.check(self.lib.amk_mpc_set_drone_radius(self.h, float(r)), "SetDroneRadius")
+
+    def SetDroneAccelLimits(self, aMinZ, aMaxZ, aMaxXy, aMaxYawDot):
+        capi.check(self.lib.amk_mpc_set_drone_accel_limits(self.h, float(aMinZ), float(aMaxZ), float(aMaxXy),
+                                                           float(aMaxYawDot)), "SetDroneAccelLimits")
+
+    def set_solver_options(self, tol=1e-4, max_iter=10):
+        capi.check(self.lib.amk_mpc_set_solver_options(self.h, float(tol), int(max_iter)), "set_solver_options")
+
+    def configure(self, prm):
+        """SetupMPC (AvoidanceStateMachine.cpp:55-70) from a synth.MpcParams."""
+        self.SetupWeights(prm.weights); self.SetupTau(prm.tau); self.SetupGains(prm.gain)
+        self.SetDroneAccelLimits(prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot)
+        self.SetDroneRadius(prm.radius)
+
+    def Solve(self, ref_states, faster=False, stream=None, want_traj=True):
+        assert ref_states.dtype == torch.float64 and tuple(ref_states.shape) == (self.S, self.ref_len)
+        dev = ref_states.device
+        u = torch.empty((self.S, 4), dtype=torch.float64, device=dev)
+        x0 = torch.empty((self.S, self.N, 14), dtype=torch.float64, device=dev) if want_traj else None
+        info = torch.empty((self.S, 4), dtype=torch.int32, device=dev)
+        capi.check(self.lib.amk_mpc_solve(self.h, capi.dptr(ref_states), capi.dptr(u), capi.dptr(x0),
+                                          capi.dptr(info), int(bool(faster)), capi.stream_ptr(stream)),
+                   "amk_mpc_solve")
+        return u, x0, info
+
+    def get_warm_start(self, stream=None):
+        w = torch.empty((self.S, self.nx), dtype=torch.float64, device=_dev())
+        capi.check(self.lib.amk_mpc_get_warm_start(self.h, capi.dptr(w), capi.stream_ptr(stream)), "get_warm_start")
+        return w
+
+    def set_warm_start(self, w, stream=None):
+        assert w.dtype == torch.float64 and tuple(w.shape) == (self.S, self.nx)
+        capi.check(self.lib.amk_mpc_set_warm_start(self.h, capi.dptr(w), capi.stream_ptr(stream)), "set_warm_start")
+
+    def reset_warm_start(self, stream=None):
+        capi.check(self.lib.amk_mpc_reset_warm_start(self.h, capi.stream_ptr(stream)), "reset_warm_start")
+
+
+def step_batch(kd_obstacle, kd_edge, mpc, prm, state_quad, pos_x, ref_path, stream=None, out=None):
+    """One control step for every scene (amk_step_batch).  ref_path is updated in place."""
+    S, N = mpc.S, mpc.N
+    assert state_quad.dtype == torch.float64 and tuple(state_quad.shape) == (S, prm.max_iter, 10)
+    assert ref_path.dtype == torch.float64 and tuple(ref_path.shape) == (S, N, 10)
+    assert pos_x.dtype == torch.float64 and pos_x.numel() == S
+    dev = ref_path.device
+    if out is None:
+        out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
+                   x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
+                   flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
+    sp = capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0)
+    capi.check(capi.load().amk_step_batch(kd_obstacle.h, kd_edge.h, mpc.h, C.byref(sp), capi.dptr(state_quad),
+                                          capi.dptr(pos_x), capi.dptr(ref_path), capi.dptr(out["u"]),
+                                          capi.dptr(out["x0array"]), capi.dptr(out["flags"]),
+                                          capi.stream_ptr(stream)), "amk_step_batch")
+    return out

@@ -1,0 +1,166 @@
+/* avoid_mpc_amd.h -- C ABI of the MI355X-native Avoid-MPC hot path.
+ *
+ * One shared library (avoid_mpc_amd/libavoid_mpc_amd.so, HIP for gfx950).  Plain pointers and
+ * sizes only; every `d_` pointer is DEVICE memory on the current HIP device, every `h_` pointer is
+ * host memory; `stream` is a hipStream_t passed as void* (NULL = the default stream).  All entry
+ * points return an amk_status and are re-entrant per handle (no global state; the reference's
+ * KDTreeTwo keeps results in members and is not re-entrant, AM/include/kd_tree_two.h:109-111).
+ *
+ * A handle holds a BATCH of S independent objects ("scenes"): scene s of an amk_kd is one
+ * KDTreeTwo<double>, scene s of an amk_mpc is one ObstacleAvoidanceMPC.  S = 1 reproduces the
+ * reference's single-robot use; S >> 1 is how the GPU is filled.
+ *
+ * Reference interfaces replaced (AM = roswrapper/ros/src/avoid_mpc in the reference tree):
+ *   amk_kd_*     AM/include/kd_tree_two.h:53-144   (KDTreeTwo<double>)  and, through it,
+ *                AM/include/nanoflann_two.hpp:1518-1541,1563-1586 (buildIndex / findNeighbors)
+ *   amk_mpc_*    AM/include/HighLvlMpc.h:4-33, AM/src/HighLvlMpc.cpp:5-137 (ObstacleAvoidanceMPC)
+ *                and the plugin it loads (AM/tools/mpc_obstacle_casadi.py:51-242,338-357)
+ *   amk_step_*   AM/src/AvoidanceStateMachine.cpp:204-281,322-355 (TASK branch of Step) with
+ *                AM/src/FrameKDMap.cpp:254-275,322-427 (QueryNearest / GetNearestDistance)
+ * C++ adapters with the reference's class names/signatures: the .hpp files under include/avoid_mpc_amd/.
+ */
+#ifndef AVOID_MPC_AMD_H
+#define AVOID_MPC_AMD_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum amk_status {
+    AMK_OK = 0,
+    AMK_ERR_INVALID_ARG = 1, /* NULL handle, k < 0, size mismatch ...                           */
+    AMK_ERR_HIP = 2,         /* a HIP runtime call failed; see amk_last_hip_error()              */
+    AMK_ERR_NO_DEVICE = 3,   /* no gfx950 device visible: there is NO CPU fallback               */
+    AMK_ERR_UNSUPPORTED = 4  /* e.g. k > AMK_MAX_K, N > AMK_MAX_HORIZON                          */
+} amk_status;
+
+#define AMK_MAX_K 64        /* neighbours per query (reference uses 1, 3, 8, <=10)               */
+#define AMK_MAX_QUERIES 64  /* queries per scene per call (reference: N <= 30 per outer pass)    */
+#define AMK_MAX_HORIZON 32  /* N = int(T/dt); reference default 30                               */
+#define AMK_S_DIM 10        /* [px,py,pz,yaw,vx,vy,vz,ax,ay,az]  mpc_obstacle_casadi.py:41-46    */
+#define AMK_U_DIM 4         /* [ax_cmd,ay_cmd,az_cmd,yaw_dot]    mpc_obstacle_casadi.py:75       */
+
+int amk_version(void);
+const char *amk_status_string(int status);
+int amk_last_hip_error(void); /* hipError_t of the last failing HIP call on this thread          */
+int amk_device_count(void);
+
+/* ------------------------------------------------------------------------------------------ */
+/* KD index: batch of KDTreeTwo<double>                                    kd_tree_two.h:53-144 */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct amk_kd amk_kd;
+
+/* KDTreeTwo() x n_scenes.  max_points = capacity per scene.                                      */
+int amk_kd_create(int n_scenes, int max_points, amk_kd **out);
+int amk_kd_destroy(amk_kd *kd);
+
+/* InitializeNew(cloud) for every scene (kd_tree_two.h:76-78,88-106): the handle COPIES the points
+ * whose x is not NaN (order preserved, :96-101) and builds its index.  Scene s reads
+ * d_xyz[s*scene_stride + i*point_stride + {0,1,2}], i < counts[s]; point_stride = 3 (packed) or
+ * 4 (pcl::PointXYZ's 16-byte layout).  d_counts == NULL means every scene has max_points.       */
+int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
+                 const int *d_counts, void *stream);
+
+/* cloud.pts.size() per scene after the NaN-x filter (synchronises the stream).                   */
+int amk_kd_sizes(amk_kd *kd, int *h_sizes, void *stream);
+
+/* SearchForNearest(x,y,z,n) (kd_tree_two.h:108-133) for n_queries query points per scene.
+ *   d_queries  [S][n_queries][3] double
+ *   d_indices  [S][n_queries][k] int     -> KDTreeTwo::indices            (may be NULL)
+ *   d_sqdist   [S][n_queries][k] double  -> KDTreeTwo::squared_distances  (may be NULL)
+ *   d_pts      [S][n_queries][k][3] float-> KDTreeTwo::closest_pts        (may be NULL)
+ *   d_counts   [S][n_queries]    int     -> number of results, reproducing :119-124 exactly:
+ *                                           size < k -> size ; size > k -> k ; size == k -> 0
+ * Results ascend in squared distance; equal distances order by index (nanoflann orders ties by
+ * tree-traversal order, nanoflann_two.hpp:224-229 -- see DESIGN.md "tie policy").  Slots beyond
+ * the count hold index -1 / distance DBL_MAX / point (0,0,0).  Distances are the IEEE
+ * left-to-right fp64 sums of kd_tree_two.h:24-27 with no FMA contraction.                       */
+int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int *d_indices,
+                  double *d_sqdist, float *d_pts, int *d_counts, void *stream);
+
+/* Host-buffer conveniences (stage through internal device buffers, synchronise).                 */
+int amk_kd_build_host(amk_kd *kd, const float *h_xyz, int point_stride, long long scene_stride,
+                      const int *h_counts);
+int amk_kd_search_host(amk_kd *kd, const double *h_queries, int n_queries, int k, int *h_indices,
+                       double *h_sqdist, float *h_pts, int *h_counts);
+
+/* ------------------------------------------------------------------------------------------ */
+/* MPC: batch of ObstacleAvoidanceMPC                          HighLvlMpc.h:4-33, .cpp:5-137    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct amk_mpc amk_mpc;
+
+/* ObstacleAvoidanceMPC(T, dt, soPath) x n_scenes (HighLvlMpc.cpp:5-57).  The reference bakes
+ * N = int(T/dt) and K = nearest_point_num into the generated plugin behind soPath
+ * (mpc_obstacle_casadi.py:36-37,76-85); here they are constructor arguments.  Defaults after
+ * create are the constructor's: weights/tau/gains of HighLvlMpc.cpp:53-56, control bounds
+ * [-10,-10,1,-10]..[10,10,20,10] (:13-16,29-30), zero warm start (:26-27,35), tol 1e-4,
+ * max_iter 10 (:19-20).                                                                          */
+int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out);
+int amk_mpc_destroy(amk_mpc *mpc);
+int amk_mpc_horizon(const amk_mpc *mpc);   /* N                                                  */
+int amk_mpc_nx(const amk_mpc *mpc);        /* 10 + 14 N                                          */
+int amk_mpc_ref_len(const amk_mpc *mpc);   /* 20 + 10 N + 3 K N  (what GetRefStates produces)    */
+
+int amk_mpc_setup_weights(amk_mpc *mpc, const double *h_weights25); /* SetupWeights  .cpp:58-60  */
+int amk_mpc_setup_tau(amk_mpc *mpc, const double *h_tau4);          /* SetupTau      .cpp:61-63  */
+int amk_mpc_setup_gains(amk_mpc *mpc, const double *h_gains4);      /* SetupGains    .cpp:67-69  */
+int amk_mpc_set_drone_radius(amk_mpc *mpc, double radius);          /* SetDroneRadius .cpp:64-66 */
+int amk_mpc_set_drone_accel_limits(amk_mpc *mpc, double aMinZ, double aMaxZ, double aMaxXy,
+                                   double aMaxYawDot);              /* .cpp:70-92                */
+/* ipopt.tol / ipopt.max_iter of HighLvlMpc.cpp:19-20                                            */
+int amk_mpc_set_solver_options(amk_mpc *mpc, double tol, int max_iter);
+
+/* Solve(vecRefStates, u, x0Array, faster) (HighLvlMpc.cpp:93-137) for every scene.
+ *   d_ref_states [S][20+10N+3KN]  = [x_init | ref_k | obstacles | target]  (GetRefStates layout,
+ *                                    AvoidanceStateMachine.cpp:236-257); gains, taus, weights and
+ *                                    radius are appended internally as in .cpp:97-107
+ *   d_u          [S][4]           = sol[10..13]                         (.cpp:124-128)
+ *   d_x0array    [S][N][14]       = rows [X_k, U_k], k < N              (.cpp:130-136) (may be NULL)
+ *   d_info       [S][4] int       = {status (0 converged, 1 iteration cap), iterations,
+ *                                    regularisations, line-search failures}   (may be NULL)
+ * The full primal solution is kept as the next call's warm start (.cpp:110,129).  The reference
+ * never inspects the solver status (.cpp:116-122); neither does this function -- it reports it.  */
+int amk_mpc_solve(amk_mpc *mpc, const double *d_ref_states, double *d_u, double *d_x0array,
+                  int *d_info, int faster, void *stream);
+
+/* mNlpW0 access: [S][nx] in the reference's decision-vector order [X_0,U_0,...,U_{N-1},X_N].    */
+int amk_mpc_get_warm_start(amk_mpc *mpc, double *d_w, void *stream);
+int amk_mpc_set_warm_start(amk_mpc *mpc, const double *d_w, void *stream);
+int amk_mpc_reset_warm_start(amk_mpc *mpc, void *stream); /* back to the constructor's zeros      */
+
+int amk_mpc_solve_host(amk_mpc *mpc, const double *h_ref_states, double *h_u, double *h_x0array,
+                       int *h_info, int faster);
+
+/* ------------------------------------------------------------------------------------------ */
+/* One control step: TASK branch of AvoidanceStateMachine::Step       AvoidanceStateMachine.cpp */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct amk_step_params {
+    double speed;           /* mSpeed                      mpc_parameters.yaml:46                 */
+    double safety_distance; /* mParamSafteyDistance        mpc_parameters.yaml:56                 */
+    int mpc_max_iter;       /* mParamMPCMaxIter (<= 8)     mpc_parameters.yaml:3                  */
+    int reserved;
+} amk_step_params;
+
+#define AMK_MAX_OUTER_ITER 8
+
+/* For every scene: for iter < mpc_max_iter { PlanWapionts (:259-281) ; ProcessWaypoints
+ * (:204-235) ; early exit (:333-335) ; GetRefStates (:236-257) ; Solve ; refill the reference path
+ * with the predicted states (:338-342) }, all on the device, no host round trip.
+ *   obstacle, edge  the dual KD indices of the current frame (FrameKDMap's mCurFrame.pointCloud /
+ *                   .edgeCloud, FrameKDMap.cpp:44-50); single-frame map (mVecQueryVector = [cur])
+ *   d_state_quad    [S][mpc_max_iter][10]  mVecStateQuad as GetCurStateQuad (:183-203) would give
+ *                   it at the start of each outer iteration (the host owns the clock model)
+ *   d_pos_x         [S]                    mPos.x() used by GetRefStates (:251)
+ *   d_ref_path      [S][N][10] in/out      mRefPath (after GetInitPath on entry)
+ *   d_u             [S][4]                 control of the last solve
+ *   d_x0array       [S][N][14]             predicted trajectory of the last solve (may be NULL)
+ *   d_flags         [S][4] int             {isSafety, solves done, last solver status, total
+ *                                           interior-point iterations}                           */
+int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *params,
+                   const double *d_state_quad, const double *d_pos_x, double *d_ref_path,
+                   double *d_u, double *d_x0array, int *d_flags, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVOID_MPC_AMD_H */

@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol the header declares.
+No compute calls (there is no GPU here and no CPU fallback to call)."""
+import os
+import re
+
+import pytest
+
+from avoid_mpc_amd import build as amk_build
+from avoid_mpc_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    amk_build.build()
+    return capi.load()
+
+
+def test_header_and_binding_agree():
+    hdr = open(os.path.join(ROOT, "include", "avoid_mpc_amd.h")).read()
+    declared = set(re.findall(r"\b(amk_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(capi.SYMBOLS)
+
+
+def test_exports_every_declared_symbol(lib):
+    assert capi.missing_symbols() == []
+    assert lib.amk_version() >= 100
+    assert lib.amk_status_string(0) == b"ok"
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every constructor must fail loudly instead of computing on the host."""
+    import ctypes as C
+    if lib.amk_device_count() > 0:
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    assert lib.amk_kd_create(1, 100, C.byref(h)) == 3      # AMK_ERR_NO_DEVICE
+    assert not h.value
+    assert lib.amk_mpc_create(0.66, 0.033, 8, 1, C.byref(h)) == 3
+    assert not h.value
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "avoid_mpc_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".hpp", ".cpp")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"liboracle|_oracle|oracle/|mpc_oracle|kd_oracle", txt):
+                    bad.append(f)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "include")):
+        for f in files:
+            txt = open(os.path.join(dirpath, f), errors="ignore").read()
+            if re.search(r"liboracle|kdo_|mpco_", txt):
+                bad.append(f)
+    assert bad == []

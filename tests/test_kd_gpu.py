@@ -1,0 +1,144 @@
+"""GPU: the HIP KD path (through the C ABI) against the oracle and the golden vectors.
+Indices bit-exact, squared distances bit-exact (IEEE, no FMA), counts per kd_tree_two.h:119-124."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "kd_golden.npz"))
+FMAX = np.finfo(np.float64).max
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test needs a GPU"
+    return torch
+
+
+def _gpu_search(torch, clouds, queries, k, counts=None, stride=3):
+    """clouds: list of [n_i,3] float32 -> batched device search; returns host arrays."""
+    from avoid_mpc_amd.host import KdBatch
+    S = len(clouds)
+    nmax = max(max(len(c) for c in clouds), 1)
+    buf = np.full((S, nmax, stride), 7.0, np.float32)
+    cnt = np.zeros(S, np.int32)
+    for s, c in enumerate(clouds):
+        buf[s, :len(c), :3] = c
+        cnt[s] = len(c)
+    kd = KdBatch(S, nmax)
+    kd.build(torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda())
+    out = kd.search(torch.from_numpy(np.ascontiguousarray(queries, np.float64)).cuda(), k)
+    torch.cuda.synchronize()
+    res = {n: (v.cpu().numpy() if v is not None else None) for n, v in out.items()}
+    res["sizes"] = kd.sizes()
+    kd.close()
+    return res
+
+
+@pytest.mark.parametrize("name", ["uniform2k", "corridor3k", "tiny5", "nan_x500"])
+def test_golden_small(name, torch_cuda):
+    cloud, qs = G[f"{name}.cloud"], G[f"{name}.queries"]
+    ks = (1, 3, 8) + ((5, 7) if name == "tiny5" else ())
+    for k in ks:
+        r = _gpu_search(torch_cuda, [cloud], qs[None], k)
+        cnt = G[f"{name}.k{k}.counts"]
+        assert np.array_equal(r["counts"][0], cnt)
+        for i in range(len(qs)):
+            c = cnt[i]
+            assert np.array_equal(r["indices"][0, i, :c], G[f"{name}.k{k}.indices"][i, :c])
+            assert np.array_equal(r["sqdist"][0, i, :c].view(np.int64), G[f"{name}.k{k}.sqdist"][i, :c].view(np.int64))
+            assert (r["indices"][0, i, c:] == -1).all() and (r["sqdist"][0, i, c:] == FMAX).all()
+
+
+@pytest.mark.parametrize("tag", ["c1_5k", "c2_50k", "c5_200k"])
+def test_golden_baseline_sizes(tag, torch_cuda):
+    n, seed = (int(v) for v in G[f"{tag}.seed"])
+    cloud, edge = synth.make_cloud(n, seed)
+    qs = G[f"{tag}.queries"]
+    r = _gpu_search(torch_cuda, [cloud], qs[None], 8)
+    assert np.array_equal(r["indices"][0], G[f"{tag}.k8.indices"])
+    assert np.array_equal(r["sqdist"][0].view(np.int64), G[f"{tag}.k8.sqdist"].view(np.int64))
+    assert np.array_equal(r["pts"][0], cloud[G[f"{tag}.k8.indices"]])
+    r = _gpu_search(torch_cuda, [edge], qs[None], 1)
+    assert np.array_equal(r["indices"][0], G[f"{tag}.edge.k1.indices"])
+    assert np.array_equal(r["sqdist"][0].view(np.int64), G[f"{tag}.edge.k1.sqdist"].view(np.int64))
+
+
+def test_batch_ragged_vs_oracle(torch_cuda, oracle):
+    """Many scenes of different sizes (incl. empty, 1 point, NaN-x points), pcl 16-byte stride."""
+    rng = np.random.default_rng(4)
+    sizes = [0, 1, 7, 8, 9, 63, 64, 65, 255, 256, 257, 1000, 4097, 20000, 333, 2, 5000, 12, 100, 1024]
+    clouds = []
+    for i, n in enumerate(sizes):
+        c = synth.make_cloud(max(n, 10), 100 + i)[0][:n].copy()
+        if n > 20:
+            c[rng.choice(n, n // 10, replace=False), 0] = np.nan
+        clouds.append(c)
+    Q, k = 22, 8
+    qs = np.stack([rng.uniform(0, 15, (len(sizes), Q)), rng.uniform(-3, 3, (len(sizes), Q)),
+                   rng.uniform(0, 3, (len(sizes), Q))], -1)
+    r = _gpu_search(torch_cuda, clouds, qs, k, stride=4)
+    for s, c in enumerate(clouds):
+        t = _oracle.kd_oracle(c)
+        assert r["sizes"][s] == t.size()
+        for q in range(Q):
+            ia, da, pa = t.search(qs[s, q], k)
+            cnt = r["counts"][s, q]
+            assert cnt == len(ia)
+            assert np.array_equal(r["indices"][s, q, :cnt], ia)
+            assert np.array_equal(r["sqdist"][s, q, :cnt].view(np.int64), da.view(np.int64))
+            assert np.array_equal(r["pts"][s, q, :cnt], pa)
+
+
+def test_ties_follow_lowest_index_policy(torch_cuda, oracle):
+    """Exact distance ties: nanoflann resolves them by traversal order (unspecified by any contract);
+    the HIP path resolves them by lowest index == the ordered brute force of the oracle.  The
+    distance lists must still equal the reference's."""
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(10), indexing="ij"), -1)
+    cloud = g.reshape(-1, 3).astype(np.float32)
+    dup = np.repeat(np.random.default_rng(1).uniform(-1, 1, (200, 3)).astype(np.float32), 3, axis=0)
+    rng = np.random.default_rng(3)
+    for c, qs in ((cloud, rng.integers(0, 9, (32, 3)) + 0.5), (dup, rng.uniform(-1, 1, (32, 3)))):
+        t = _oracle.kd_oracle(c)
+        for k in (1, 4, 8):
+            r = _gpu_search(torch_cuda, [c], qs[None], k)
+            for i, q in enumerate(qs):
+                ib, db = t.bruteforce(q, k)
+                assert np.array_equal(r["indices"][0, i], ib)
+                assert np.array_equal(r["sqdist"][0, i], db)
+                assert np.array_equal(r["sqdist"][0, i], t.search_raw(q, k)[1])   # same distances as nanoflann
+
+
+def test_single_query_and_host_api(torch_cuda, oracle):
+    from avoid_mpc_amd.host import KdBatch
+    cloud = synth.make_cloud(5000, 77)[0]
+    t = _oracle.kd_oracle(cloud)
+    kd = KdBatch(1, 5000)
+    kd.build_host(cloud[None])
+    rng = np.random.default_rng(8)
+    for Q, k in ((1, 1), (1, 8), (3, 3), (30, 10), (64, 64)):
+        qs = rng.uniform([0, -4, 0], [20, 4, 3], (1, Q, 3))
+        r = kd.search_host(qs, k)
+        for q in range(Q):
+            ia, da, pa = t.search(qs[0, q], k)
+            assert np.array_equal(r["indices"][0, q], ia) and np.array_equal(r["sqdist"][0, q], da)
+            assert np.array_equal(r["pts"][0, q], pa)
+    kd.close()
+
+
+def test_argument_errors(torch_cuda):
+    import ctypes as C
+    from avoid_mpc_amd import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.amk_kd_create(0, 10, C.byref(h)) == 1
+    assert lib.amk_kd_create(1, 10, C.byref(h)) == 0
+    assert lib.amk_kd_search(h, None, 1, 1, None, None, None, None, None) == 1
+    q = torch_cuda.zeros((1, 1, 3), dtype=torch_cuda.float64, device="cuda")
+    assert lib.amk_kd_search(h, C.c_void_p(q.data_ptr()), 1, 65, None, None, None, None, None) == 4
+    assert lib.amk_kd_destroy(h) == 0
