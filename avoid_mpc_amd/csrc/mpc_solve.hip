@@ -1,0 +1,251 @@
+// MPC solve of the Avoid-MPC hot path for gfx950: batch of ObstacleAvoidanceMPC objects.
+//
+// Replaces AM/include/HighLvlMpc.h:4-33 / AM/src/HighLvlMpc.cpp:5-137 (class
+// ObstacleAvoidanceMPC: constructor defaults, setters, Solve, warm start) and the generated plugin it
+// loads through casadi::nlpsol (AM/tools/mpc_obstacle_casadi.py).  Device algorithm: mpc_device.h.
+#include "mpc_device.h"
+
+#include <cmath>
+#include <cstring>
+
+using namespace amk;
+
+struct amk_mpc {
+    double T = 0, dt = 0;
+    int N = 0, K = 0, S = 0, nx = 0, nref = 0;
+    double h_prm[PRM_LEN];
+    SolveOpts opt;
+    size_t lds_bytes = 0;
+    DevBuf<double> prm;   // [PRM_LEN]
+    DevBuf<double> w0;    // [S][nx]  mNlpW0
+    // staging for amk_mpc_solve_host
+    DevBuf<double> st_ref, st_u, st_x0;
+    DevBuf<int> st_info;
+};
+
+namespace {
+
+// ---- host-side model: RK4 x 4 of the quadrotor ODE (mpc_obstacle_casadi.py:106-122, 338-357) probed for
+// its affine form F(x,u) = A x + B u + c (exactly affine with the drag term off, the repo default
+// mpc_parameters.yaml:4).
+void ode_host(const double *x, const double *u, const double *tau, double *xd) {
+    xd[0] = x[4]; xd[1] = x[5]; xd[2] = x[6];
+    xd[3] = u[3];
+    xd[4] = x[7]; xd[5] = x[8]; xd[6] = x[9];
+    xd[7] = (u[0] - x[7]) * tau[0];
+    xd[8] = (u[1] - x[8]) * tau[1];
+    xd[9] = (u[2] - kGz - x[9]) * tau[2];
+}
+
+void rk4_host(const double *x, const double *u, const double *tau, double dt, double *xn) {
+    const int M = 4;
+    const double DT = dt / M;
+    double X[SD], k1[SD], k2[SD], k3[SD], k4[SD], t[SD];
+    std::memcpy(X, x, sizeof X);
+    for (int m = 0; m < M; ++m) {
+        ode_host(X, u, tau, k1);
+        for (int i = 0; i < SD; ++i) { k1[i] *= DT; t[i] = X[i] + 0.5 * k1[i]; }
+        ode_host(t, u, tau, k2);
+        for (int i = 0; i < SD; ++i) { k2[i] *= DT; t[i] = X[i] + 0.5 * k2[i]; }
+        ode_host(t, u, tau, k3);
+        for (int i = 0; i < SD; ++i) { k3[i] *= DT; t[i] = X[i] + k3[i]; }
+        ode_host(t, u, tau, k4);
+        for (int i = 0; i < SD; ++i) { k4[i] *= DT; X[i] = X[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6; }
+    }
+    std::memcpy(xn, X, sizeof X);
+}
+
+void refresh_dynamics(amk_mpc *m) {
+    double *A = m->h_prm + PRM_A, *B = m->h_prm + PRM_B, *c = m->h_prm + PRM_C;
+    const double *tau = m->h_prm + PRM_TAU;
+    double z10[SD] = {0}, z4[UD] = {0}, e10[SD], e4[UD], f[SD];
+    rk4_host(z10, z4, tau, m->dt, c);
+    for (int j = 0; j < SD; ++j) {
+        std::memset(e10, 0, sizeof e10);
+        e10[j] = 1.0;
+        rk4_host(e10, z4, tau, m->dt, f);
+        for (int i = 0; i < SD; ++i) A[i * SD + j] = f[i] - c[i];
+    }
+    for (int j = 0; j < UD; ++j) {
+        std::memset(e4, 0, sizeof e4);
+        e4[j] = 1.0;
+        rk4_host(z10, e4, tau, m->dt, f);
+        for (int i = 0; i < SD; ++i) B[i * UD + j] = f[i] - c[i];
+    }
+}
+
+int upload_params(amk_mpc *m) {
+    AMK_HIP(hipMemcpy(m->prm.p, m->h_prm, sizeof(double) * PRM_LEN, hipMemcpyHostToDevice));
+    return AMK_OK;
+}
+
+}  // namespace
+
+// Internal debugging aid (not part of the C ABI): when set, scene 0 of mpc_solve_kernel writes 8 doubles per
+// interior-point iteration {J, kkt error, mu, delta, alpha, alpha_pr, alpha_du, dphi}.
+static double *g_trace = nullptr;
+extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
+
+// grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total doubles
+__global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, int nx, const double *__restrict__ prm,
+                                                       SolveOpts opt, const double *__restrict__ ref_states,
+                                                       double *__restrict__ w0, double *__restrict__ u_out,
+                                                       double *__restrict__ x0array, int *__restrict__ info,
+                                                       double *trace) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int s = blockIdx.x;
+    const LdsMap L(N);
+    const double *P = ref_states + (size_t)s * nref;
+    SceneIO io;
+    io.ref = P + SD;
+    io.obs = P + SD + SD * N;
+    const double *target = P + SD + SD * N + 3 * K * N;
+    double *w = w0 + (size_t)s * nx;
+    solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, s == 0 ? trace : nullptr);
+    __syncthreads();
+    const int lane = threadIdx.x;
+    if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
+    if (x0array)                                           // rows [X_k,U_k], k < N  :130-136
+        for (int e = lane; e < 14 * N; e += 64) {
+            const int k = e / 14, i = e % 14;
+            x0array[(size_t)s * 14 * N + e] = i < SD ? sm[L.X + k * SD + i] : sm[L.U + k * UD + (i - SD)];
+        }
+}
+
+extern "C" {
+
+int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out) {
+    if (!out || !(T > 0) || !(dt > 0) || nearest_point_num < 0 || n_scenes <= 0) return AMK_ERR_INVALID_ARG;
+    *out = nullptr;
+    const int N = (int)(T / dt);  // HighLvlMpc.cpp:9 (mN = T / dt, truncating)
+    if (N < 2 || N > AMK_MAX_HORIZON || nearest_point_num > AMK_MAX_K) return AMK_ERR_UNSUPPORTED;
+    if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
+    amk_mpc *m = new amk_mpc();
+    m->T = T; m->dt = dt; m->N = N; m->K = nearest_point_num; m->S = n_scenes;
+    m->nx = 10 + 14 * N;
+    m->nref = 20 + 10 * N + 3 * m->K * N;
+    std::memset(m->h_prm, 0, sizeof m->h_prm);
+    // constructor defaults, HighLvlMpc.cpp:13-16,53-56
+    const double wdef[25] = {100, 100, 100, 300, 1, 1, 1, 0., 0., 0., 0.0, 10, 10, 30, 0, 1, 1, 0., 0., 0., 1., 1., 1., 1., 1.};
+    std::memcpy(m->h_prm + PRM_W, wdef, sizeof wdef);
+    const double tdef[4] = {0.01, 0.01, 0.01, 0};
+    std::memcpy(m->h_prm + PRM_TAU, tdef, sizeof tdef);
+    for (int i = 0; i < 4; ++i) m->h_prm[PRM_GAIN + i] = 1.0;
+    const double lb[4] = {-10., -10., 1., -10.}, ub[4] = {10., 10., 20., 10.};
+    std::memcpy(m->h_prm + PRM_LB, lb, sizeof lb);
+    std::memcpy(m->h_prm + PRM_UB, ub, sizeof ub);
+    refresh_dynamics(m);
+    m->opt.tol = 1e-4; m->opt.max_iter = 10; m->opt.max_ls = 12; m->opt.mu_init = 0.1;
+    m->opt.bound_push = 1e-3; m->opt.bound_frac = 1e-3; m->opt.kappa_mu = 0.2; m->opt.tau_min = 0.99;
+    m->opt.eta_phi = 1e-8; m->opt.s_max = 100.0; m->opt.kappa_sigma = 1e10;
+    m->lds_bytes = sizeof(double) * (size_t)LdsMap(N).total;
+    hipError_t e;
+    if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
+        (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
+        (e = hipFuncSetAttribute((const void *)mpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)m->lds_bytes)) != hipSuccess) {
+        delete m;
+        return amk::hip_fail(e);
+    }
+    int st = upload_params(m);
+    if (st != AMK_OK) {
+        delete m;
+        return st;
+    }
+    *out = m;
+    return AMK_OK;
+}
+
+int amk_mpc_destroy(amk_mpc *m) {
+    if (!m) return AMK_ERR_INVALID_ARG;
+    delete m;
+    return AMK_OK;
+}
+
+int amk_mpc_horizon(const amk_mpc *m) { return m ? m->N : -1; }
+int amk_mpc_nx(const amk_mpc *m) { return m ? m->nx : -1; }
+int amk_mpc_ref_len(const amk_mpc *m) { return m ? m->nref : -1; }
+
+int amk_mpc_setup_weights(amk_mpc *m, const double *w) {
+    if (!m || !w) return AMK_ERR_INVALID_ARG;
+    std::memcpy(m->h_prm + PRM_W, w, sizeof(double) * 25);
+    return upload_params(m);
+}
+int amk_mpc_setup_tau(amk_mpc *m, const double *tau) {
+    if (!m || !tau) return AMK_ERR_INVALID_ARG;
+    std::memcpy(m->h_prm + PRM_TAU, tau, sizeof(double) * 4);
+    refresh_dynamics(m);
+    return upload_params(m);
+}
+int amk_mpc_setup_gains(amk_mpc *m, const double *g) {
+    if (!m || !g) return AMK_ERR_INVALID_ARG;
+    std::memcpy(m->h_prm + PRM_GAIN, g, sizeof(double) * 4);
+    return upload_params(m);
+}
+int amk_mpc_set_drone_radius(amk_mpc *m, double r) {
+    if (!m) return AMK_ERR_INVALID_ARG;
+    m->h_prm[PRM_RADIUS] = r;
+    return upload_params(m);
+}
+int amk_mpc_set_drone_accel_limits(amk_mpc *m, double aMinZ, double aMaxZ, double aMaxXy, double aMaxYawDot) {
+    if (!m) return AMK_ERR_INVALID_ARG;
+    const double lb[4] = {-aMaxXy, -aMaxXy, aMinZ, -aMaxYawDot}, ub[4] = {aMaxXy, aMaxXy, aMaxZ, aMaxYawDot};
+    for (int i = 0; i < 4; ++i)
+        if (!(ub[i] > lb[i])) return AMK_ERR_INVALID_ARG;
+    std::memcpy(m->h_prm + PRM_LB, lb, sizeof lb);
+    std::memcpy(m->h_prm + PRM_UB, ub, sizeof ub);
+    return upload_params(m);
+}
+int amk_mpc_set_solver_options(amk_mpc *m, double tol, int max_iter) {
+    if (!m || !(tol > 0) || max_iter < 0) return AMK_ERR_INVALID_ARG;
+    m->opt.tol = tol;
+    m->opt.max_iter = max_iter;
+    return AMK_OK;
+}
+
+int amk_mpc_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, int faster,
+                  void *stream) {
+    (void)faster;  // mSolver and mSolverFaster carry identical options, HighLvlMpc.cpp:50-52
+    if (!m || !d_ref_states || !d_u) return AMK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(mpc_solve_kernel, dim3(m->S), dim3(64), m->lds_bytes, (hipStream_t)stream, m->N, m->K, m->nref,
+                       m->nx, m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+int amk_mpc_get_warm_start(amk_mpc *m, double *d_w, void *stream) {
+    if (!m || !d_w) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipMemcpyAsync(d_w, m->w0.p, sizeof(double) * (size_t)m->S * m->nx, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AMK_OK;
+}
+int amk_mpc_set_warm_start(amk_mpc *m, const double *d_w, void *stream) {
+    if (!m || !d_w) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipMemcpyAsync(m->w0.p, d_w, sizeof(double) * (size_t)m->S * m->nx, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return AMK_OK;
+}
+int amk_mpc_reset_warm_start(amk_mpc *m, void *stream) {
+    if (!m) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipMemsetAsync(m->w0.p, 0, sizeof(double) * (size_t)m->S * m->nx, (hipStream_t)stream));
+    return AMK_OK;
+}
+
+int amk_mpc_solve_host(amk_mpc *m, const double *h_ref_states, double *h_u, double *h_x0array, int *h_info, int faster) {
+    if (!m || !h_ref_states || !h_u) return AMK_ERR_INVALID_ARG;
+    const size_t S = m->S;
+    if (!m->st_ref.p) {
+        AMK_HIP(m->st_ref.alloc(S * m->nref));
+        AMK_HIP(m->st_u.alloc(S * 4));
+        AMK_HIP(m->st_x0.alloc(S * 14 * m->N));
+        AMK_HIP(m->st_info.alloc(S * 4));
+    }
+    AMK_HIP(hipMemcpy(m->st_ref.p, h_ref_states, sizeof(double) * S * m->nref, hipMemcpyHostToDevice));
+    int st = amk_mpc_solve(m, m->st_ref.p, m->st_u.p, m->st_x0.p, m->st_info.p, faster, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h_u, m->st_u.p, sizeof(double) * S * 4, hipMemcpyDeviceToHost));
+    if (h_x0array) AMK_HIP(hipMemcpy(h_x0array, m->st_x0.p, sizeof(double) * S * 14 * m->N, hipMemcpyDeviceToHost));
+    if (h_info) AMK_HIP(hipMemcpy(h_info, m->st_info.p, sizeof(int) * S * 4, hipMemcpyDeviceToHost));
+    return AMK_OK;
+}
+
+}  // extern "C"

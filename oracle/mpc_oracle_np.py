@@ -122,10 +122,15 @@ def rot_of_ref(yaw_ref):
     return R
 
 
-def collide_terms(p, v, obs, lam, radius, want_derivs):
+ABS_EPS = 1e-3
+
+
+def collide_terms(p, v, obs, lam, radius, want_derivs, majorise_abs=True):
     """Sum over the K obstacle points of one stage (mpc_obstacle_casadi.py:186-204).
 
-    returns cost, grad(6: p then v), hess(6x6)"""
+    returns cost, grad(6: p then v), hess(6x6).  With majorise_abs=False the Hessian is the plain
+    second derivative with sign(s) frozen (what CasADi's AD of fabs gives); the solver's model
+    Hessian adds the majoriser curvature of the abs term."""
     cost = 0.0
     g6 = np.zeros(6)
     H6 = np.zeros((6, 6))
@@ -160,13 +165,17 @@ def collide_terms(p, v, obs, lam, radius, want_derivs):
         H6[0:3, 0:3] += lam * sgn * Hpp
         H6[0:3, 3:6] += lam * sgn * Hpv
         H6[3:6, 0:3] += lam * sgn * Hpv.T
+        if majorise_abs:
+            # curvature of the quadratic majoriser of |s| (see oracle/mpc_oracle.c collide_point)
+            gs = np.concatenate([-t / rho, n])
+            H6 += lam * g / max(abs(s), ABS_EPS) * np.outer(gs, gs)
     return cost, g6, H6
 
 
 PV = np.array([0, 1, 2, 4, 5, 6])  # positions then velocities inside the 10-state
 
 
-def stage_cost(k, N, xk1, uk, pp, want_derivs=True):
+def stage_cost(k, N, xk1, uk, pp, want_derivs=True, majorise_abs=True):
     """Cost attached to (U_k, X_{k+1}); returns (cost, q(10), Q(10x10), r(4), Rdiag(4))."""
     u_ref = np.array([0.0, 0.0, GZ, 0.0])
     du = uk - u_ref
@@ -189,7 +198,7 @@ def stage_cost(k, N, xk1, uk, pp, want_derivs=True):
         q = 2.0 * R.T @ (pp["q_pen"] * y)
         Q = 2.0 * R.T @ np.diag(pp["q_pen"]) @ R
         c, g6, H6 = collide_terms(xk1[0:3], xk1[4:7], pp["obs"][k], pp["lam"], pp["radius"],
-                                  want_derivs)
+                                  want_derivs, majorise_abs)
         cost += c
         if want_derivs:
             q = q.copy()
@@ -241,13 +250,15 @@ def nlp_grad_f(w, P, N, K):
     return pack_w(gX, gU)
 
 
-def nlp_hess_f(w, P, N, K):
+def nlp_hess_f(w, P, N, K, majorise_abs=False):
+    """Dense Hessian of f.  majorise_abs=False: plain second derivatives (sign frozen), the thing
+    finite differences can check; True: the solver's model Hessian."""
     pp = split_p(P, N, K)
     X, U = unpack_w(w, N)
     nx = 10 + 14 * N
     H = np.zeros((nx, nx))
     for k in range(N):
-        _, _, Q, _, Rd = stage_cost(k, N, X[k + 1], U[k], pp)
+        _, _, Q, _, Rd = stage_cost(k, N, X[k + 1], U[k], pp, True, majorise_abs)
         ix = slice(14 * (k + 1), 14 * (k + 1) + 10)
         iu = slice(14 * k + 10, 14 * k + 14)
         H[ix, ix] = Q
@@ -290,7 +301,7 @@ def nlp_jac_g(w, P, N, K, dt):
 # ----------------------------------------------------------------------------------------------
 class IpmOptions:
     def __init__(self, tol=1e-4, max_iter=10, mu_init=0.1, bound_push=1e-3, bound_frac=1e-3,
-                 kappa_eps=10.0, kappa_mu=0.2, theta_mu=1.5, tau_min=0.99, eta_phi=1e-8,
+                 kappa_mu=0.2, tau_min=0.99, eta_phi=1e-8,
                  max_ls=12, s_max=100.0, kappa_sigma=1e10):
         self.__dict__.update(locals())
         del self.__dict__["self"]
@@ -328,16 +339,22 @@ def riccati(A, B, q, Q, r, Rdiag, delta):
         Quu = np.diag(Rdiag[k] + delta) + B.T @ PB
         Qux = PB.T @ A
         qu = r[k] + B.T @ p
-        try:
-            L = np.linalg.cholesky(Quu)
-        except np.linalg.LinAlgError:
-            return False, None, None
-        Kk = -np.linalg.solve(L.T, np.linalg.solve(L, Qux))
-        dk = -np.linalg.solve(L.T, np.linalg.solve(L, qu))
+        # Quu = L D L^T; not positive definite <=> some D_j <= 0
+        L = np.eye(U_DIM); D = np.zeros(U_DIM)
+        for j in range(U_DIM):
+            dj = Quu[j, j] - np.sum(L[j, :j] ** 2 * D[:j])
+            if not dj > 0.0:
+                return False, None, None
+            D[j] = dj
+            for i in range(j + 1, U_DIM):
+                L[i, j] = (Quu[i, j] - np.sum(L[i, :j] * L[j, :j] * D[:j])) / dj
+        Y = np.linalg.solve(L, Qux); yv = np.linalg.solve(L, qu)
+        Kk = -np.linalg.solve(L.T, Y / D[:, None])
+        dk = -np.linalg.solve(L.T, yv / D)
         Ks[k], ds[k] = Kk, dk
         if k > 0:
-            Pn = Q[k] + delta * np.eye(S_DIM) + A.T @ P @ A + Qux.T @ Kk
-            pn = q[k] + A.T @ p + Qux.T @ dk
+            Pn = Q[k] + delta * np.eye(S_DIM) + A.T @ P @ A - Y.T @ (Y / D[:, None])
+            pn = q[k] + A.T @ p - Y.T @ (yv / D)
             P = 0.5 * (Pn + Pn.T)
             p = pn
     dU = np.zeros((N, U_DIM)); dX = np.zeros((N + 1, S_DIM))
@@ -363,6 +380,7 @@ def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
     mu = opt.mu_init
     zl = mu / (U - lb); zu = mu / (ub - U)
     delta_last = 0.0
+    a_last = 0.0
     X = rollout(pp["x_init"], U, A, B, c)
     info = dict(iters=0, status=1, mu=mu, err=np.inf, n_reg=0, ls_fail=0)
     nvar = U.size
@@ -370,7 +388,7 @@ def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
     def barrier(Uc, Jc, mu_):
         return Jc - mu_ * np.sum(np.log(Uc - lb)) - mu_ * np.sum(np.log(ub - Uc))
 
-    for it in range(opt.max_iter + 1):
+    for it in range(opt.max_iter):
         J, q, Q, r, Rd = total_cost(X, U, pp, N, True)
         # reduced gradient by the adjoint sweep
         lam = q[N].copy()
@@ -394,14 +412,11 @@ def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
         if err0 <= opt.tol:
             info["status"] = 0
             break
-        if it == opt.max_iter:
-            break
-        # barrier update (monotone, IPOPT eq. (7))
-        while kkt_err(mu) <= opt.kappa_eps * mu and mu > opt.tol / 10.0:
-            mu = max(opt.tol / 10.0, min(opt.kappa_mu * mu, mu ** opt.theta_mu))
+        # barrier update: shrink after every iteration that took at least half a step
+        if it > 0 and a_last >= 0.5:
+            mu = max(opt.tol / 10.0, opt.kappa_mu * mu)
         tau = max(opt.tau_min, 1.0 - mu)
         Sig = zl / sl + zu / su
-        rbar = gU_bar = None
         # Newton rhs in stage form: r_k - mu/sl + mu/su  (q unchanged)
         rb = r - mu / sl + mu / su
         delta = 0.0
@@ -432,18 +447,23 @@ def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
         accepted = False
         for _ in range(opt.max_ls):
             Ut = U + a * dU
-            Xt = rollout(pp["x_init"], Ut, A, B, c)
+            Xt = X + a * dX          # affine dynamics: X(U + a dU) = X + a dX exactly
             Jt = total_cost(Xt, Ut, pp, N, False)[0]
             if barrier(Ut, Jt, mu) <= phi0 + opt.eta_phi * a * dphi:
                 accepted = True
                 break
-            a *= 0.5
+            if _ + 1 < opt.max_ls:
+                a *= 0.5
         if not accepted:
             info["ls_fail"] += 1
+        a_last = a if accepted else 0.0
         U, X = Ut, Xt
         zl = zl + a_du * dzl; zu = zu + a_du * dzu
         # keep duals in the IPOPT safeguard box (eq. (16))
         sl = U - lb; su = ub - U
         zl = np.maximum(np.minimum(zl, opt.kappa_sigma * mu / sl), mu / (opt.kappa_sigma * sl))
         zu = np.maximum(np.minimum(zu, opt.kappa_sigma * mu / su), mu / (opt.kappa_sigma * su))
+    else:
+        info["iters"] = opt.max_iter
+    info["cost"] = total_cost(X, U, pp, N, False)[0]
     return pack_w(X, U), info

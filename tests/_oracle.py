@@ -128,5 +128,121 @@ def kd_ref(xyz, stride=None, strict=True):
     return None if lib is None else KdHandle(lib, "ref_kd", xyz, stride)
 
 
+class MpcoOpts(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("mu_init", C.c_double),
+                ("bound_push", C.c_double), ("bound_frac", C.c_double), ("kappa_mu", C.c_double),
+                ("tau_min", C.c_double), ("eta_phi", C.c_double), ("max_ls", C.c_int),
+                ("s_max", C.c_double), ("kappa_sigma", C.c_double)]
+
+
 def _decl_mpc(lib):
-    pass
+    i, d, vp = C.c_int, C.c_double, C.c_void_p
+    lib.mpco_default_opts.argtypes = [C.POINTER(MpcoOpts)]
+    lib.mpco_p_len.restype = i; lib.mpco_p_len.argtypes = [i, i]
+    lib.mpco_rk4_step.argtypes = [_f64p, _f64p, _f64p, d, _f64p]
+    lib.mpco_affine.argtypes = [_f64p, d, _f64p, _f64p, _f64p]
+    lib.mpco_nlp_f.restype = d; lib.mpco_nlp_f.argtypes = [_f64p, _f64p, i, i]
+    lib.mpco_nlp_grad_f.argtypes = [_f64p, _f64p, i, i, _f64p]
+    lib.mpco_nlp_hess_blocks.argtypes = [_f64p, _f64p, i, i, _f64p, _f64p]
+    lib.mpco_nlp_g.argtypes = [_f64p, _f64p, i, i, d, _f64p]
+    lib.mpco_solve.restype = i
+    lib.mpco_solve.argtypes = [_f64p, _f64p, _f64p, _f64p, i, i, d, C.POINTER(MpcoOpts), _f64p, _i32p, _f64p]
+    lib.mpco_create.restype = vp; lib.mpco_create.argtypes = [d, d, i]
+    lib.mpco_destroy.argtypes = [vp]
+    lib.mpco_horizon.restype = i; lib.mpco_horizon.argtypes = [vp]
+    for n in ("weights", "tau", "gains"):
+        getattr(lib, "mpco_setup_" + n).argtypes = [vp, _f64p]
+    lib.mpco_set_drone_radius.argtypes = [vp, d]
+    lib.mpco_set_drone_accel_limits.argtypes = [vp, d, d, d, d]
+    lib.mpco_set_solver_options.argtypes = [vp, d, i]
+    lib.mpco_warm_start.restype = C.POINTER(C.c_double); lib.mpco_warm_start.argtypes = [vp]
+    lib.mpco_last_info.restype = C.POINTER(C.c_int); lib.mpco_last_info.argtypes = [vp]
+    lib.mpco_last_stats.restype = C.POINTER(C.c_double); lib.mpco_last_stats.argtypes = [vp]
+    lib.mpco_Solve.restype = i; lib.mpco_Solve.argtypes = [vp, _f64p, _f64p, _f64p, i]
+    if hasattr(lib, "stepo_run"):
+        lib.stepo_run.restype = i
+        lib.stepo_run.argtypes = [vp, vp, vp, i, d, d, d, i, _f64p, d, _f64p, _f64p, _f64p, _i32p, vp]
+        lib.stepo_cur_state_quad.argtypes = [_f64p, _f64p, _f64p, d, d, i, _f64p]
+        lib.stepo_get_init_path.argtypes = [_f64p, i, d, d, d, d, d]
+
+
+def mpco_solve(P, w0, lbu, ubu, N, K, dt, tol=1e-4, max_iter=10):
+    """-> (w, info[4], stats[4]) from the C solver."""
+    lib = load_oracle()
+    opt = MpcoOpts(); lib.mpco_default_opts(C.byref(opt)); opt.tol = tol; opt.max_iter = max_iter
+    w = np.zeros(10 + 14 * N); info = np.zeros(4, np.int32); stats = np.zeros(4)
+    lib.mpco_solve(np.ascontiguousarray(P, np.float64), np.ascontiguousarray(w0, np.float64),
+                   np.ascontiguousarray(lbu, np.float64), np.ascontiguousarray(ubu, np.float64), N, K, dt,
+                   C.byref(opt), w, info, stats)
+    return w, info, stats
+
+
+class MpcOracle:
+    """ObstacleAvoidanceMPC restated (oracle/mpc_oracle.c mpco_create ... mpco_Solve)."""
+
+    def __init__(self, T, dt, K):
+        self.lib = load_oracle()
+        self.h = self.lib.mpco_create(T, dt, K)
+        self.N = self.lib.mpco_horizon(self.h); self.K = K
+        self.nx = 10 + 14 * self.N
+
+    def configure(self, prm):
+        f = lambda v: np.ascontiguousarray(v, np.float64)
+        self.lib.mpco_setup_weights(self.h, f(prm.weights)); self.lib.mpco_setup_tau(self.h, f(prm.tau))
+        self.lib.mpco_setup_gains(self.h, f(prm.gain)); self.lib.mpco_set_drone_radius(self.h, prm.radius)
+        self.lib.mpco_set_drone_accel_limits(self.h, prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot)
+
+    def set_solver_options(self, tol=1e-4, max_iter=10):
+        self.lib.mpco_set_solver_options(self.h, tol, max_iter)
+
+    def Solve(self, ref_states, faster=False):
+        u = np.zeros(4); x0 = np.zeros((self.N, 14))
+        st = self.lib.mpco_Solve(self.h, np.ascontiguousarray(ref_states, np.float64), u, x0.reshape(-1), int(faster))
+        info = np.ctypeslib.as_array(self.lib.mpco_last_info(self.h), (4,)).copy()
+        return u, x0, info
+
+    @property
+    def warm_start(self):
+        return np.ctypeslib.as_array(self.lib.mpco_warm_start(self.h), (self.nx,))
+
+    def close(self):
+        if self.h:
+            self.lib.mpco_destroy(self.h); self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cur_state_quad(pos, vel, acc, yaw, dt, use_odom_est=True):
+    """GetCurStateQuad restated (oracle/step_oracle.c)."""
+    sq = np.zeros(10)
+    f = lambda v: np.ascontiguousarray(v, np.float64)
+    load_oracle().stepo_cur_state_quad(f(pos), f(vel), f(acc), float(yaw), float(dt), int(use_odom_est), sq)
+    return sq
+
+
+def scene_state_quads(scene, prm):
+    """[max_iter][10] per-iteration initial states: the clock model of this project -- outer
+    iteration i starts (i+1)*decay after the odometry stamp (AvoidanceStateMachine.cpp:327-330,343
+    with every iteration taking `decay` seconds)."""
+    return np.stack([cur_state_quad(scene["pos"], scene["vel"], scene["acc"], scene["yaw"], prm.decay * (i + 1))
+                     for i in range(prm.max_iter)])
+
+
+def step_oracle(kd_obs, kd_edge, mpc, prm, state_quad, pos_x, ref_path, want_log=False):
+    """One control step on the CPU oracle.  kd_*: KdHandle (kdo), mpc: MpcOracle.  ref_path is
+    updated in place.  -> dict(u, x0array, flags, ref_log)"""
+    lib = load_oracle()
+    N, K = mpc.N, mpc.K
+    nref = 20 + 10 * N + 3 * K * N
+    u = np.zeros(4); x0 = np.zeros((N, 14)); flags = np.zeros(4, np.int32)
+    log = np.zeros((prm.max_iter, nref)) if want_log else None
+    sq = np.ascontiguousarray(state_quad, np.float64)
+    assert sq.shape == (prm.max_iter, 10) and ref_path.shape == (N, 10) and ref_path.flags.c_contiguous
+    lib.stepo_run(kd_obs.h, kd_edge.h if kd_edge is not None else None, mpc.h, K, prm.speed, prm.T,
+                  prm.safety_distance, prm.max_iter, sq.reshape(-1), float(pos_x), ref_path.reshape(-1), u,
+                  x0.reshape(-1), flags, log.ctypes.data_as(C.c_void_p) if want_log else None)
+    return dict(u=u, x0array=x0, flags=flags, ref_log=log)

@@ -1,0 +1,113 @@
+"""GPU: the HIP interior-point solve (through the C ABI) against the CPU oracle on identical inputs.
+
+Tolerance (stated, fp64): both sides run the same algorithm; they differ in FMA contraction,
+summation order of wave reductions and libm vs ocml exp/log.  A solve is a chaotic map of its
+rounding noise only through line-search / regularisation branch flips, which the seeded cases below
+do not hit: |u - u*|_inf <= 1e-6 m/s^2 and |x - x*|_inf <= 1e-6 on every scene (measured ~1e-10)."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+def _scene_inputs(n, seeds, prm):
+    """Per scene: the vecRefStates of every outer iteration of the oracle's own step."""
+    logs = []
+    for seed in seeds:
+        sc = synth.make_scene(n, seed, prm)
+        kd, ke = _oracle.kd_oracle(sc["cloud"]), _oracle.kd_oracle(sc["edge"])
+        mpc = _oracle.MpcOracle(prm.T, prm.dt, prm.K); mpc.configure(prm)
+        r = _oracle.step_oracle(kd, ke, mpc, prm, _oracle.scene_state_quads(sc, prm), sc["pos"][0],
+                                sc["ref_path"].copy(), want_log=True)
+        logs.append(r["ref_log"][:r["flags"][1]])
+    return logs
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C5"])
+def test_solve_matches_oracle(cfg, torch_cuda):
+    torch = torch_cuda
+    from avoid_mpc_amd.host import MpcBatch
+    c = synth.CONFIGS[cfg]
+    prm = synth.MpcParams(T=c["T"], K=c["K"])
+    seeds = list(range(200, 216))
+    logs = _scene_inputs(min(c["n"], 20000), seeds, prm)
+    S = len(seeds)
+    gpu = MpcBatch(prm.T, prm.dt, prm.K, S); gpu.configure(prm)
+    cpu = [_oracle.MpcOracle(prm.T, prm.dt, prm.K) for _ in seeds]
+    for m in cpu:
+        m.configure(prm)
+    n_it = min(len(l) for l in logs)
+    worst_u = worst_x = 0.0
+    for it in range(n_it):
+        ref = np.stack([l[it] for l in logs])
+        u, x0, info = gpu.Solve(torch.from_numpy(ref).cuda(), faster=(it == 0))
+        torch.cuda.synchronize()
+        u, x0, info = u.cpu().numpy(), x0.cpu().numpy(), info.cpu().numpy()
+        warm = gpu.get_warm_start().cpu().numpy()
+        for s in range(S):
+            uc, xc, ic = cpu[s].Solve(ref[s], it == 0)
+            worst_u = max(worst_u, np.abs(u[s] - uc).max())
+            worst_x = max(worst_x, np.abs(x0[s] - xc).max())
+            assert np.array_equal(info[s], ic), (cfg, it, s, info[s], ic)
+            assert np.abs(warm[s] - cpu[s].warm_start).max() <= TOL
+    print(f"{cfg}: max |du| = {worst_u:.3e}, max |dx| = {worst_x:.3e}")
+    assert worst_u <= TOL and worst_x <= TOL
+
+
+def test_constructor_defaults_and_setters(torch_cuda):
+    """HighLvlMpc.cpp:5-57 defaults (weights, tau, bounds incl. a_min_z = 1) and the setters."""
+    torch = torch_cuda
+    from avoid_mpc_amd.host import MpcBatch
+    prm = synth.MpcParams(T=0.33, K=3)
+    logs = _scene_inputs(5000, [7], prm)
+    ref = logs[0][0][None]
+    gpu = MpcBatch(prm.T, prm.dt, prm.K, 1)
+    cpu = _oracle.MpcOracle(prm.T, prm.dt, prm.K)
+    gpu.SetDroneRadius(0.4); cpu.lib.mpco_set_drone_radius(cpu.h, 0.4)       # radius has no default (:64-66)
+    u, x0, info = gpu.Solve(torch.from_numpy(ref).cuda())
+    uc, xc, ic = cpu.Solve(ref[0])
+    assert np.abs(u.cpu().numpy()[0] - uc).max() <= TOL
+    gpu.set_solver_options(1e-4, 25); cpu.set_solver_options(1e-4, 25)
+    gpu.reset_warm_start(); cpu.warm_start[:] = 0
+    u, x0, info = gpu.Solve(torch.from_numpy(ref).cuda())
+    uc, xc, ic = cpu.Solve(ref[0])
+    assert np.abs(u.cpu().numpy()[0] - uc).max() <= TOL and np.abs(x0.cpu().numpy()[0] - xc).max() <= TOL
+    assert np.array_equal(info.cpu().numpy()[0], ic)
+
+
+def test_host_api_and_errors(torch_cuda):
+    import ctypes as C
+    from avoid_mpc_amd import capi
+    lib = capi.load()
+    h = C.c_void_p()
+    assert lib.amk_mpc_create(1.0, 0.01, 3, 1, C.byref(h)) == 4          # N = 100 > AMK_MAX_HORIZON
+    assert lib.amk_mpc_create(0.33, 0.033, 3, 2, C.byref(h)) == 0
+    assert lib.amk_mpc_horizon(h) == 10 and lib.amk_mpc_nx(h) == 150 and lib.amk_mpc_ref_len(h) == 210
+    prm = synth.MpcParams(T=0.33, K=3)
+    logs = _scene_inputs(5000, [1, 2], prm)
+    ref = np.ascontiguousarray(np.stack([l[0] for l in logs]))
+    u = np.zeros((2, 4)); x0 = np.zeros((2, 10, 14)); info = np.zeros((2, 4), np.int32)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    for name, val in (("weights", prm.weights), ("tau", prm.tau), ("gains", prm.gain)):
+        a = np.ascontiguousarray(val, np.float64)
+        assert getattr(lib, "amk_mpc_setup_" + name)(h, vp(a)) == 0
+    assert lib.amk_mpc_set_drone_radius(h, prm.radius) == 0
+    assert lib.amk_mpc_set_drone_accel_limits(h, prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot) == 0
+    assert lib.amk_mpc_set_drone_accel_limits(h, 5.0, 5.0, 1.0, 1.0) == 1  # empty box
+    assert lib.amk_mpc_solve_host(h, vp(ref), vp(u), vp(x0), vp(info), 0) == 0
+    for s in range(2):
+        m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)
+        uc, xc, ic = m.Solve(ref[s])
+        assert np.abs(u[s] - uc).max() <= TOL and np.abs(x0[s] - xc).max() <= TOL
+    assert lib.amk_mpc_destroy(h) == 0
