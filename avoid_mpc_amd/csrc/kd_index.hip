@@ -14,7 +14,7 @@
 // ballot to find the (rare) lanes that beat it and a shuffle-based insertion into a sorted top-k
 // list that lives in lanes 0..k-1.  Only *results* must equal the reference's;
 // the tree shape is free.
-#include "amk_common.h"
+#include "kd_device.h"
 
 namespace amk {
 thread_local int g_last_hip_error = 0;
@@ -82,36 +82,8 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// search: streaming exact kNN, one wavefront per (scene, group of QPW queries)
+// search: one wavefront per (scene, group of QPW queries); device scan in kd_device.h
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sq_dist(double qx, double qy, double qz, float px, float py, float pz) {
-    // kd_tree_two.h:24-27 / nanoflann_two.hpp:590-598: r = d0*d0; r += d1*d1; r += d2*d2.  Contraction
-    // into FMAs must stay off here (HIP's __dmul_rn/__dadd_rn do contract): the squared distances are
-    // part of the bit-exact contract.
-#pragma clang fp contract(off)
-    const double d0 = qx - (double)px;
-    const double d1 = qy - (double)py;
-    const double d2 = qz - (double)pz;
-    double r = d0 * d0;
-    r = r + d1 * d1;
-    r = r + d2 * d2;
-    return r;
-}
-
-__device__ __forceinline__ double shfl_up1_f64(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_up(lo, 1);
-    hi = __shfl_up(hi, 1);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
-    return __hiloint2double(hi, lo);
-}
-
 template <int QPW>
 __global__ __launch_bounds__(kWave) void kd_scan_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
@@ -130,7 +102,7 @@ __global__ __launch_bounds__(kWave) void kd_scan_kernel(
     const int size = sizes[s];
     const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
 
-    double qx[QPW], qy[QPW], qz[QPW], tau[QPW];
+    double qx[QPW], qy[QPW], qz[QPW];
     double ld[QPW];  // lane i < k: i-th best squared distance
     int li[QPW];     //             and its index
 #pragma unroll
@@ -141,50 +113,8 @@ __global__ __launch_bounds__(kWave) void kd_scan_kernel(
         qx[qq] = qp[0];
         qy[qq] = qp[1];
         qz[qq] = qp[2];
-        tau[qq] = DBL_MAX;  // KNNResultSet::init, nanoflann_two.hpp:196-202
-        ld[qq] = DBL_MAX;
-        li[qq] = 0x7fffffff;
     }
-
-    for (int base = 0; base < size; base += 4 * kWave) {
-        const int i0 = base + 4 * lane;
-        const float4 x4 = *reinterpret_cast<const float4 *>(xs + i0);
-        const float4 y4 = *reinterpret_cast<const float4 *>(ys + i0);
-        const float4 z4 = *reinterpret_cast<const float4 *>(zs + i0);
-        const float px[4] = {x4.x, x4.y, x4.z, x4.w};
-        const float py[4] = {y4.x, y4.y, y4.z, y4.w};
-        const float pz[4] = {z4.x, z4.y, z4.z, z4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-#pragma unroll
-            for (int qq = 0; qq < QPW; ++qq) {
-                const double d = sq_dist(qx[qq], qy[qq], qz[qq], px[e], py[e], pz[e]);
-                // NaN padding / NaN coordinates compare false, as in the reference's dist < worst
-                unsigned long long m = __ballot(d <= tau[qq]);
-                while (m) {  // rare: a lane beats (or ties) the current k-th best
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const double dc = readlane_f64(d, src);
-                    const int ic = base + 4 * src + e;
-                    // rank of the candidate in (distance, index) order among the kept entries
-                    const bool lt = (lane < k) && (ld[qq] < dc || (ld[qq] == dc && li[qq] < ic));
-                    const int pos = __popcll(__ballot(lt));
-                    if (pos < k && dc < DBL_MAX) {
-                        const double up_d = shfl_up1_f64(ld[qq]);
-                        const int up_i = __shfl_up(li[qq], 1);
-                        if (lane > pos) {
-                            ld[qq] = up_d;
-                            li[qq] = up_i;
-                        } else if (lane == pos) {
-                            ld[qq] = dc;
-                            li[qq] = ic;
-                        }
-                        tau[qq] = readlane_f64(ld[qq], k - 1);
-                    }
-                }
-            }
-        }
-    }
+    amk::scan_cloud<QPW>(xs, ys, zs, size, qx, qy, qz, k, ld, li);
 
     // KDTreeTwo::SearchForNearest count rule, kd_tree_two.h:119-124
     const int cnt = size < k ? size : (size > k ? k : 0);
@@ -195,7 +125,7 @@ __global__ __launch_bounds__(kWave) void kd_scan_kernel(
         const size_t row = (size_t)s * n_queries + q;
         if (lane == 0 && out_cnt) out_cnt[row] = cnt;
         if (lane < k) {
-            const bool ok = lane < cnt && li[qq] != 0x7fffffff;
+            const bool ok = lane < cnt && li[qq] != amk::kNoIndex;
             const int idx = ok ? li[qq] : -1;
             if (out_idx) out_idx[row * k + lane] = idx;
             if (out_d2) out_d2[row * k + lane] = ok ? ld[qq] : DBL_MAX;

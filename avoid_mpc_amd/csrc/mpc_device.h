@@ -641,6 +641,10 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
     __syncthreads();
     for (int e = lane; e < (N + 1) * SD; e += 64) w_out[14 * (e / SD) + (e % SD)] = sm[L.X + e];
     for (int e = lane; e < nvar; e += 64) w_out[14 * (e / UD) + 10 + (e % UD)] = sm[L.U + e];
+    if (lane == 0) {  // kept for the control-step bookkeeping of the calling kernel
+        sm[L.red + 0] = (double)status;
+        sm[L.red + 1] = (double)it;
+    }
     if (info && lane == 0) {
         info[0] = status;
         info[1] = it;
@@ -648,5 +652,8 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
         info[3] = ls_fail;
     }
 }
+
+__device__ __forceinline__ int sm_status(const double *sm, const LdsMap &L) { return (int)sm[L.red + 0]; }
+__device__ __forceinline__ int sm_iters(const double *sm, const LdsMap &L) { return (int)sm[L.red + 1]; }
 
 }  // namespace amk

@@ -1,0 +1,31 @@
+// Host-side handle of a batch of ObstacleAvoidanceMPC objects (AM/include/HighLvlMpc.h:4-33) and the
+// device workspace of the fused control step.  Shared by mpc_solve.hip and step.hip.
+#pragma once
+#include "mpc_device.h"
+
+struct amk_mpc {
+    double T = 0, dt = 0;
+    int N = 0, K = 0, S = 0, nx = 0, nref = 0;
+    double h_prm[amk::PRM_LEN];
+    amk::SolveOpts opt;
+    size_t lds_bytes = 0;
+    amk::DevBuf<double> prm;  // [PRM_LEN]
+    amk::DevBuf<double> w0;   // [S][nx]  mNlpW0
+    // staging for amk_mpc_solve_host
+    amk::DevBuf<double> st_ref, st_u, st_x0;
+    amk::DevBuf<int> st_info;
+    // control-step workspace (allocated by the first amk_step_batch)
+    amk::DevBuf<float> knn_pts;     // [S][N][K][3] neighbours of every reference point
+    amk::DevBuf<double> knn_d2;     // [S][N][K]
+    amk::DevBuf<float> edge_pt;     // [S][3]       nearest edge point of reference point 0
+    amk::DevBuf<double> edge_d2;    // [S]
+    amk::DevBuf<double> ref_states; // [S][nref]    vecRefStates handed to Solve
+    amk::DevBuf<int> done;          // [S]          scene left the re-plan loop (:333-335)
+};
+
+namespace amk {
+// Launches the solve for every scene of `m` (skipping scenes with d_done[s] != 0 when given).
+// d_ref_path / d_step_flags: control-step mode (refill mRefPath, count solves / iterations).
+int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
+                 double *d_ref_path, int *d_step_flags, hipStream_t stream);
+}  // namespace amk

@@ -3,25 +3,12 @@
 // Replaces AM/include/HighLvlMpc.h:4-33 / AM/src/HighLvlMpc.cpp:5-137 (class
 // ObstacleAvoidanceMPC: constructor defaults, setters, Solve, warm start) and the generated plugin it
 // loads through casadi::nlpsol (AM/tools/mpc_obstacle_casadi.py).  Device algorithm: mpc_device.h.
-#include "mpc_device.h"
+#include "mpc_handle.h"
 
 #include <cmath>
 #include <cstring>
 
 using namespace amk;
-
-struct amk_mpc {
-    double T = 0, dt = 0;
-    int N = 0, K = 0, S = 0, nx = 0, nref = 0;
-    double h_prm[PRM_LEN];
-    SolveOpts opt;
-    size_t lds_bytes = 0;
-    DevBuf<double> prm;   // [PRM_LEN]
-    DevBuf<double> w0;    // [S][nx]  mNlpW0
-    // staging for amk_mpc_solve_host
-    DevBuf<double> st_ref, st_u, st_x0;
-    DevBuf<int> st_info;
-};
 
 namespace {
 
@@ -91,9 +78,11 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, i
                                                        SolveOpts opt, const double *__restrict__ ref_states,
                                                        double *__restrict__ w0, double *__restrict__ u_out,
                                                        double *__restrict__ x0array, int *__restrict__ info,
-                                                       double *trace) {
+                                                       double *trace, const int *__restrict__ done,
+                                                       double *__restrict__ ref_path, int *__restrict__ step_flags) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = blockIdx.x;
+    if (done && done[s]) return;  // control step: this scene left the re-plan loop already
     const LdsMap L(N);
     const double *P = ref_states + (size_t)s * nref;
     SceneIO io;
@@ -110,7 +99,25 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, i
             const int k = e / 14, i = e % 14;
             x0array[(size_t)s * 14 * N + e] = i < SD ? sm[L.X + k * SD + i] : sm[L.U + k * UD + (i - SD)];
         }
+    if (ref_path)  // mRefPath[i] = x0Array[i][0:10], AvoidanceStateMachine.cpp:338-342
+        for (int e = lane; e < SD * N; e += 64) ref_path[(size_t)s * SD * N + e] = sm[L.X + e];
+    if (step_flags && lane == 0) {
+        step_flags[4 * s + 1] += 1;
+        step_flags[4 * s + 2] = sm_status(sm, L);
+        step_flags[4 * s + 3] += sm_iters(sm, L);
+    }
 }
+
+namespace amk {
+int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
+                 double *d_ref_path, int *d_step_flags, hipStream_t stream) {
+    hipLaunchKernelGGL(mpc_solve_kernel, dim3(m->S), dim3(64), m->lds_bytes, stream, m->N, m->K, m->nref, m->nx,
+                       m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path,
+                       d_step_flags);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+}  // namespace amk
 
 extern "C" {
 
@@ -207,10 +214,7 @@ int amk_mpc_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d
                   void *stream) {
     (void)faster;  // mSolver and mSolverFaster carry identical options, HighLvlMpc.cpp:50-52
     if (!m || !d_ref_states || !d_u) return AMK_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(mpc_solve_kernel, dim3(m->S), dim3(64), m->lds_bytes, (hipStream_t)stream, m->N, m->K, m->nref,
-                       m->nx, m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace);
-    AMK_HIP(hipGetLastError());
-    return AMK_OK;
+    return amk::launch_solve(m, d_ref_states, d_u, d_x0array, d_info, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int amk_mpc_get_warm_start(amk_mpc *m, double *d_w, void *stream) {

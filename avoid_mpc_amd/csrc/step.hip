@@ -1,0 +1,216 @@
+// One control step for a batch of scenes on gfx950: the TASK branch of AvoidanceStateMachine::Step
+// (AM/src/AvoidanceStateMachine.cpp:322-355) with the single-frame FrameKDMap queries it makes
+// (AM/src/FrameKDMap.cpp:254-275,322-427), as a fixed sequence of kernels on one stream -- no host
+// round trip between the dual-KD-tree queries, the packing of P and the solves.
+//
+// Per outer iteration (<= mpc_max_iter):
+//   step_scan_kernel<2>  N K-NN queries at the reference points against the obstacle cloud     (:204-215)
+//   step_scan_kernel<1>  1-NN of reference point 0 against the edge cloud                      (:270)
+//   step_plan_kernel     PlanWapionts: nearest-obstacle test, snap to the edge point, re-query (:259-281)
+//   step_pack_kernel     ProcessWaypoints padding/needReplan, early exit, GetRefStates         (:216-257,333-335)
+//   mpc_solve_kernel     Solve + refill of the reference path                                  (:337-342)
+#include "kd_device.h"
+#include "mpc_handle.h"
+
+using namespace amk;
+
+namespace {
+
+__global__ void step_begin_kernel(int S, int *__restrict__ done, int *__restrict__ flags, double *__restrict__ u) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    done[s] = 0;
+    flags[4 * s + 0] = 1;   // isSafety = true (:326)
+    flags[4 * s + 1] = 0;
+    flags[4 * s + 2] = -1;
+    flags[4 * s + 3] = 0;
+    u[4 * s + 0] = u[4 * s + 1] = u[4 * s + 2] = u[4 * s + 3] = 0.0;
+}
+
+// Raw k nearest neighbours (nanoflann's own answer: min(k, size) entries, no adaptor count rule) of
+// n_queries reference points per scene; queries are read in place from the reference path
+// (stride 10 doubles).  Empty slots: distance DBL_MAX.
+template <int QPW>
+__global__ __launch_bounds__(kWave) void step_scan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                          const float *__restrict__ Z, int cap,
+                                                          const int *__restrict__ sizes, int n_scenes,
+                                                          const double *__restrict__ ref_path, int N, int n_queries,
+                                                          int k, float *__restrict__ out_pts,
+                                                          double *__restrict__ out_d2, const int *__restrict__ done) {
+    const int groups = (n_queries + QPW - 1) / QPW;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / groups) * 8 + xcd;  // all query groups of a scene share one XCD's L2
+    const int g = j % groups;
+    if (s >= n_scenes || done[s]) return;
+    const int lane = threadIdx.x;
+    const int size = sizes[s];
+    const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+    double qx[QPW], qy[QPW], qz[QPW], ld[QPW];
+    int li[QPW];
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq) {
+        int q = g * QPW + qq;
+        q = q < n_queries ? q : n_queries - 1;
+        const double *qp = ref_path + ((size_t)s * N + q) * SD;
+        qx[qq] = qp[0];
+        qy[qq] = qp[1];
+        qz[qq] = qp[2];
+    }
+    scan_cloud<QPW>(xs, ys, zs, size, qx, qy, qz, k, ld, li);
+#pragma unroll
+    for (int qq = 0; qq < QPW; ++qq) {
+        const int q = g * QPW + qq;
+        if (q >= n_queries) break;
+        const size_t row = (size_t)s * n_queries + q;
+        if (lane < k) {
+            const bool ok = li[qq] != kNoIndex;
+            out_d2[row * k + lane] = ok ? ld[qq] : DBL_MAX;
+            float *o = out_pts + (row * k + lane) * 3;
+            o[0] = ok ? xs[li[qq]] : 0.f;
+            o[1] = ok ? ys[li[qq]] : 0.f;
+            o[2] = ok ? zs[li[qq]] : 0.f;
+        }
+    }
+}
+
+// PlanWapionts (:259-281) for reference point 0; one wavefront per scene.
+__global__ __launch_bounds__(kWave) void step_plan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                          const float *__restrict__ Z, int cap,
+                                                          const int *__restrict__ sizes_obs,
+                                                          const int *__restrict__ sizes_edge, int N, int K,
+                                                          double safety_distance, double *__restrict__ ref_path,
+                                                          float *__restrict__ knn_pts, double *__restrict__ knn_d2,
+                                                          const float *__restrict__ edge_pt,
+                                                          const double *__restrict__ edge_d2,
+                                                          const int *__restrict__ done, int *__restrict__ flags) {
+    const int s = blockIdx.x;
+    if (done[s]) return;
+    const int lane = threadIdx.x;
+    const int size_o = sizes_obs[s];
+    // GetNearestDistance (FrameKDMap.cpp:400-427): SearchForNearest(p, 1) -> no result unless the cloud
+    // holds more than one point (kd_tree_two.h:119-124); DBL_MAX then.
+    const double d2n = (size_o > 1) ? knn_d2[(size_t)s * N * K] : DBL_MAX;
+    const double nearest = sqrt(d2n);
+    int is_safety = 1;
+    if (!(nearest > safety_distance)) {
+        // QueryNearest(p1, 1, edgePts, distances, true) (:270): one result iff the edge cloud has > 1 point
+        const bool has_edge = sizes_edge[s] > 1 && edge_d2[s] < DBL_MAX;
+        if (!has_edge) {
+            is_safety = 0;
+        } else {
+            double *p1 = ref_path + (size_t)s * N * SD;
+            const double ex = (double)edge_pt[3 * s + 0], ey = (double)edge_pt[3 * s + 1], ez = (double)edge_pt[3 * s + 2];
+            // the snapped point is what ProcessWaypoints queries next (:210-215): redo query 0
+            const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+            const double qx[1] = {ex}, qy[1] = {ey}, qz[1] = {ez};
+            double ld[1];
+            int li[1];
+            scan_cloud<1>(xs, ys, zs, size_o, qx, qy, qz, K, ld, li);
+            if (lane < K) {
+                const bool ok = li[0] != kNoIndex;
+                knn_d2[(size_t)s * N * K + lane] = ok ? ld[0] : DBL_MAX;
+                float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
+                o[0] = ok ? xs[li[0]] : 0.f;
+                o[1] = ok ? ys[li[0]] : 0.f;
+                o[2] = ok ? zs[li[0]] : 0.f;
+            }
+            if (lane == 0) {
+                p1[0] = ex;
+                p1[1] = ey;
+                p1[2] = ez;
+            }
+        }
+    }
+    if (lane == 0) flags[4 * s + 0] = is_safety;
+}
+
+// ProcessWaypoints' padding and needReplan (:216-231), the early exit (:333-335) and GetRefStates
+// (:236-257).  One wavefront per scene.
+__global__ __launch_bounds__(kWave) void step_pack_kernel(const int *__restrict__ sizes_obs, int N, int K, int nref,
+                                                          int iter, int max_iter, double speed, double T,
+                                                          double safety_distance,
+                                                          const double *__restrict__ state_quad,
+                                                          const double *__restrict__ pos_x,
+                                                          const double *__restrict__ ref_path,
+                                                          const float *__restrict__ knn_pts,
+                                                          const double *__restrict__ knn_d2,
+                                                          double *__restrict__ ref_states, int *__restrict__ done,
+                                                          const int *__restrict__ flags) {
+    const int s = blockIdx.x;
+    if (done[s]) return;
+    const int lane = threadIdx.x;
+    // QueryNearest through either path returns K points iff the cloud holds more than K, else none
+    // (FrameKDMap.cpp:298,339-345 + kd_tree_two.h:119-124)
+    const int cnt = sizes_obs[s] > K ? K : 0;
+    bool need = false;
+    if (lane < N) need = (cnt == 0) || (sqrt(knn_d2[((size_t)s * N + lane) * K]) <= safety_distance);
+    const bool need_replan = __ballot(need) != 0ull;
+    if (!need_replan && iter > 0 && flags[4 * s + 0]) {  // :333-335
+        if (lane == 0) done[s] = 1;
+        return;
+    }
+    double *P = ref_states + (size_t)s * nref;
+    const double *sq = state_quad + ((size_t)s * max_iter + iter) * SD;
+    const double *rp = ref_path + (size_t)s * N * SD;
+    if (lane < SD) P[lane] = sq[lane];
+    for (int e = lane; e < SD * N; e += 64) P[SD + e] = rp[e];
+    for (int e = lane; e < 3 * K * N; e += 64) {
+        const int j = (e / 3) % K;
+        P[SD + SD * N + e] = (j < cnt) ? (double)knn_pts[(size_t)s * N * K * 3 + e] : 10000.0;  // :223-226
+    }
+    if (lane < SD) {
+        const double *last = rp + (N - 1) * SD;
+        double v = last[lane];
+        if (lane == 0) {
+            double dX = speed * T - fmax(0., last[0] - pos_x[s]);
+            dX = fmax(0., dX);
+            v += dX;
+        }
+        if (lane == 1) v = 0.;
+        P[SD + SD * N + 3 * K * N + lane] = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *prm,
+                              const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
+                              double *d_x0array, int *d_flags, void *stream_) {
+    if (!obstacle || !edge || !mpc || !prm || !d_state_quad || !d_pos_x || !d_ref_path || !d_u || !d_flags)
+        return AMK_ERR_INVALID_ARG;
+    if (obstacle->n_scenes != mpc->S || edge->n_scenes != mpc->S) return AMK_ERR_INVALID_ARG;
+    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int S = mpc->S, N = mpc->N, K = mpc->K;
+    if (!mpc->done.p) {
+        AMK_HIP(mpc->knn_pts.alloc((size_t)S * N * K * 3));
+        AMK_HIP(mpc->knn_d2.alloc((size_t)S * N * K));
+        AMK_HIP(mpc->edge_pt.alloc((size_t)S * 3));
+        AMK_HIP(mpc->edge_d2.alloc(S));
+        AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
+        AMK_HIP(mpc->done.alloc(S));
+    }
+    hipLaunchKernelGGL(step_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
+    const int groups = (N + 1) / 2;
+    const int S8 = (S + 7) / 8 * 8;
+    for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
+        hipLaunchKernelGGL(step_scan_kernel<2>, dim3(S8 * groups), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
+                           obstacle->z.p, obstacle->cap, obstacle->size.p, S, d_ref_path, N, N, K, mpc->knn_pts.p,
+                           mpc->knn_d2.p, mpc->done.p);
+        hipLaunchKernelGGL(step_scan_kernel<1>, dim3(S8), dim3(kWave), 0, stream, edge->x.p, edge->y.p, edge->z.p,
+                           edge->cap, edge->size.p, S, d_ref_path, N, 1, 1, mpc->edge_pt.p, mpc->edge_d2.p,
+                           mpc->done.p);
+        hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
+                           obstacle->z.p, obstacle->cap, obstacle->size.p, edge->size.p, N, K, prm->safety_distance,
+                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p,
+                           d_flags);
+        hipLaunchKernelGGL(step_pack_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->size.p, N, K, mpc->nref, iter,
+                           prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
+                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
+        AMK_HIP(hipGetLastError());
+        int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
+        if (st != AMK_OK) return st;
+    }
+    return AMK_OK;
+}

@@ -1,0 +1,153 @@
+"""CPU: pins for the MPC half of the oracle.  PARITY UNPINNED against the reference's CasADi+IPOPT
+(absent, see oracle/mpc_oracle.c); the substitutes are
+  * the numpy twin (oracle/mpc_oracle_np.py) -- function values, derivatives, solver iterates
+  * finite differences of the restated objective / constraints
+  * the lambda = 0 case, an equality-constrained QP with a dense KKT solution (fixture)
+  * the reference's own smoke scenario (mpc_obstacle_casadi.py:448-498) against the converged
+    optimum of scipy's L-BFGS-B (fixture tests/golden/mpc_golden.npz)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+import mpc_oracle_np as M  # noqa: E402
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_golden.npz"))
+N, K, DT = 30, 3, 0.033
+
+
+def _rand_w(rng):
+    w = rng.normal(size=10 + 14 * N)
+    X, U = M.unpack_w(w, N)
+    X[:, 0:3] += np.array([1.0, 0.0, 1.0])
+    return M.pack_w(X, U)
+
+
+def test_layout_sizes(oracle):
+    for n, k, plen in ((10, 3, 244), (20, 8, 734), (30, 8, 1074)):
+        assert oracle.mpco_p_len(n, k) == plen == M.p_len(n, k)
+
+
+def test_dynamics_are_affine_with_the_documented_structure(oracle):
+    tau = np.array(synth.DEFAULT_TAU)
+    A = np.zeros(100); B = np.zeros(40); c = np.zeros(10)
+    oracle.mpco_affine(tau, DT, A, B, c)
+    A, B = A.reshape(10, 10), B.reshape(10, 4)
+    An, Bn, cn = M.affine_dynamics(tau, DT)
+    assert np.allclose(A, An, atol=1e-15) and np.allclose(B, Bn, atol=1e-15) and np.allclose(c, cn, atol=1e-15)
+    assert np.count_nonzero(A) == 19 and np.count_nonzero(B) == 10 and np.count_nonzero(c) == 3
+    # SURVEY.md appendix A probe values (yaml tau, dt = 0.033)
+    assert abs(A[7, 7] - 0.81771) < 1e-5 and abs(A[8, 8] - 0.81452) < 1e-5 and abs(A[9, 9] - 0.59373) < 1e-5
+    assert abs(c[9] + 3.98555) < 1e-5
+    rng = np.random.default_rng(0)
+    x, u = rng.normal(size=10), rng.normal(size=4)
+    f = np.zeros(10); oracle.mpco_rk4_step(x, u, tau, DT, f)
+    assert np.allclose(f, A @ x + B @ u + c, atol=1e-13)
+    assert np.allclose(f, M.rk4_step(x, u, tau, DT), atol=1e-15)
+
+
+def test_c_equals_numpy_on_values_and_derivatives(oracle):
+    P = G["smoke.P"]
+    rng = np.random.default_rng(1)
+    for _ in range(5):
+        w = _rand_w(rng)
+        assert abs(oracle.mpco_nlp_f(w, P, N, K) - M.nlp_f(w, P, N, K)) < 1e-10
+        g = np.zeros_like(w); oracle.mpco_nlp_grad_f(w, P, N, K, g)
+        assert np.abs(g - M.nlp_grad_f(w, P, N, K)).max() < 1e-10
+        Qs = np.zeros(N * 100); Rs = np.zeros(N * 4); oracle.mpco_nlp_hess_blocks(w, P, N, K, Qs, Rs)
+        H = M.nlp_hess_f(w, P, N, K, majorise_abs=True)
+        for k in range(N):
+            ix = slice(14 * (k + 1), 14 * (k + 1) + 10)
+            assert np.abs(H[ix, ix] - Qs[100 * k:100 * k + 100].reshape(10, 10)).max() < 1e-9
+            iu = slice(14 * k + 10, 14 * k + 14)
+            assert np.allclose(np.diag(H[iu, iu]), Rs[4 * k:4 * k + 4])
+        cg = np.zeros(10 + 10 * N); oracle.mpco_nlp_g(w, P, N, K, DT, cg)
+        assert np.abs(cg - M.nlp_g(w, P, N, K, DT)).max() < 1e-13
+
+
+def test_finite_differences():
+    P = G["smoke.P"]
+    w = _rand_w(np.random.default_rng(2))
+    h = 1e-6
+    g = M.nlp_grad_f(w, P, N, K)
+    H = M.nlp_hess_f(w, P, N, K, majorise_abs=False)
+    J = M.nlp_jac_g(w, P, N, K, DT)
+    gfd = np.zeros_like(g); Hfd = np.zeros_like(H); Jfd = np.zeros_like(J)
+    for i in range(len(w)):
+        e = np.zeros_like(w); e[i] = h
+        gfd[i] = (M.nlp_f(w + e, P, N, K) - M.nlp_f(w - e, P, N, K)) / (2 * h)
+        Hfd[:, i] = (M.nlp_grad_f(w + e, P, N, K) - M.nlp_grad_f(w - e, P, N, K)) / (2 * h)
+        Jfd[:, i] = (M.nlp_g(w + e, P, N, K, DT) - M.nlp_g(w - e, P, N, K, DT)) / (2 * h)
+    assert np.abs(g - gfd).max() < 1e-5 * max(1.0, np.abs(g).max())
+    assert np.abs(H - Hfd).max() < 1e-5 * max(1.0, np.abs(H).max())
+    assert np.abs(J - Jfd).max() < 1e-7
+    # structure claimed in SURVEY.md §8 a17/a18
+    assert np.count_nonzero(np.abs(J) > 1e-14) == 10 + 39 * N
+
+
+def test_lambda_zero_is_a_qp_with_the_dense_kkt_solution(oracle):
+    """collide_lambda = 0: equality-constrained QP; wide bounds keep the box inactive."""
+    P, wq = G["qp.P"], G["qp.w"]
+    lb, ub = np.full(4, -100.0), np.full(4, 100.0)
+    w, info, stats = _oracle.mpco_solve(P, G["smoke.w0"], lb, ub, N, K, DT, tol=1e-8, max_iter=40)
+    assert info[0] == 0
+    assert np.abs(w - wq).max() < 1e-5
+    assert abs(stats[0] - float(G["qp.f"])) < 1e-6
+
+
+def test_smoke_scenario_reaches_the_scipy_optimum(oracle):
+    """The reference's own smoke scenario.  The abs() term makes the optimum a kink point, so the KKT
+    residual does not vanish; the objective does converge to the L-BFGS-B value and the path swerves
+    around the cylinder (radius 0.1 at x = 1; the penalty is soft, so not by the full drone radius)."""
+    P, w0, lbu, ubu = G["smoke.P"], G["smoke.w0"], G["smoke.lbu"], G["smoke.ubu"]
+    f_star = float(G["smoke.scipy_fun"])
+    w, info, stats = _oracle.mpco_solve(P, w0, lbu, ubu, N, K, DT, max_iter=80)
+    assert abs(stats[0] - f_star) < 1e-3 * f_star, (stats[0], f_star)
+    Us = G["smoke.scipy_U"].reshape(N, 4)
+    U = np.stack([w[14 * k + 10:14 * k + 14] for k in range(N)])
+    assert np.abs(U - Us).max() < 0.05
+    X = np.stack([w[14 * k:14 * k + 10] for k in range(N + 1)])
+    near = np.abs(X[:, 0] - 1.0) < 0.3
+    assert np.all(np.hypot(X[near, 0] - 1.0, X[near, 1]) > 0.3)
+    # ten iterations (the reference's cap) already descend monotonically towards it
+    w10, info10, st10 = _oracle.mpco_solve(P, w0, lbu, ubu, N, K, DT, max_iter=10)
+    assert info10[1] == 10 and st10[0] < M.nlp_f(M.pack_w(M.rollout(P[:10], np.tile([0, 0, 9.81, 0.0], (N, 1)),
+                                                  *M.affine_dynamics(P[-30:-26], DT)), np.tile([0, 0, 9.81, 0.0], (N, 1))), P, N, K)
+
+
+def test_c_solver_equals_numpy_solver_iterate_for_iterate(oracle):
+    P, w0, lbu, ubu = G["smoke.P"], G["smoke.w0"], G["smoke.lbu"], G["smoke.ubu"]
+    for mi in (1, 5, 10, 25):
+        wc, info, stats = _oracle.mpco_solve(P, w0, lbu, ubu, N, K, DT, max_iter=mi)
+        wn, inf = M.ipm_solve(P, w0, lbu, ubu, N, K, DT, M.IpmOptions(max_iter=mi))
+        assert np.abs(wc - wn).max() < 1e-9
+        assert info[1] == inf["iters"] and info[2] == inf["n_reg"] and info[3] == inf["ls_fail"]
+
+
+def test_mpc_object_semantics(oracle):
+    """ObstacleAvoidanceMPC restated: constructor defaults (HighLvlMpc.cpp:13-16,26-35,53-56), the
+    appended parameter tail (:97-107), warm start carried between calls (:110,129)."""
+    prm = synth.MpcParams(T=0.33, K=3)
+    sc = synth.make_scene(5000, 5, prm)
+    kd, ke = _oracle.kd_oracle(sc["cloud"]), _oracle.kd_oracle(sc["edge"])
+    m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)
+    r = _oracle.step_oracle(kd, ke, m, prm, _oracle.scene_state_quads(sc, prm), sc["pos"][0], sc["ref_path"].copy(), True)
+    ref0 = r["ref_log"][0]
+    m2 = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m2.configure(prm)
+    assert m2.N == 10 and np.all(m2.warm_start == 0)
+    u, x0, info = m2.Solve(ref0)
+    Pfull = np.concatenate([ref0, prm.gain, prm.tau, prm.weights, [prm.radius]])
+    lbu = [-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot]
+    ubu = [prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot]
+    w, _, _ = _oracle.mpco_solve(Pfull, np.zeros(150), lbu, ubu, 10, 3, prm.dt)
+    assert np.array_equal(u, w[10:14]) and np.array_equal(x0.reshape(-1), w[:140])
+    assert np.array_equal(m2.warm_start, w)
+    u2, _, _ = m2.Solve(ref0)                                   # warm-started second call differs
+    w2, _, _ = _oracle.mpco_solve(Pfull, w, lbu, ubu, 10, 3, prm.dt)
+    assert np.array_equal(u2, w2[10:14])
+    assert np.all(u >= np.array(lbu) - 1e-9) and np.all(u <= np.array(ubu) + 1e-9)
