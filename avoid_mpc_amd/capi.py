@@ -48,6 +48,14 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise AmkError(f"{LIB_PATH} is missing: build it with `python -m avoid_mpc_amd.build` "
                        "(hipcc, gfx950).  There is no CPU fallback.")
+    # One HIP runtime per process: PyTorch-ROCm wheels bundle their own libamdhip64; if the system
+    # copy (which this library is linked against) is mapped first, the process ends up with two
+    # runtimes and the second one sees no device.  Map torch's first when torch is installed; a
+    # torch-free C++ host simply uses the system runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp, i, d, ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
     sig = {

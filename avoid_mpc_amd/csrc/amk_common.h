@@ -6,6 +6,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 #include "../../include/avoid_mpc_amd.h"
 
@@ -45,6 +46,18 @@ struct DevBuf {
         n = 0;
     }
     ~DevBuf() { release(); }
+};
+
+// ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
+// Off by default; internal (amk__timing_* are not part of the C ABI in include/avoid_mpc_amd.h).
+enum KernelClass { KC_COMPACT = 0, KC_SCAN_OBS, KC_SCAN_EDGE, KC_PLAN, KC_PACK, KC_SOLVE, KC_BEGIN, KC_COUNT };
+struct Timing;
+Timing &timing();
+struct TimedLaunch {  // RAII: records an event before and after the enclosed launch when enabled
+    TimedLaunch(int kclass, hipStream_t stream);
+    ~TimedLaunch();
+    int slot;
+    hipStream_t stream;
 };
 
 }  // namespace amk

@@ -18,6 +18,49 @@
 
 namespace amk {
 thread_local int g_last_hip_error = 0;
+
+struct Timing {
+    int mode = 0;  // 0 off, 1 KC_SOLVE only, 2 every kernel class
+    struct Rec { int kclass; hipEvent_t a, b; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Timing &timing() { static Timing t; return t; }
+
+TimedLaunch::TimedLaunch(int kclass, hipStream_t s) : slot(-1), stream(s) {
+    Timing &t = timing();
+    if (t.mode == 0 || (t.mode == 1 && kclass != KC_SOLVE)) return;
+    Timing::Rec r{kclass, t.get(), t.get()};
+    (void)hipEventRecord(r.a, stream);
+    slot = (int)t.recs.size();
+    t.recs.push_back(r);
+}
+TimedLaunch::~TimedLaunch() {
+    if (slot >= 0) (void)hipEventRecord(timing().recs[slot].b, stream);
+}
+}  // namespace amk
+
+extern "C" void amk__timing_enable(int mode) { amk::timing().mode = mode; }
+// Waits for the recorded events; adds elapsed milliseconds / launch counts per kernel class; resets.
+extern "C" int amk__timing_collect(double *ms, int *counts) {
+    amk::Timing &t = amk::timing();
+    for (int i = 0; i < amk::KC_COUNT; ++i) { ms[i] = 0.0; counts[i] = 0; }
+    for (auto &r : t.recs) {
+        float f = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&f, r.a, r.b) != hipSuccess) return AMK_ERR_HIP;
+        ms[r.kclass] += f;
+        counts[r.kclass] += 1;
+        t.pool.push_back(r.a);
+        t.pool.push_back(r.b);
+    }
+    t.recs.clear();
+    return AMK_OK;
 }
 
 using amk::kWave;
@@ -197,6 +240,7 @@ int amk_kd_destroy(amk_kd *kd) {
 int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
                  const int *d_counts, void *stream) {
     if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
+    amk::TimedLaunch tl(amk::KC_COMPACT, (hipStream_t)stream);
     hipLaunchKernelGGL(kd_compact_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
                        point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
                        kd->size.p);

@@ -111,6 +111,7 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, i
 namespace amk {
 int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
                  double *d_ref_path, int *d_step_flags, hipStream_t stream) {
+    TimedLaunch tl(KC_SOLVE, stream);
     hipLaunchKernelGGL(mpc_solve_kernel, dim3(m->S), dim3(64), m->lds_bytes, stream, m->N, m->K, m->nref, m->nx,
                        m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path,
                        d_step_flags);

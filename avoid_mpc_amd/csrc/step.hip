@@ -191,23 +191,28 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
         AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
         AMK_HIP(mpc->done.alloc(S));
     }
-    hipLaunchKernelGGL(step_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
+    { TimedLaunch tl(KC_BEGIN, stream);
+    hipLaunchKernelGGL(step_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u); }
     const int groups = (N + 1) / 2;
     const int S8 = (S + 7) / 8 * 8;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
+        { TimedLaunch tl(KC_SCAN_OBS, stream);
         hipLaunchKernelGGL(step_scan_kernel<2>, dim3(S8 * groups), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
                            obstacle->z.p, obstacle->cap, obstacle->size.p, S, d_ref_path, N, N, K, mpc->knn_pts.p,
-                           mpc->knn_d2.p, mpc->done.p);
+                           mpc->knn_d2.p, mpc->done.p); }
+        { TimedLaunch tl(KC_SCAN_EDGE, stream);
         hipLaunchKernelGGL(step_scan_kernel<1>, dim3(S8), dim3(kWave), 0, stream, edge->x.p, edge->y.p, edge->z.p,
                            edge->cap, edge->size.p, S, d_ref_path, N, 1, 1, mpc->edge_pt.p, mpc->edge_d2.p,
-                           mpc->done.p);
+                           mpc->done.p); }
+        { TimedLaunch tl(KC_PLAN, stream);
         hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
                            obstacle->z.p, obstacle->cap, obstacle->size.p, edge->size.p, N, K, prm->safety_distance,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p,
-                           d_flags);
+                           d_flags); }
+        { TimedLaunch tl(KC_PACK, stream);
         hipLaunchKernelGGL(step_pack_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->size.p, N, K, mpc->nref, iter,
                            prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
-                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
+                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags); }
         AMK_HIP(hipGetLastError());
         int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
         if (st != AMK_OK) return st;
