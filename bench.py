@@ -155,7 +155,7 @@ def main():
     out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
                x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
                flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
-    gathered = [torch.empty_like(out["u"]) for _ in range(world)] if world > 1 else None
+    from avoid_mpc_amd import shard
 
     def one_step():
         ref_d.copy_(ref0_d)                 # fresh frame: mRefPath after GetInitPath
@@ -164,7 +164,7 @@ def main():
         kd_e.build(edges)                   # ... and edge index (FrameKDMap.cpp:44-47)
         step_batch(kd_o, kd_e, mpc, prm, sq_d, posx_d, ref_d, out=out)
         if world > 1:
-            dist.all_gather(gathered, out["u"])   # the one exchange step: controls to every rank
+            shard.gather_controls(out["u"])       # the one exchange step: controls to every rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -184,10 +184,7 @@ def main():
     ms = (C.c_double * 8)(); cnt = (C.c_int * 8)()
     capi.check(lib.amk__timing_collect(ms, cnt), "timing")
     lib.amk__timing_enable(0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = shard.max_over_ranks(dt, dev)
 
     flags = out["flags"].cpu().numpy()
     solves = float(flags[:, 1].mean()); ipm_iters = float(flags[:, 3].mean())
