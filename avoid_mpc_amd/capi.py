@@ -24,7 +24,7 @@ SYMBOLS = [
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
-    "amk_mpc_solve_host", "amk_step_batch",
+    "amk_mpc_solve_host", "amk_step_batch", "amk_step_batch_host",
 ]
 
 
@@ -87,6 +87,7 @@ def load():
         "amk_mpc_reset_warm_start": (i, [vp, vp]),
         "amk_mpc_solve_host": (i, [vp, vp, vp, vp, vp, i]),
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
+        "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(lib, name, None)

@@ -21,6 +21,9 @@ struct amk_mpc {
     amk::DevBuf<double> edge_d2;    // [S]
     amk::DevBuf<double> ref_states; // [S][nref]    vecRefStates handed to Solve
     amk::DevBuf<int> done;          // [S]          scene left the re-plan loop (:333-335)
+    // staging for amk_step_batch_host
+    amk::DevBuf<double> sh_sq, sh_posx, sh_ref, sh_u, sh_x0;
+    amk::DevBuf<int> sh_flags;
 };
 
 namespace amk {

@@ -219,3 +219,31 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     }
     return AMK_OK;
 }
+
+extern "C" int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *prm,
+                                   const double *h_state_quad, const double *h_pos_x, double *h_ref_path, double *h_u,
+                                   double *h_x0array, int *h_flags) {
+    if (!mpc || !prm || !h_state_quad || !h_pos_x || !h_ref_path || !h_u || !h_flags) return AMK_ERR_INVALID_ARG;
+    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER) return AMK_ERR_INVALID_ARG;
+    const size_t S = mpc->S, N = mpc->N, mi = prm->mpc_max_iter;
+    if (mpc->sh_sq.n < S * mi * SD) AMK_HIP(mpc->sh_sq.alloc(S * AMK_MAX_OUTER_ITER * SD));
+    if (!mpc->sh_ref.p) {
+        AMK_HIP(mpc->sh_posx.alloc(S));
+        AMK_HIP(mpc->sh_ref.alloc(S * N * SD));
+        AMK_HIP(mpc->sh_u.alloc(S * 4));
+        AMK_HIP(mpc->sh_x0.alloc(S * N * 14));
+        AMK_HIP(mpc->sh_flags.alloc(S * 4));
+    }
+    AMK_HIP(hipMemcpy(mpc->sh_sq.p, h_state_quad, sizeof(double) * S * mi * SD, hipMemcpyHostToDevice));
+    AMK_HIP(hipMemcpy(mpc->sh_posx.p, h_pos_x, sizeof(double) * S, hipMemcpyHostToDevice));
+    AMK_HIP(hipMemcpy(mpc->sh_ref.p, h_ref_path, sizeof(double) * S * N * SD, hipMemcpyHostToDevice));
+    int st = amk_step_batch(obstacle, edge, mpc, prm, mpc->sh_sq.p, mpc->sh_posx.p, mpc->sh_ref.p, mpc->sh_u.p,
+                            mpc->sh_x0.p, mpc->sh_flags.p, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h_ref_path, mpc->sh_ref.p, sizeof(double) * S * N * SD, hipMemcpyDeviceToHost));
+    AMK_HIP(hipMemcpy(h_u, mpc->sh_u.p, sizeof(double) * S * 4, hipMemcpyDeviceToHost));
+    if (h_x0array) AMK_HIP(hipMemcpy(h_x0array, mpc->sh_x0.p, sizeof(double) * S * N * 14, hipMemcpyDeviceToHost));
+    AMK_HIP(hipMemcpy(h_flags, mpc->sh_flags.p, sizeof(int) * S * 4, hipMemcpyDeviceToHost));
+    return AMK_OK;
+}

@@ -160,6 +160,12 @@ int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_
                    const double *d_state_quad, const double *d_pos_x, double *d_ref_path,
                    double *d_u, double *d_x0array, int *d_flags, void *stream);
 
+/* Same with host buffers (stages through device memory, synchronises); what a single-robot host
+ * (S = 1) calls once per control period.                                                         */
+int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *params,
+                        const double *h_state_quad, const double *h_pos_x, double *h_ref_path,
+                        double *h_u, double *h_x0array, int *h_flags);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,143 @@
+// FrameKDMap's query front end with the reference's interface (AM/include/FrameKDMap.h:60-67,
+// AM/src/FrameKDMap.cpp:34-74,254-427) on top of KDTreeTwo (kd_tree_two.hpp -> C ABI).
+//
+// In scope: per-frame dual trees, the query list [cur, keyframes[0..size-2]]
+// (FrameKDMap.cpp:64-74), the fast path / multi-frame merge of QueryNearest (:322-376) and
+// GetNearestDistance (:400-427).  Out of scope here: depth image -> clouds (ProcessDepth /
+// BuildEdgeCloud, §8 f2/f3) -- AddVertex takes the two clouds directly -- and the keyframe
+// maintenance thread (§8 f1).  The reference fans frames out over std::threads; every per-frame search
+// here is one device call, so the loop is sequential on the host.
+#pragma once
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <functional>
+#include <list>
+#include <memory>
+#include <mutex>
+#include <vector>
+
+#include "kd_tree_two.hpp"
+
+namespace avoid_mpc_amd {
+
+#if __has_include(<Eigen/Core>)
+}  // namespace avoid_mpc_amd
+#include <Eigen/Core>
+namespace avoid_mpc_amd {
+using Vector3d = Eigen::Vector3d;
+inline double vx(const Vector3d &v) { return v.x(); }
+inline double vy(const Vector3d &v) { return v.y(); }
+inline double vz(const Vector3d &v) { return v.z(); }
+#else
+struct Vector3d {
+    double x_, y_, z_;
+    Vector3d() : x_(0), y_(0), z_(0) {}
+    Vector3d(double x, double y, double z) : x_(x), y_(y), z_(z) {}
+    double x() const { return x_; }
+    double y() const { return y_; }
+    double z() const { return z_; }
+};
+inline double vx(const Vector3d &v) { return v.x(); }
+inline double vy(const Vector3d &v) { return v.y(); }
+inline double vz(const Vector3d &v) { return v.z(); }
+#endif
+
+class FrameKDMap {
+public:
+    using PtCloudKdPtr = std::shared_ptr<KDTreeTwo<double>>;
+    struct Frame {
+        PtCloudKdPtr pointCloud;
+        PtCloudKdPtr edgeCloud;
+    };
+
+    // PtIsInFrame (FrameKDMap.cpp:215-231) needs the camera model; the default accepts every point
+    // (both query paths return the same neighbours for a single-frame map).
+    std::function<bool(const Vector3d &)> ptIsInCurFrame = [](const Vector3d &) { return true; };
+
+    // AddVertex after ProcessDepth (FrameKDMap.cpp:39-51): two fresh trees, then swap under the lock.
+    template <class CloudPtr>
+    void AddVertex(CloudPtr const &cloud, CloudPtr const &edgeCloud) {
+        if (cloud->points.empty()) return;  // :39-41
+        PtCloudKdPtr kdtree = std::make_shared<KDTreeTwo<double>>();
+        kdtree->InitializeNew(cloud);
+        PtCloudKdPtr edgeKdtree = std::make_shared<KDTreeTwo<double>>();
+        edgeKdtree->InitializeNew(edgeCloud);
+        std::lock_guard<std::mutex> lock(mMtxKdTree);
+        mCurFrame.pointCloud = kdtree;
+        mCurFrame.edgeCloud = edgeKdtree;
+        UpdateQueryVector();
+    }
+    void InsertKeyFrame() {  // FrameKDMap.cpp:428-431
+        std::lock_guard<std::mutex> lock(mMtxKdTree);
+        mKeyFrameMap.push_back(mCurFrame);
+    }
+    const Frame &CurFrame() const { return mCurFrame; }
+
+    void QueryNearest(const Vector3d &point, int nearestPointCount, std::vector<Vector3d> &nearestPoints,
+                      std::vector<double> &distances, bool queryEdge = false) {  // :322-376
+        struct PtDists { Vector3d pt; double dist; };
+        std::vector<PtDists> pointsDist;
+        std::lock_guard<std::mutex> lock(mMtxKdTree);
+        PtCloudKdPtr cur = queryEdge ? mCurFrame.edgeCloud : mCurFrame.pointCloud;
+        if (cur) {
+            const int first = (int)cur->GetPointCloud().pts.size();
+            if (first >= nearestPointCount && ptIsInCurFrame(point)) {  // fast path :339-345
+                cur->SearchForNearest(vx(point), vy(point), vz(point), nearestPointCount);
+                nearestPoints.clear();
+                distances.clear();
+                for (size_t i = 0; i < cur->squared_distances.size(); ++i) {
+                    nearestPoints.push_back(Vector3d(cur->closest_pts[i].x, cur->closest_pts[i].y, cur->closest_pts[i].z));
+                    distances.push_back(cur->squared_distances[i]);
+                }
+                return;
+            }
+        }
+        for (auto &fr : mVecQueryVector) {  // :347-364 (one worker per frame in the reference)
+            PtCloudKdPtr pc = queryEdge ? fr.edgeCloud : fr.pointCloud;
+            if (!pc) continue;
+            const int queryPointCount = std::min(nearestPointCount, (int)pc->GetPointCloud().pts.size());  // :298
+            pc->SearchForNearest(vx(point), vy(point), vz(point), queryPointCount);
+            for (size_t j = 0; j < pc->squared_distances.size(); ++j)
+                pointsDist.push_back({Vector3d(pc->closest_pts[j].x, pc->closest_pts[j].y, pc->closest_pts[j].z),
+                                      pc->squared_distances[j]});
+        }
+        nearestPoints.clear();
+        distances.clear();
+        if (pointsDist.empty()) return;
+        std::sort(pointsDist.begin(), pointsDist.end(), [](const PtDists &a, const PtDists &b) { return a.dist < b.dist; });
+        for (int i = 0; i < nearestPointCount && i < (int)pointsDist.size(); ++i) {  // :372-375
+            nearestPoints.push_back(pointsDist[i].pt);
+            distances.push_back(pointsDist[i].dist);
+        }
+    }
+
+    double GetNearestDistance(const Vector3d &point) {  // :400-427
+        double nearestDistance = DBL_MAX;
+        std::lock_guard<std::mutex> lock(mMtxKdTree);
+        if (mVecQueryVector.empty()) return nearestDistance;
+        for (auto &fr : mVecQueryVector) {
+            if (!fr.pointCloud || fr.pointCloud->GetPointCloud().pts.empty()) continue;  // :385-387
+            fr.pointCloud->SearchForNearest(vx(point), vy(point), vz(point), 1);
+            if (!fr.pointCloud->squared_distances.empty())
+                nearestDistance = std::min(nearestDistance, fr.pointCloud->squared_distances[0]);
+        }
+        return std::sqrt(nearestDistance);
+    }
+
+private:
+    void UpdateQueryVector() {  // :64-74: current frame + all key frames but the newest
+        mVecQueryVector.clear();
+        mVecQueryVector.push_back(mCurFrame);
+        if (!mKeyFrameMap.empty()) {
+            auto it = mKeyFrameMap.begin();
+            for (size_t i = 0; i + 1 < mKeyFrameMap.size(); ++i, ++it) mVecQueryVector.push_back(*it);
+        }
+    }
+    std::list<Frame> mKeyFrameMap;
+    std::vector<Frame> mVecQueryVector;
+    Frame mCurFrame;
+    std::mutex mMtxKdTree;
+};
+
+}  // namespace avoid_mpc_amd

@@ -1,0 +1,110 @@
+// Exercises the reference-shaped C++ adapters (include/avoid_mpc_amd/*.hpp) the way the reference's
+// own code uses the classes they replace; driven by tests/test_cpp_adapters_gpu.py, which compares
+// the numbers written here with the oracle.
+//   adapter_demo <in.bin> <out.bin>
+// in.bin : int32 n, ne, N, K, max_iter, nq ; double params[6+25+4+4+5] ; float cloud[n*3], edge[ne*3] ;
+//          double odom[10] (pos vel acc yaw) ; double ref_path[N*10] ; double queries[nq*3]
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <vector>
+
+#include "avoid_mpc_amd/avoidance_step.hpp"
+
+using namespace avoid_mpc_amd;
+
+struct Cloud {  // stands where pcl::PointCloud<pcl::PointXYZ> stands in the reference
+    std::vector<PointXYZ> points;
+};
+
+template <class T>
+static void rd(FILE *f, T *p, size_t n) {
+    if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
+}
+template <class T>
+static void wr(FILE *f, const T *p, size_t n) { fwrite(p, sizeof(T), n, f); }
+
+int main(int argc, char **argv) {
+    if (argc < 3) return 1;
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 1;
+    int hdr[6];
+    rd(f, hdr, 6);
+    const int n = hdr[0], ne = hdr[1], N = hdr[2], K = hdr[3], max_iter = hdr[4], nq = hdr[5];
+    double sc[6];  // T, dt, speed, safety, decay, height
+    rd(f, sc, 6);
+    std::vector<double> weights(25), tau(4), gains(4), lim(5);  // lim: aMinZ aMaxZ aMaxXy aMaxYawDot radius
+    rd(f, weights.data(), 25); rd(f, tau.data(), 4); rd(f, gains.data(), 4); rd(f, lim.data(), 5);
+    std::vector<float> cl((size_t)n * 3), ed((size_t)ne * 3);
+    rd(f, cl.data(), cl.size()); rd(f, ed.data(), ed.size());
+    double od[10];
+    rd(f, od, 10);
+    std::vector<double> ref((size_t)N * 10), qs((size_t)nq * 3);
+    rd(f, ref.data(), ref.size()); rd(f, qs.data(), qs.size());
+    fclose(f);
+
+    auto cloud = std::make_shared<Cloud>(), edge = std::make_shared<Cloud>();
+    for (int i = 0; i < n; ++i) cloud->points.emplace_back(cl[3 * i], cl[3 * i + 1], cl[3 * i + 2]);
+    for (int i = 0; i < ne; ++i) edge->points.emplace_back(ed[3 * i], ed[3 * i + 1], ed[3 * i + 2]);
+
+    FILE *o = fopen(argv[2], "wb");
+    // 1. KDTreeTwo used directly, as FrameKDMap.cpp:45,264 does
+    KDTreeTwo<double> tree;
+    tree.InitializeNew(cloud);
+    for (int i = 0; i < nq; ++i) {
+        tree.SearchForNearest(qs[3 * i], qs[3 * i + 1], qs[3 * i + 2], K);
+        int c = (int)tree.indices.size();
+        wr(o, &c, 1);
+        wr(o, tree.indices.data(), c);
+        wr(o, tree.squared_distances.data(), c);
+        for (int j = 0; j < c; ++j) { float p[3] = {tree.closest_pts[j].x, tree.closest_pts[j].y, tree.closest_pts[j].z}; wr(o, p, 3); }
+    }
+    // 2. FrameKDMap front end, as AvoidanceStateMachine.cpp:214,264,270 does
+    FrameKDMap map;
+    map.AddVertex(cloud, edge);
+    for (int i = 0; i < nq; ++i) {
+        Vector3d p(qs[3 * i], qs[3 * i + 1], qs[3 * i + 2]);
+        std::vector<Vector3d> pts; std::vector<double> d2;
+        map.QueryNearest(p, K, pts, d2);
+        double nd = map.GetNearestDistance(p);
+        std::vector<Vector3d> ep; std::vector<double> ed2;
+        map.QueryNearest(p, 1, ep, ed2, true);
+        int c = (int)d2.size(), ce = (int)ed2.size();
+        wr(o, &c, 1); wr(o, d2.data(), c); wr(o, &nd, 1); wr(o, &ce, 1); wr(o, ed2.data(), ce);
+    }
+    // 3. the TASK step (SetupMPC + Step), twice: second call carries the warm start
+    AvoidanceTaskStep task(sc[0], sc[1], K, max_iter, sc[2], sc[3], sc[4], sc[5]);
+    amk_mpc_setup_weights(task.mpc(), weights.data());
+    amk_mpc_setup_tau(task.mpc(), tau.data());
+    amk_mpc_setup_gains(task.mpc(), gains.data());
+    amk_mpc_set_drone_accel_limits(task.mpc(), lim[0], lim[1], lim[2], lim[3]);
+    amk_mpc_set_drone_radius(task.mpc(), lim[4]);
+    task.RefPath() = ref;
+    OdomState os;
+    for (int i = 0; i < 3; ++i) { os.pos[i] = od[i]; os.vel[i] = od[3 + i]; os.acc[i] = od[6 + i]; }
+    os.yaw = od[9];
+    for (int rep = 0; rep < 2; ++rep) {
+        std::vector<double> u; std::vector<std::vector<double>> x0;
+        bool safe = task.Step(map, os, u, x0);
+        int s = safe ? 1 : 0;
+        wr(o, &s, 1); wr(o, task.Flags(), 4); wr(o, u.data(), 4);
+        for (auto &row : x0) wr(o, row.data(), 14);
+        wr(o, task.RefPath().data(), (size_t)N * 10);
+    }
+    // 4. ObstacleAvoidanceMPC on its own (HighLvlMpc.cpp), K inferred from the vector length
+    {
+        ObstacleAvoidanceMPC mpc(sc[0], sc[1], "so/mpc_obstacle_v2.so");
+        mpc.SetupWeights(weights); mpc.SetupTau(tau); mpc.SetupGains(gains);
+        mpc.SetDroneAccelLimits(lim[0], lim[1], lim[2], lim[3]); mpc.SetDroneRadius(lim[4]);
+        std::vector<double> vecRef(20 + 10 * N + 3 * K * N, 0.0);
+        for (int i = 0; i < 10; ++i) vecRef[i] = (i < 3) ? od[i] : (i >= 4 && i < 7 ? od[3 + i - 4] : 0.0);
+        for (int i = 0; i < 10 * N; ++i) vecRef[10 + i] = ref[i];
+        for (int i = 0; i < 3 * K * N; ++i) vecRef[10 + 10 * N + i] = 10000.0;  // no obstacles
+        for (int i = 0; i < 10; ++i) vecRef[10 + 10 * N + 3 * K * N + i] = ref[10 * (N - 1) + i];
+        std::vector<double> u; std::vector<std::vector<double>> x0;
+        mpc.Solve(vecRef, u, x0, true);
+        wr(o, vecRef.data(), vecRef.size()); wr(o, u.data(), 4); wr(o, mpc.LastSolveInfo(), 4);
+    }
+    fclose(o);
+    return 0;
+}

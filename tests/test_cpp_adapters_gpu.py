@@ -1,0 +1,78 @@
+"""GPU: the reference-shaped C++ adapters (include/avoid_mpc_amd/*.hpp: KDTreeTwo, FrameKDMap,
+ObstacleAvoidanceMPC, AvoidanceTaskStep) compiled with g++ against the C ABI, versus the oracle."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_adapters_match_oracle(tmp_path):
+    exe = str(tmp_path / "adapter_demo")
+    libdir = os.path.join(ROOT, "avoid_mpc_amd")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "adapter_demo.cpp"), "-o", exe,
+                           "-L", libdir, "-lavoid_mpc_amd", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
+    prm = synth.MpcParams(T=0.33, K=3)
+    n = 5000
+    sc = synth.make_scene(n, 321, prm)
+    sc["acc"] = np.array([0.2, -0.1, 0.05])
+    N, K = prm.N, prm.K
+    rng = np.random.default_rng(0)
+    qs = np.stack([rng.uniform(0, 10, 16), rng.uniform(-2, 2, 16), rng.uniform(0.5, 2.5, 16)], 1)
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("6i", n, n // 10, N, K, prm.max_iter, len(qs)))
+        f.write(np.array([prm.T, prm.dt, prm.speed, prm.safety_distance, prm.decay, prm.height]).tobytes())
+        f.write(np.array(prm.weights, np.float64).tobytes()); f.write(np.array(prm.tau, np.float64).tobytes())
+        f.write(np.array(prm.gain, np.float64).tobytes())
+        f.write(np.array([prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot, prm.radius]).tobytes())
+        f.write(sc["cloud"].tobytes()); f.write(sc["edge"].tobytes())
+        f.write(np.concatenate([sc["pos"], sc["vel"], sc["acc"], [sc["yaw"]]]).tobytes())
+        f.write(sc["ref_path"].tobytes()); f.write(qs.tobytes())
+    subprocess.check_call([exe, fin, fout])
+    buf = open(fout, "rb").read()
+    off = 0
+
+    def take(dtype, cnt):
+        nonlocal off
+        a = np.frombuffer(buf, dtype=dtype, count=cnt, offset=off)
+        off += a.nbytes
+        return a
+
+    kd, ke = _oracle.kd_oracle(sc["cloud"]), _oracle.kd_oracle(sc["edge"])
+    for q in qs:                                                     # 1. KDTreeTwo
+        c = int(take(np.int32, 1)[0])
+        ia, da, pa = kd.search(q, K)
+        assert c == len(ia)
+        assert np.array_equal(take(np.int32, c), ia) and np.array_equal(take(np.float64, c), da)
+        assert np.array_equal(take(np.float32, 3 * c).reshape(-1, 3), pa)
+    for q in qs:                                                     # 2. FrameKDMap
+        c = int(take(np.int32, 1)[0]); d2 = take(np.float64, c); nd = take(np.float64, 1)[0]
+        ce = int(take(np.int32, 1)[0]); ed2 = take(np.float64, ce)
+        assert np.array_equal(d2, kd.search(q, K)[1])
+        assert nd == np.sqrt(kd.search(q, 1)[1][0])
+        assert np.array_equal(ed2, ke.search(q, 1)[1])
+    m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)    # 3. TASK step x 2
+    rp = sc["ref_path"].copy()
+    sq = _oracle.scene_state_quads(sc, prm)
+    for rep in range(2):
+        r = _oracle.step_oracle(kd, ke, m, prm, sq, sc["pos"][0], rp)
+        safe = int(take(np.int32, 1)[0]); flags = take(np.int32, 4); u = take(np.float64, 4)
+        x0 = take(np.float64, 14 * N).reshape(N, 14); ref = take(np.float64, 10 * N).reshape(N, 10)
+        assert safe == r["flags"][0] and np.array_equal(flags, r["flags"])
+        assert np.abs(u - r["u"]).max() <= 1e-6 and np.abs(x0 - r["x0array"]).max() <= 1e-6
+        assert np.abs(ref - rp).max() <= 1e-6
+    nref = 20 + 10 * N + 3 * K * N                                   # 4. ObstacleAvoidanceMPC
+    vec = take(np.float64, nref); u = take(np.float64, 4); info = take(np.int32, 4)
+    m2 = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m2.configure(prm)
+    uc, _, ic = m2.Solve(vec.copy(), True)
+    assert np.abs(u - uc).max() <= 1e-6 and np.array_equal(info, ic)
+    assert off == len(buf)
