@@ -36,6 +36,8 @@ def _deps():
 
 
 def build(force=False, verbose=False, extra_flags=()):
+    if os.environ.get("AMK_SOLVE_TRACE"):
+        extra_flags = tuple(extra_flags) + ("-DAMK_SOLVE_TRACE",)
     os.makedirs(OBJ, exist_ok=True)
     dep_mtime = max(os.path.getmtime(h) for h in _deps())
     objs, relink = [], force or not os.path.exists(LIB)

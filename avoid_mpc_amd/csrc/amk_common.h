@@ -48,6 +48,14 @@ struct DevBuf {
     ~DevBuf() { release(); }
 };
 
+// value of lane `src` (wave-uniform) broadcast to every lane through scalar registers
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; internal (amk__timing_* are not part of the C ABI in include/avoid_mpc_amd.h).
 enum KernelClass { KC_COMPACT = 0, KC_SCAN_OBS, KC_SCAN_EDGE, KC_PLAN, KC_PACK, KC_SOLVE, KC_BEGIN, KC_COUNT };

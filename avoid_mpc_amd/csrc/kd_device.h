@@ -31,13 +31,6 @@ __device__ __forceinline__ double shfl_up1_f64(double v) {
     return __hiloint2double(hi, lo);
 }
 
-__device__ __forceinline__ double readlane_f64(double v, int src) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, src);
-    hi = __builtin_amdgcn_readlane(hi, src);
-    return __hiloint2double(hi, lo);
-}
-
 constexpr int kNoIndex = 0x7fffffff;
 
 // Scans the whole cloud of one scene for QPW queries.  On return lane i < k holds the i-th best

@@ -20,6 +20,16 @@
 
 namespace amk {
 
+// Per-phase clocks / per-iteration trace of the solve (scratch/dbg2.py); compiled in only with
+// -DAMK_SOLVE_TRACE (AMK_SOLVE_TRACE=1 python -m avoid_mpc_amd.build --force).
+#ifdef AMK_SOLVE_TRACE
+#define AMK_CLK() wall_clock64()
+constexpr bool kTrace = true;
+#else
+#define AMK_CLK() 0LL
+constexpr bool kTrace = false;
+#endif
+
 constexpr int SD = AMK_S_DIM;  // 10
 constexpr int UD = AMK_U_DIM;  // 4
 constexpr double kGz = 9.81;   // mpc_obstacle_casadi.py:39
@@ -55,7 +65,7 @@ struct LdsMap {
     int prm, xinit, target, cy, sy;
     int X, U, zl, zu, dX, dU, dzl, dzu, Xt, Ut;
     int q, r, rb, Rb, gU, H6, rotQ;
-    int P, p, lam, M, Hm, G, Atp, Atl, qu, Y, D, Kk, red;
+    int P, p, lam, M, Hm, G, Atp, Atl, qu, Y, Z, D, Kk, red;
     int total;
     __host__ __device__ explicit LdsMap(int N) {
         int o = 0;
@@ -67,30 +77,58 @@ struct LdsMap {
         q = take((N + 1) * SD); r = take(N * UD); rb = take(N * UD); Rb = take(N * UD); gU = take(N * UD);
         H6 = take(N * 36); rotQ = take(N * 6);
         P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
-        Atp = take(SD); Atl = take(SD); qu = take(UD); Y = take(44); D = take(UD + 6 + 2);
+        Atp = take(SD); Atl = take(SD); qu = take(UD); Y = take(44); Z = take(44); D = take(UD + 6 + 2);
         Kk = take(N * 44); red = take(64);
         total = o;
     }
 };
 
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+// ---- cross-lane reductions on DPP (no LDS crossbar): quad_perm for lane^1 / lane^2, row_half_mirror and
+// row_mirror for the 8- and 16-lane levels (valid because every lane of the lower level already holds
+// that level's result), v_readlane for the four rows.  __shfl_xor would be two ds_bpermute_b32 + a wait
+// per double per level; the collision Hessian reduction alone is 28 values x 3 levels x 3 rounds.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
+constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
+constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each row of 16
+
+struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
+struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return fmin(a, b); } };
+struct OpMax { __device__ __forceinline__ static double f(double a, double b) { return fmax(a, b); } };
+
+template <class Op>
+__device__ __forceinline__ double row_reduce(double v) {  // every lane of a 16-lane row gets the row result
+    v = Op::f(v, dpp_f64<DPP_XOR1>(v));
+    v = Op::f(v, dpp_f64<DPP_XOR2>(v));
+    v = Op::f(v, dpp_f64<DPP_HALF_MIRROR>(v));
+    v = Op::f(v, dpp_f64<DPP_MIRROR>(v));
     return v;
 }
-__device__ __forceinline__ double wave_min(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+template <class Op>
+__device__ __forceinline__ double wave_reduce(double v) {
+    v = row_reduce<Op>(v);
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return Op::f(Op::f(r0, r1), Op::f(r2, r3));
 }
-__device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
+__device__ __forceinline__ double wave_sum(double v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ double wave_min(double v) { return wave_reduce<OpMin>(v); }
+__device__ __forceinline__ double wave_max(double v) { return wave_reduce<OpMax>(v); }
+
 // sum over aligned segments of `seg` (power of two) consecutive lanes; every lane gets its segment's sum
 __device__ __forceinline__ double seg_sum(double v, int seg) {
-    for (int off = seg >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if (seg >= 2) v += dpp_f64<DPP_XOR1>(v);
+    if (seg >= 4) v += dpp_f64<DPP_XOR2>(v);
+    if (seg >= 8) v += dpp_f64<DPP_HALF_MIRROR>(v);
+    if (seg >= 16) v += dpp_f64<DPP_MIRROR>(v);
+    if (seg >= 32) v += __shfl_xor(v, 16);
+    if (seg >= 64) v += __shfl_xor(v, 32);
     return v;
 }
 
@@ -168,8 +206,8 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
 // Evaluate the objective on (Xs, Us) held in LDS.  DERIV: also q, r, H6 (36 per stage, full
 // symmetric), rotQ.  Returns J (wave-uniform).  One wave; caller syncs before/after.
 template <bool DERIV>
-__device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N, int K, int Kpad, const double *Xs,
-                           const double *Us) {
+__device__ __forceinline__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N, int K, int Kpad, const double *Xs,
+                           const double *Us, long long *tclk = nullptr) {
     const int lane = threadIdx.x;
     const double *prm = sm + L.prm;
     const double lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
@@ -179,6 +217,7 @@ __device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N
     for (int k0 = 0; k0 < N - 1; k0 += spr) {
         const int k = k0 + lane / Kpad, j = lane % Kpad;
         const bool act = (k < N - 1) && (j < K);
+        const long long tc0 = AMK_CLK();
         double c = 0.0, g6[6] = {0, 0, 0, 0, 0, 0}, H[21];
         if (DERIV) {
 #pragma unroll
@@ -191,6 +230,7 @@ __device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N
             const double o[3] = {op[0], op[1], op[2]};
             collide_point<DERIV>(p, v, o, lamw, radius, c, g6, H);
         }
+        const long long tc1 = AMK_CLK();
         c = seg_sum(c, Kpad);
         if (DERIV) {
 #pragma unroll
@@ -198,6 +238,8 @@ __device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N
 #pragma unroll
             for (int e = 0; e < 21; ++e) H[e] = seg_sum(H[e], Kpad);
         }
+        const long long tc2 = AMK_CLK();
+        if (kTrace && tclk) { tclk[0] += tc1 - tc0; tclk[1] += tc2 - tc1; }
         if (j == 0 && k < N - 1) {
             Jloc += c;
             if (DERIV) {
@@ -217,6 +259,7 @@ __device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N
         }
     }
     if (DERIV) __syncthreads();
+    const long long tc3 = AMK_CLK();
     // ---- per-stage quadratic terms: lane = stage
     if (lane < N) {
         const int k = lane;
@@ -273,6 +316,7 @@ __device__ double evaluate(double *sm, const LdsMap &L, const SceneIO &io, int N
             }
         }
     }
+    if (kTrace && tclk) tclk[2] += AMK_CLK() - tc3;
     return wave_sum(Jloc);
 }
 
@@ -296,16 +340,80 @@ __device__ __forceinline__ double q_elem(const double *sm, const LdsMap &L, int 
     return v;
 }
 
+// ---- Riccati plan: which LDS cells each lane combines in "round A" of a backward stage.  The affine
+// dynamics are constant, so every entry of A'PA, B'PB, B'PA, A'p, A'lam, B'p, B'lam is a fixed <= 9-term
+// linear combination of entries of P / p / lam; the host enumerates the terms once per handle
+// (mpc_solve.hip: build_plan) from the non-zeros of A (19) and B (10).  128 items = 2 per lane.
+constexpr int PLAN_ITEMS = 128;
+constexpr int PLAN_TERMS = 9;
+struct PlanItemMeta {            // one per item, ints
+    int idx[PLAN_TERMS];         // LDS offsets (doubles) of the source cells
+    int out;                     // LDS offset of the result (+ k * out_kstride)
+    int out_kstride;
+    int aux;                     // LDS offset of a per-stage addend (+ 4 k), or -1
+    int aux_delta;               // 1: also add the regularisation shift (diagonal of the control block)
+};
+
+struct LanePlan {                // the two items of this lane, in registers for the whole solve
+    double coef[2][PLAN_TERMS];
+    int idx[2][PLAN_TERMS];
+    int out[2], out_kstride[2], aux[2], aux_delta[2];
+    // round C: (i, j) of the P entry owned by this lane and how to assemble Q_k[i][j]
+    int ci, cj;                  // lane < 55: lower-triangular entry; 55..63: p entry ci
+    double qdiag;                // constant diagonal part (2 Qpen[i] outside the rotated blocks)
+    int rot_off, h6_off;         // offsets into rotQ[st*6 + .] / H6[st*36 + .] or -1
+};
+
+__device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_coef, const int *plan_meta,
+                                               const double *prm) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;
+        const PlanItemMeta *m = reinterpret_cast<const PlanItemMeta *>(plan_meta) + e;
+#pragma unroll
+        for (int t = 0; t < PLAN_TERMS; ++t) {
+            lp.coef[h][t] = plan_coef[e * PLAN_TERMS + t];
+            lp.idx[h][t] = m->idx[t];
+        }
+        lp.out[h] = m->out; lp.out_kstride[h] = m->out_kstride; lp.aux[h] = m->aux; lp.aux_delta[h] = m->aux_delta;
+    }
+    int i = 0, j = 0;
+    if (lane < 55) {
+        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+        j = lane - i * (i + 1) / 2;
+    } else {
+        i = lane - 55;
+    }
+    lp.ci = i; lp.cj = j;
+    lp.qdiag = 0.0; lp.rot_off = -1; lp.h6_off = -1;
+    if (lane < 55) {
+        const int bi = (i == 0 || i == 1) ? 0 : ((i == 4 || i == 5) ? 1 : -1);
+        const int bj = (j == 0 || j == 1) ? 0 : ((j == 4 || j == 5) ? 1 : -1);
+        if (bi >= 0 && bi == bj) lp.rot_off = bi * 3 + ((i == 1 || i == 5) ? 1 : 0) + ((j == 1 || j == 5) ? 1 : 0);
+        else if (i == j) lp.qdiag = 2.0 * prm[PRM_W + 10 + i];
+        const int pi = pv_inv(i), pj = pv_inv(j);
+        if (pi >= 0 && pj >= 0) lp.h6_off = pi * 6 + pj;
+    }
+}
+
+// 1/x to full double precision: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~4x longer)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
 // Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
 // control block is not positive definite.  Gains go to L.Kk ([k][a*11 + j], column 10 = feed-forward).
-__device__ bool riccati_backward(double *sm, const LdsMap &L, int N, double delta) {
+__device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, const LanePlan &lp, int N, double delta) {
     const int lane = threadIdx.x;
-    const double *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
     double *P = sm + L.P, *pv = sm + L.p, *lam = sm + L.lam;
-    // terminal: P = Q_N + delta I, p = lam = q_N
+    // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
     for (int e = lane; e < 100; e += 64) {
         const int i = e / 10, j = e % 10;
-        P[e] = q_elem(sm, L, N, N, i, j) + (i == j ? delta : 0.0);
+        P[e] = (i == j) ? 2.0 * sm[L.prm + PRM_W + i] + delta : 0.0;
     }
     if (lane < SD) {
         pv[lane] = sm[L.q + N * SD + lane];
@@ -313,83 +421,41 @@ __device__ bool riccati_backward(double *sm, const LdsMap &L, int N, double delt
     }
     __syncthreads();
     for (int k = N - 1; k >= 0; --k) {
-        // ---- round A: M = A'PA (55 lower), Hm = B'PB + Rb (10 lower), G = B'PA (40), A'p, A'lam, qu, gU
-        for (int e = lane; e < 119; e += 64) {
-            if (e < 105) {
-                int ri[3], rj[3], ni, nj, i, j;
-                const double *Li, *Lj;
-                int si, sj;  // strides of the left/right factor matrices
-                if (e < 55) {  // M(i,j), j <= i
-                    i = 0;
-                    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                    j = e - i * (i + 1) / 2;
-                    ni = rows_of_A(i, ri); nj = rows_of_A(j, rj);
-                    Li = A; si = SD; Lj = A; sj = SD;
-                } else if (e < 65) {  // Hm(a,b), b <= a
-                    const int f = e - 55;
-                    i = 0;
-                    while ((i + 1) * (i + 2) / 2 <= f) ++i;
-                    j = f - i * (i + 1) / 2;
-                    ni = rows_of_B(i, ri); nj = rows_of_B(j, rj);
-                    Li = B; si = UD; Lj = B; sj = UD;
-                } else {  // G(a,j)
-                    const int f = e - 65;
-                    i = f / 10; j = f % 10;
-                    ni = rows_of_B(i, ri); nj = rows_of_A(j, rj);
-                    Li = B; si = UD; Lj = A; sj = SD;
-                }
-                double acc = 0.0;
-                for (int a = 0; a < ni; ++a) {
-                    const int l = ri[a];
-                    double inner = 0.0;
-                    for (int b = 0; b < nj; ++b) inner += P[l * 10 + rj[b]] * Lj[rj[b] * sj + j];
-                    acc += Li[l * si + i] * inner;
-                }
-                if (e < 55) sm[L.M + e] = acc;
-                else if (e < 65) sm[L.Hm + (e - 55)] = acc + ((i == j) ? sm[L.Rb + k * UD + i] + delta : 0.0);
-                else sm[L.G + (e - 65)] = acc;
-            } else if (e < 115) {
-                const int i = e - 105;
-                int ri[3];
-                const int ni = rows_of_A(i, ri);
-                double a1 = 0.0, a2 = 0.0;
-                for (int a = 0; a < ni; ++a) {
-                    a1 += A[ri[a] * SD + i] * pv[ri[a]];
-                    a2 += A[ri[a] * SD + i] * lam[ri[a]];
-                }
-                sm[L.Atp + i] = a1;
-                sm[L.Atl + i] = a2;
-            } else {
-                const int a = e - 115;
-                int ri[3];
-                const int ni = rows_of_B(a, ri);
-                double a1 = 0.0, a2 = 0.0;
-                for (int b = 0; b < ni; ++b) {
-                    a1 += B[ri[b] * UD + a] * pv[ri[b]];
-                    a2 += B[ri[b] * UD + a] * lam[ri[b]];
-                }
-                sm[L.qu + a] = sm[L.rb + k * UD + a] + a1;
-                sm[L.gU + k * UD + a] = sm[L.r + k * UD + a] + a2;
-            }
+        // ---- round A: the two plan items of this lane
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            double v[PLAN_TERMS];
+#pragma unroll
+            for (int t = 0; t < PLAN_TERMS; ++t) v[t] = sm[lp.idx[h][t]];
+            double acc = 0.0;
+#pragma unroll
+            for (int t = 0; t < PLAN_TERMS; ++t) acc = fma(lp.coef[h][t], v[t], acc);
+            if (lp.aux[h] >= 0) acc += sm[lp.aux[h] + 4 * k];
+            if (lp.aux_delta[h]) acc += delta;
+            sm[lp.out[h] + k * lp.out_kstride[h]] = acc;
         }
         __syncthreads();
         // ---- round B: LDL' of Hm (every lane, wave-uniform), Y = L^-1 [G | qu], gains
-        double Lm[6], Dm[4];  // L10 L20 L21 L30 L31 L32
+        double Lm[6], Di[4];  // L10 L20 L21 L30 L31 L32 ; reciprocals of D
         {
             const double *h = sm + L.Hm;  // lower: h00 h10 h11 h20 h21 h22 h30 h31 h32 h33
             const double d0 = h[0];
             if (!(d0 > 0.0)) return false;
-            Lm[0] = h[1] / d0; Lm[1] = h[3] / d0; Lm[3] = h[6] / d0;
-            const double d1 = h[2] - Lm[0] * Lm[0] * d0;
+            Di[0] = fast_rcp(d0);
+            Lm[0] = h[1] * Di[0]; Lm[1] = h[3] * Di[0]; Lm[3] = h[6] * Di[0];
+            const double d1 = h[2] - Lm[0] * h[1];
             if (!(d1 > 0.0)) return false;
-            Lm[2] = (h[4] - Lm[1] * Lm[0] * d0) / d1;
-            Lm[4] = (h[7] - Lm[3] * Lm[0] * d0) / d1;
-            const double d2 = h[5] - Lm[1] * Lm[1] * d0 - Lm[2] * Lm[2] * d1;
+            Di[1] = fast_rcp(d1);
+            Lm[2] = (h[4] - Lm[1] * h[1]) * Di[1];
+            Lm[4] = (h[7] - Lm[3] * h[1]) * Di[1];
+            const double l21d1 = Lm[2] * d1;
+            const double d2 = h[5] - Lm[1] * h[3] - Lm[2] * l21d1;
             if (!(d2 > 0.0)) return false;
-            Lm[5] = (h[8] - Lm[3] * Lm[1] * d0 - Lm[4] * Lm[2] * d1) / d2;
-            const double d3 = h[9] - Lm[3] * Lm[3] * d0 - Lm[4] * Lm[4] * d1 - Lm[5] * Lm[5] * d2;
+            Di[2] = fast_rcp(d2);
+            Lm[5] = (h[8] - Lm[3] * h[3] - Lm[4] * l21d1) * Di[2];
+            const double d3 = h[9] - Lm[3] * h[6] - Lm[4] * (Lm[4] * d1) - Lm[5] * (Lm[5] * d2);
             if (!(d3 > 0.0)) return false;
-            Dm[0] = d0; Dm[1] = d1; Dm[2] = d2; Dm[3] = d3;
+            Di[3] = fast_rcp(d3);
         }
         if (lane <= SD) {
             const int j = lane;  // column j of G, or j == 10: qu
@@ -401,41 +467,41 @@ __device__ bool riccati_backward(double *sm, const LdsMap &L, int N, double delt
             const double y1 = g1 - Lm[0] * y0;
             const double y2 = g2 - Lm[1] * y0 - Lm[2] * y1;
             const double y3 = g3 - Lm[3] * y0 - Lm[4] * y1 - Lm[5] * y2;
+            // x = L^-T D^-1 y ; gain = -x ; Z = D^-1 Y is what round C multiplies with
+            const double z0 = y0 * Di[0], z1 = y1 * Di[1], z2 = y2 * Di[2], z3 = y3 * Di[3];
             sm[L.Y + j] = y0; sm[L.Y + 11 + j] = y1; sm[L.Y + 22 + j] = y2; sm[L.Y + 33 + j] = y3;
-            // x = L^-T D^-1 y ; gain = -x
-            const double x3 = y3 / Dm[3];
-            const double x2 = y2 / Dm[2] - Lm[5] * x3;
-            const double x1 = y1 / Dm[1] - Lm[2] * x2 - Lm[4] * x3;
-            const double x0 = y0 / Dm[0] - Lm[0] * x1 - Lm[1] * x2 - Lm[3] * x3;
+            sm[L.Z + j] = z0; sm[L.Z + 11 + j] = z1; sm[L.Z + 22 + j] = z2; sm[L.Z + 33 + j] = z3;
+            const double x3 = z3;
+            const double x2 = z2 - Lm[5] * x3;
+            const double x1 = z1 - Lm[2] * x2 - Lm[4] * x3;
+            const double x0 = z0 - Lm[0] * x1 - Lm[1] * x2 - Lm[3] * x3;
             double *kk = sm + L.Kk + k * 44;
             kk[j] = -x0; kk[11 + j] = -x1; kk[22 + j] = -x2; kk[33 + j] = -x3;
-        }
-        if (lane == 0) {
-            sm[L.D + 0] = Dm[0]; sm[L.D + 1] = Dm[1]; sm[L.D + 2] = Dm[2]; sm[L.D + 3] = Dm[3];
         }
         __syncthreads();
         // ---- round C: P_k = Q_k + delta I + M - Y'D^-1 Y ; p_k = q_k + A'p - Y'D^-1 yv ; lam_k = q_k + A'lam
         if (k > 0) {
-            const double *Y = sm + L.Y;
-            const double i0 = 1.0 / Dm[0], i1 = 1.0 / Dm[1], i2 = 1.0 / Dm[2], i3 = 1.0 / Dm[3];
-            for (int e = lane; e < 55 + SD; e += 64) {  // 65 work items: two rounds on 64 lanes
-                if (e < 55) {
-                    int i = 0;
-                    while ((i + 1) * (i + 2) / 2 <= e) ++i;
-                    const int j = e - i * (i + 1) / 2;
-                    const double ww = Y[i] * Y[j] * i0 + Y[11 + i] * Y[11 + j] * i1 + Y[22 + i] * Y[22 + j] * i2 +
-                                      Y[33 + i] * Y[33 + j] * i3;
-                    const double val = q_elem(sm, L, N, k, i, j) + (i == j ? delta : 0.0) + sm[L.M + e] - ww;
-                    P[i * 10 + j] = val;
-                    P[j * 10 + i] = val;
-                } else {
-                    const int i = e - 55;
-                    const double wv = Y[i] * Y[10] * i0 + Y[11 + i] * Y[21] * i1 + Y[22 + i] * Y[32] * i2 +
-                                      Y[33 + i] * Y[43] * i3;
-                    const double qk = sm[L.q + k * SD + i];
-                    pv[i] = qk + sm[L.Atp + i] - wv;
-                    lam[i] = qk + sm[L.Atl + i];
-                }
+            const double *Y = sm + L.Y, *Z = sm + L.Z;
+            const int i = lp.ci;
+            if (lane < 55) {
+                const int j = lp.cj, st = k - 1;
+                const double ww = Y[i] * Z[j] + Y[11 + i] * Z[11 + j] + Y[22 + i] * Z[22 + j] + Y[33 + i] * Z[33 + j];
+                double qe = lp.qdiag + (i == j ? delta : 0.0);
+                if (lp.rot_off >= 0) qe += sm[L.rotQ + st * 6 + lp.rot_off];
+                if (lp.h6_off >= 0) qe += sm[L.H6 + st * 36 + lp.h6_off];
+                const double val = qe + sm[L.M + lane] - ww;
+                P[i * 10 + j] = val;
+                P[j * 10 + i] = val;
+            } else {  // p entries 0..8
+                const double wv = Y[i] * Z[10] + Y[11 + i] * Z[21] + Y[22 + i] * Z[32] + Y[33 + i] * Z[43];
+                pv[i] = sm[L.q + k * SD + i] + sm[L.Atp + i] - wv;
+            }
+            if (lane == 0) {  // p entry 9
+                const double wv = Y[9] * Z[10] + Y[20] * Z[21] + Y[31] * Z[32] + Y[42] * Z[43];
+                pv[9] = sm[L.q + k * SD + 9] + sm[L.Atp + 9] - wv;
+            } else if (lane <= SD) {  // lam entries
+                const int ii = lane - 1;
+                lam[ii] = sm[L.q + k * SD + ii] + sm[L.Atl + ii];
             }
         }
         __syncthreads();
@@ -443,39 +509,50 @@ __device__ bool riccati_backward(double *sm, const LdsMap &L, int N, double delt
     return true;
 }
 
-// forward roll of the Newton step: dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k
-__device__ void riccati_forward(double *sm, const LdsMap &L, int N) {
+// forward roll of the Newton step, entirely in registers: lane i < 10 carries dX_k[i]; the values a
+// lane needs from other lanes are wave-uniform broadcasts (v_readlane), no LDS round trip per stage.
+// dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k
+__device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int N) {
     const int lane = threadIdx.x;
     const double *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
-    double *dX = sm + L.dX, *dU = sm + L.dU;
-    if (lane < SD) dX[lane] = 0.0;
-    __syncthreads();
+    double arow[SD], brow[UD];  // row `lane` of A and B (lanes >= 10 idle)
+    const int row = lane < SD ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < SD; ++j) arow[j] = A[row * SD + j];
+#pragma unroll
+    for (int j = 0; j < UD; ++j) brow[j] = B[row * UD + j];
+    const int a = lane < UD ? lane : 0;
+    double dx = 0.0;  // dX_k[lane]
+    if (lane < SD) sm[L.dX + lane] = 0.0;
     for (int k = 0; k < N; ++k) {
-        if (lane < UD) {
-            const double *kk = sm + L.Kk + k * 44 + lane * 11;
-            double a = kk[10];
+        const double *kk = sm + L.Kk + k * 44 + a * 11;
+        double krow[SD + 1];
 #pragma unroll
-            for (int j = 0; j < SD; ++j) a += kk[j] * dX[k * SD + j];
-            dU[k * UD + lane] = a;
-        }
-        __syncthreads();
-        if (lane < SD) {
-            double a = 0.0;
+        for (int j = 0; j <= SD; ++j) krow[j] = kk[j];
+        double xs[SD];
 #pragma unroll
-            for (int j = 0; j < SD; ++j) a += A[lane * SD + j] * dX[k * SD + j];
+        for (int j = 0; j < SD; ++j) xs[j] = readlane_f64(dx, j);
+        double du = krow[SD];
 #pragma unroll
-            for (int j = 0; j < UD; ++j) a += B[lane * UD + j] * dU[k * UD + j];
-            dX[(k + 1) * SD + lane] = a;
-        }
-        __syncthreads();
+        for (int j = 0; j < SD; ++j) du = fma(krow[j], xs[j], du);
+        if (lane < UD) sm[L.dU + k * UD + lane] = du;
+        double acc = 0.0;
+#pragma unroll
+        for (int j = 0; j < SD; ++j) acc = fma(arow[j], xs[j], acc);
+#pragma unroll
+        for (int j = 0; j < UD; ++j) acc = fma(brow[j], readlane_f64(du, j), acc);
+        dx = acc;
+        if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = dx;
     }
+    __syncthreads();
 }
 
 // The whole solve for one scene.  w0/w_out: decision vector [X_0,U_0,...,U_{N-1},X_N] in global
 // memory (warm start in, solution out; may alias).  info[4] as in the C ABI.
-__device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
+__device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
                             const double *x_init, const double *target, const SceneIO &io, const double *w0,
-                            double *w_out, int *info, double *trace = nullptr) {
+                            double *w_out, int *info, const double *plan_coef, const int *plan_meta,
+                            double *trace = nullptr) {
     const int lane = threadIdx.x;
     int Kpad = 1;
     while (Kpad < K) Kpad <<= 1;
@@ -491,6 +568,9 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
     }
     __syncthreads();
     const double *prm = sm + L.prm;
+    LanePlan lp;
+    load_lane_plan(lp, plan_coef, plan_meta, prm);
+    for (int e = lane; e < 56 + 10 + 40; e += 64) sm[L.M + e] = 0.0;  // structurally-zero outputs stay zero
     if (lane < N - 1) {  // constant part of Q on the rotated (px,py) and (vx,vy) blocks
         const double cy = sm[L.cy + lane], sy = sm[L.sy + lane];
 #pragma unroll
@@ -535,8 +615,11 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
     int status = 1, n_reg = 0, ls_fail = 0, it = 0;
     const int nvar = UD * N;
     for (it = 0; it < opt.max_iter; ++it) {
-        const double J = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U);
+        const long long t0 = AMK_CLK();
+        long long tclk[3] = {0, 0, 0};
+        const double J = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U, kTrace ? tclk : nullptr);
         __syncthreads();
+        const long long t1 = AMK_CLK();
         if (it > 0 && a_last >= 0.5) mu = fmax(mu_min, opt.kappa_mu * mu);
         const double tau = fmax(opt.tau_min, 1.0 - mu);
         for (int e = lane; e < nvar; e += 64) {
@@ -549,14 +632,14 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
         __syncthreads();
         double delta = 0.0;
         int reg_now = 0;
-        bool ok = riccati_backward(sm, L, N, delta);
+        bool ok = riccati_backward(sm, L, lp, N, delta);
         while (!ok) {
             __syncthreads();
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
             ++reg_now;
             if (delta > 1e40) break;
-            ok = riccati_backward(sm, L, N, delta);
+            ok = riccati_backward(sm, L, lp, N, delta);
         }
         if (!ok) { status = 2; break; }
         // KKT error E_0 at the current iterate (gU from the adjoint sweep inside the backward pass)
@@ -572,15 +655,17 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
             }
             zs = wave_sum(zs); ed = wave_max(ed); ec = wave_max(ec);
             const double s_d = fmax(opt.s_max, zs / (2.0 * nvar)) / opt.s_max;
-            if (trace && lane == 0) {
-                trace[8 * it + 0] = J; trace[8 * it + 1] = fmax(ed, ec) / s_d; trace[8 * it + 2] = mu;
-                trace[8 * it + 3] = delta;
+            if (kTrace && trace && lane == 0) {
+                trace[16 * it + 0] = J; trace[16 * it + 1] = fmax(ed, ec) / s_d; trace[16 * it + 2] = mu;
+                trace[16 * it + 3] = delta;
             }
             if (fmax(ed, ec) / s_d <= opt.tol) { status = 0; break; }
         }
         n_reg += reg_now;
         if (delta > 0.0) delta_last = delta;
+        const long long t2 = AMK_CLK();
         riccati_forward(sm, L, N);
+        const long long t3 = AMK_CLK();
         // dual steps, fraction to the boundary, directional derivative, barrier value
         double a_pr = 1.0, a_du = 1.0, dphi = 0.0, phi0 = 0.0;
         for (int e = lane; e < nvar; e += 64) {
@@ -600,6 +685,8 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
         }
         a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi); phi0 = J + wave_sum(phi0);
         // backtracking Armijo line search on the barrier function
+        const long long t4 = AMK_CLK();
+        int n_ls = 0;
         double a = a_pr;
         bool accepted = false;
         for (int ls = 0; ls < opt.max_ls; ++ls) {
@@ -607,6 +694,7 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
             for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
             for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
             __syncthreads();
+            ++n_ls;
             double phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
             double lg = 0.0;
             for (int e = lane; e < nvar; e += 64) {
@@ -620,8 +708,11 @@ __device__ void solve_scene(double *sm, const LdsMap &L, int N, int K, const dou
         }
         if (!accepted) ++ls_fail;
         a_last = accepted ? a : 0.0;
-        if (trace && lane == 0) {
-            trace[8 * it + 4] = a; trace[8 * it + 5] = a_pr; trace[8 * it + 6] = a_du; trace[8 * it + 7] = dphi;
+        if (kTrace && trace && lane == 0) {
+            trace[16 * it + 4] = a; trace[16 * it + 5] = a_pr; trace[16 * it + 6] = a_du; trace[16 * it + 7] = dphi;
+            trace[16 * it + 8] = (double)(t1 - t0); trace[16 * it + 9] = (double)(t2 - t1);
+            trace[16 * it + 10] = (double)(t3 - t2); trace[16 * it + 11] = (double)(t4 - t3);
+            trace[16 * it + 12] = (double)(AMK_CLK() - t4); trace[16 * it + 13] = (double)tclk[0]; trace[16 * it + 14] = (double)tclk[1]; trace[16 * it + 15] = (double)tclk[2];
         }
         __syncthreads();
         for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] = sm[L.Xt + e];

@@ -7,6 +7,8 @@
 
 #include <cmath>
 #include <cstring>
+#include <utility>
+#include <vector>
 
 using namespace amk;
 
@@ -61,8 +63,90 @@ void refresh_dynamics(amk_mpc *m) {
     }
 }
 
+// Enumerates, for every entry of A'PA, B'PB(+R), B'PA, A'p, A'lam, B'p(+r_bar), B'lam(+r), the <= 9 source cells
+// and coefficients (mpc_device.h "Riccati plan").  Generic in the non-zeros of A and B; the yaw chain
+// is decoupled from the others (checked), so P[yaw][other] == 0 for every stage and those terms drop out.
+int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
+    const double *A = m->h_prm + PRM_A, *B = m->h_prm + PRM_B;
+    const LdsMap L(m->N);
+    bool yaw_free = true;
+    for (int i = 0; i < SD; ++i)
+        if (i != 3 && (A[3 * SD + i] != 0.0 || A[i * SD + 3] != 0.0)) yaw_free = false;
+    for (int a = 0; a < 3; ++a)
+        if (B[3 * UD + a] != 0.0) yaw_free = false;
+    for (int i = 0; i < SD; ++i)
+        if (i != 3 && B[i * UD + 3] != 0.0) yaw_free = false;
+    auto zeroP = [&](int l, int mm) { return yaw_free && ((l == 3) != (mm == 3)); };
+    struct Item { std::vector<std::pair<int, double>> t; int out, ks, aux, auxd; };
+    std::vector<Item> items;
+    auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
+    auto mat_terms = [&](const double *Lf, int ls, int ci, const double *Rf, int rs, int cj) {
+        std::vector<std::pair<int, double>> t;
+        for (int l = 0; l < SD; ++l) {
+            if (Lf[l * ls + ci] == 0.0) continue;
+            for (int mm = 0; mm < SD; ++mm) {
+                if (Rf[mm * rs + cj] == 0.0 || zeroP(l, mm)) continue;
+                t.push_back({L.P + l * 10 + mm, Lf[l * ls + ci] * Rf[mm * rs + cj]});
+            }
+        }
+        return t;
+    };
+    auto vec_terms = [&](const double *Lf, int ls, int ci, int base) {
+        std::vector<std::pair<int, double>> t;
+        for (int l = 0; l < SD; ++l)
+            if (Lf[l * ls + ci] != 0.0) t.push_back({base + l, Lf[l * ls + ci]});
+        return t;
+    };
+    for (int i = 0; i < SD; ++i)
+        for (int j = 0; j <= i; ++j) {
+            auto t = mat_terms(A, SD, i, A, SD, j);
+            if (!t.empty()) items.push_back({t, L.M + tri(i, j), 0, -1, 0});
+        }
+    for (int a = 0; a < UD; ++a)
+        for (int b = 0; b <= a; ++b) {
+            auto t = mat_terms(B, UD, a, B, UD, b);
+            if (!t.empty() || a == b) items.push_back({t, L.Hm + tri(a, b), 0, a == b ? L.Rb + a : -1, a == b ? 1 : 0});
+        }
+    for (int a = 0; a < UD; ++a)
+        for (int j = 0; j < SD; ++j) {
+            auto t = mat_terms(B, UD, a, A, SD, j);
+            if (!t.empty()) items.push_back({t, L.G + a * 10 + j, 0, -1, 0});
+        }
+    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.p), L.Atp + i, 0, -1, 0});
+    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.lam), L.Atl + i, 0, -1, 0});
+    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.p), L.qu + a, 0, L.rb + a, 0});
+    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.lam), L.gU + a, UD, L.r + a, 0});
+    if ((int)items.size() > PLAN_ITEMS) return AMK_ERR_UNSUPPORTED;
+    coef.assign((size_t)PLAN_ITEMS * PLAN_TERMS, 0.0);
+    meta.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 4), 0);
+    for (int e = 0; e < PLAN_ITEMS; ++e) {
+        int *mt = meta.data() + (size_t)e * (PLAN_TERMS + 4);
+        for (int t = 0; t < PLAN_TERMS; ++t) mt[t] = L.P;
+        mt[PLAN_TERMS + 0] = L.red + 8;  // dummy output cell
+        mt[PLAN_TERMS + 1] = 0;
+        mt[PLAN_TERMS + 2] = -1;
+        mt[PLAN_TERMS + 3] = 0;
+        if (e >= (int)items.size()) continue;
+        const Item &it = items[e];
+        if ((int)it.t.size() > PLAN_TERMS) return AMK_ERR_UNSUPPORTED;
+        for (size_t t = 0; t < it.t.size(); ++t) {
+            mt[t] = it.t[t].first;
+            coef[(size_t)e * PLAN_TERMS + t] = it.t[t].second;
+        }
+        mt[PLAN_TERMS + 0] = it.out; mt[PLAN_TERMS + 1] = it.ks; mt[PLAN_TERMS + 2] = it.aux; mt[PLAN_TERMS + 3] = it.auxd;
+    }
+    return AMK_OK;
+}
+
 int upload_params(amk_mpc *m) {
+    static_assert(sizeof(PlanItemMeta) == sizeof(int) * (PLAN_TERMS + 4), "PlanItemMeta layout");
     AMK_HIP(hipMemcpy(m->prm.p, m->h_prm, sizeof(double) * PRM_LEN, hipMemcpyHostToDevice));
+    std::vector<double> coef;
+    std::vector<int> meta;
+    int st = build_plan(m, coef, meta);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipMemcpy(m->plan_coef.p, coef.data(), sizeof(double) * coef.size(), hipMemcpyHostToDevice));
+    AMK_HIP(hipMemcpy(m->plan_meta.p, meta.data(), sizeof(int) * meta.size(), hipMemcpyHostToDevice));
     return AMK_OK;
 }
 
@@ -74,15 +158,19 @@ static double *g_trace = nullptr;
 extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
 
 // grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total doubles
-__global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, int nx, const double *__restrict__ prm,
+template <int NT>  // NT > 0: horizon baked in (LDS offsets become immediates, as the reference bakes N into its plugin)
+__global__ __launch_bounds__(64) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
                                                        SolveOpts opt, const double *__restrict__ ref_states,
                                                        double *__restrict__ w0, double *__restrict__ u_out,
                                                        double *__restrict__ x0array, int *__restrict__ info,
                                                        double *trace, const int *__restrict__ done,
-                                                       double *__restrict__ ref_path, int *__restrict__ step_flags) {
+                                                       double *__restrict__ ref_path, int *__restrict__ step_flags,
+                                                       const double *__restrict__ plan_coef,
+                                                       const int *__restrict__ plan_meta) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int s = blockIdx.x;
     if (done && done[s]) return;  // control step: this scene left the re-plan loop already
+    const int N = NT > 0 ? NT : Nrt;
     const LdsMap L(N);
     const double *P = ref_states + (size_t)s * nref;
     SceneIO io;
@@ -90,7 +178,8 @@ __global__ __launch_bounds__(64) void mpc_solve_kernel(int N, int K, int nref, i
     io.obs = P + SD + SD * N;
     const double *target = P + SD + SD * N + 3 * K * N;
     double *w = w0 + (size_t)s * nx;
-    solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, s == 0 ? trace : nullptr);
+    solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, plan_coef, plan_meta,
+                s == 0 ? trace : nullptr);
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
@@ -112,9 +201,17 @@ namespace amk {
 int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
                  double *d_ref_path, int *d_step_flags, hipStream_t stream) {
     TimedLaunch tl(KC_SOLVE, stream);
-    hipLaunchKernelGGL(mpc_solve_kernel, dim3(m->S), dim3(64), m->lds_bytes, stream, m->N, m->K, m->nref, m->nx,
-                       m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path,
-                       d_step_flags);
+#define AMK_LAUNCH_SOLVE(NT)                                                                                         \
+    hipLaunchKernelGGL(mpc_solve_kernel<NT>, dim3(m->S), dim3(64), m->lds_bytes, stream, m->N, m->K, m->nref, m->nx, \
+                       m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, \
+                       d_step_flags, m->plan_coef.p, m->plan_meta.p)
+    switch (m->N) {  // the BASELINE horizons get their own instantiation; anything else runs the generic one
+        case 10: AMK_LAUNCH_SOLVE(10); break;
+        case 20: AMK_LAUNCH_SOLVE(20); break;
+        case 30: AMK_LAUNCH_SOLVE(30); break;
+        default: AMK_LAUNCH_SOLVE(0); break;
+    }
+#undef AMK_LAUNCH_SOLVE
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }
@@ -148,10 +245,15 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     m->opt.eta_phi = 1e-8; m->opt.s_max = 100.0; m->opt.kappa_sigma = 1e10;
     m->lds_bytes = sizeof(double) * (size_t)LdsMap(N).total;
     hipError_t e;
-    if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
+    if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess ||
+        (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * PLAN_TERMS)) != hipSuccess ||
+        (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4))) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
-        (e = hipFuncSetAttribute((const void *)mpc_solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)m->lds_bytes)) != hipSuccess) {
+        (e = hipFuncSetAttribute(N == 10   ? (const void *)mpc_solve_kernel<10>
+                                 : N == 20 ? (const void *)mpc_solve_kernel<20>
+                                 : N == 30 ? (const void *)mpc_solve_kernel<30>
+                                           : (const void *)mpc_solve_kernel<0>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)m->lds_bytes)) != hipSuccess) {
         delete m;
         return amk::hip_fail(e);
     }
