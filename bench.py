@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--T", type=float, default=0.66)
     ap.add_argument("--K", type=int, default=8)
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent steps in flight (each on its own HIP stream with its own handles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with every kernel class timed")
     args = ap.parse_args()
@@ -149,22 +151,38 @@ def main():
         edges[s] = torch.from_numpy(sc["edge"]).to(dev)
         sq[s] = fsm.state_quads(sc["pos"], sc["vel"], sc["acc"], sc["yaw"], prm.decay, prm.max_iter); ref0[s] = sc["ref_path"]; posx[s] = sc["pos"][0]
     sq_d = torch.from_numpy(sq).to(dev); ref0_d = torch.from_numpy(ref0).to(dev); posx_d = torch.from_numpy(posx).to(dev)
-    ref_d = ref0_d.clone()
-    kd_o, kd_e = KdBatch(S, n), KdBatch(S, ne)
-    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
-    out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
-               x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
-               flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
     from avoid_mpc_amd import shard
 
+    class Slot:
+        """Everything one in-flight step owns: a HIP stream, the dual KD indices of its frame, its
+        MPC batch (warm start, workspace), its reference path and outputs.  Consecutive steps are
+        independent frames, so several are kept in flight: while one step sits in its latency-bound
+        solve (256 wavefronts on 1024 SIMDs) another streams its clouds."""
+
+        def __init__(self):
+            self.stream = torch.cuda.Stream(device=dev)
+            self.kd_o, self.kd_e = KdBatch(S, n), KdBatch(S, ne)
+            self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm)
+            self.ref = ref0_d.clone()
+            self.out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
+                            x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
+                            flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
+
+    slots = [Slot() for _ in range(max(1, args.streams))]
+    out = slots[0].out
+    step_no = [0]
+
     def one_step():
-        ref_d.copy_(ref0_d)                 # fresh frame: mRefPath after GetInitPath
-        mpc.reset_warm_start()              # zero warm start (HighLvlMpc.cpp:26-27,35)
-        kd_o.build(clouds)                  # FrameKDMap::AddVertex: obstacle index ...
-        kd_e.build(edges)                   # ... and edge index (FrameKDMap.cpp:44-47)
-        step_batch(kd_o, kd_e, mpc, prm, sq_d, posx_d, ref_d, out=out)
-        if world > 1:
-            shard.gather_controls(out["u"])       # the one exchange step: controls to every rank
+        sl = slots[step_no[0] % len(slots)]
+        step_no[0] += 1
+        with torch.cuda.stream(sl.stream):
+            sl.ref.copy_(ref0_d, non_blocking=True)   # fresh frame: mRefPath after GetInitPath
+            sl.mpc.reset_warm_start(sl.stream)        # zero warm start (HighLvlMpc.cpp:26-27,35)
+            sl.kd_o.build(clouds, stream=sl.stream)   # FrameKDMap::AddVertex: obstacle index ...
+            sl.kd_e.build(edges, stream=sl.stream)    # ... and edge index (FrameKDMap.cpp:44-47)
+            step_batch(sl.kd_o, sl.kd_e, sl.mpc, prm, sq_d, posx_d, sl.ref, stream=sl.stream, out=sl.out)
+            if world > 1:
+                shard.gather_controls(sl.out["u"])    # the one exchange step: controls to every rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -172,6 +190,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    for _ in range(len(slots)):            # untimed priming: every slot allocates its workspace once
+        one_step()
+    barrier()
     for _ in range(args.warmup):
         one_step()
     barrier()
@@ -219,6 +240,7 @@ def main():
                                    f"every step", "scenes_per_gpu": S, "points": n, "horizon": N, "K": prm.K,
                        "mpc_max_iter": prm.max_iter, "ipm_max_iter": 10,
                        "solves_per_step": round(solves, 3), "ipm_iters_per_step": round(ipm_iters, 2),
+                       "streams_in_flight": len(slots),
                        "parallelism": f"scenes sharded over {world} GPU(s); all_gather of u" if world > 1
                        else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "mpc_solve_kernel", "achieved": round(achieved, 3),
