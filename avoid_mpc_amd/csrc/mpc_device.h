@@ -153,8 +153,8 @@ struct SceneIO {
     const double *obs;     // [N][K][3] obstacle points           (P[10+10N : ...])
 };
 
-// ---- one obstacle term: cost and, when DERIV, gradient (6) + model Hessian (21 unique, row-major
-// lower triangle of the (p,v) 6x6 block).  Mirrors oracle collide_point statement by statement.
+// ---- one obstacle term, ACCUMULATED into cost and, when DERIV, gradient (6) + model Hessian (21 unique,
+// row-major lower triangle of the (p,v) 6x6 block).  Mirrors oracle collide_point statement by statement.
 template <bool DERIV>
 __device__ __forceinline__ void collide_point(const double p[3], const double v[3], const double o[3], double lam,
                                               double radius, double &cost, double g6[6], double H[21]) {
@@ -167,7 +167,7 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
     const double ex = exp(x);
     const double g = log(1.0 + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
     const double as = fabs(s);
-    cost = lam * g * as;
+    cost += lam * g * as;
     if (!DERIV) return;
     const double sg = 1.0 / (1.0 + exp(-x));
     const double gp = -32.0 * sg;
@@ -177,8 +177,8 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
     const double ls = lam * sgn;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        g6[i] = ls * (gp * (-n[i]) * s + g * (-t[i] * ir));
-        g6[3 + i] = ls * g * n[i];
+        g6[i] += ls * (gp * (-n[i]) * s + g * (-t[i] * ir));
+        g6[3 + i] += ls * g * n[i];
     }
     const double gs[6] = {-t[0] * ir, -t[1] * ir, -t[2] * ir, n[0], n[1], n[2]};
     const double wk = lam * g / (as > kAbsEps ? as : kAbsEps);
@@ -199,7 +199,7 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
                 const double Pn = (a == j ? 1.0 : 0.0) - nn;
                 h += ls * (-gp * nn - g * Pn * ir);
             }
-            H[i * (i + 1) / 2 + j] = h;
+            H[i * (i + 1) / 2 + j] += h;
         }
 }
 
@@ -212,31 +212,42 @@ __device__ __forceinline__ double evaluate(double *sm, const LdsMap &L, const Sc
     const double *prm = sm + L.prm;
     const double lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
     double Jloc = 0.0;
-    // ---- collision terms: lanes = (stage, obstacle) with the obstacle index padded to Kpad
-    const int spr = 64 / Kpad;
+    // ---- collision terms: Lp lanes per stage (power of two, all N-1 stages in one round when they fit),
+    // each lane accumulates a contiguous block of `per` obstacle points before the cross-lane reduction
+    // (a 28-value DPP reduction per level costs more than a whole collide_point evaluation)
+    int Lp = 1;
+    while (Lp * 2 <= Kpad && (N - 1) * (Lp * 2) <= 64) Lp *= 2;
+    const int per = (K + Lp - 1) / Lp;
+    const int spr = 64 / Lp;
     for (int k0 = 0; k0 < N - 1; k0 += spr) {
-        const int k = k0 + lane / Kpad, j = lane % Kpad;
-        const bool act = (k < N - 1) && (j < K);
+        const int k = k0 + lane / Lp, jl = lane % Lp;
         const long long tc0 = AMK_CLK();
         double c = 0.0, g6[6] = {0, 0, 0, 0, 0, 0}, H[21];
         if (DERIV) {
 #pragma unroll
             for (int e = 0; e < 21; ++e) H[e] = 0.0;
         }
-        if (act) {
+        if (k < N - 1) {
             const double *xk = Xs + (k + 1) * SD;
             const double p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
-            const double *op = io.obs + ((size_t)k * K + j) * 3;
-            const double o[3] = {op[0], op[1], op[2]};
-            collide_point<DERIV>(p, v, o, lamw, radius, c, g6, H);
+            for (int jj = 0; jj < per; ++jj) {
+                const int j = jl * per + jj;
+                if (j < K) {
+                    const double *op = io.obs + ((size_t)k * K + j) * 3;
+                    const double o[3] = {op[0], op[1], op[2]};
+                    collide_point<DERIV>(p, v, o, lamw, radius, c, g6, H);
+                }
+            }
         }
+        const int j = jl;
+        const int Kpad_red = Lp;
         const long long tc1 = AMK_CLK();
-        c = seg_sum(c, Kpad);
+        c = seg_sum(c, Kpad_red);
         if (DERIV) {
 #pragma unroll
-            for (int e = 0; e < 6; ++e) g6[e] = seg_sum(g6[e], Kpad);
+            for (int e = 0; e < 6; ++e) g6[e] = seg_sum(g6[e], Kpad_red);
 #pragma unroll
-            for (int e = 0; e < 21; ++e) H[e] = seg_sum(H[e], Kpad);
+            for (int e = 0; e < 21; ++e) H[e] = seg_sum(H[e], Kpad_red);
         }
         const long long tc2 = AMK_CLK();
         if (kTrace && tclk) { tclk[0] += tc1 - tc0; tclk[1] += tc2 - tc1; }
@@ -457,35 +468,38 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
             if (!(d3 > 0.0)) return false;
             Di[3] = fast_rcp(d3);
         }
-        if (lane <= SD) {
-            const int j = lane;  // column j of G, or j == 10: qu
-            const double g0 = j < SD ? sm[L.G + j] : sm[L.qu + 0];
-            const double g1 = j < SD ? sm[L.G + 10 + j] : sm[L.qu + 1];
-            const double g2 = j < SD ? sm[L.G + 20 + j] : sm[L.qu + 2];
-            const double g3 = j < SD ? sm[L.G + 30 + j] : sm[L.qu + 3];
-            const double y0 = g0;
-            const double y1 = g1 - Lm[0] * y0;
-            const double y2 = g2 - Lm[1] * y0 - Lm[2] * y1;
-            const double y3 = g3 - Lm[3] * y0 - Lm[4] * y1 - Lm[5] * y2;
-            // x = L^-T D^-1 y ; gain = -x ; Z = D^-1 Y is what round C multiplies with
-            const double z0 = y0 * Di[0], z1 = y1 * Di[1], z2 = y2 * Di[2], z3 = y3 * Di[3];
-            sm[L.Y + j] = y0; sm[L.Y + 11 + j] = y1; sm[L.Y + 22 + j] = y2; sm[L.Y + 33 + j] = y3;
-            sm[L.Z + j] = z0; sm[L.Z + 11 + j] = z1; sm[L.Z + 22 + j] = z2; sm[L.Z + 33 + j] = z3;
-            const double x3 = z3;
-            const double x2 = z2 - Lm[5] * x3;
-            const double x1 = z1 - Lm[2] * x2 - Lm[4] * x3;
-            const double x0 = z0 - Lm[0] * x1 - Lm[1] * x2 - Lm[3] * x3;
+        // ---- rounds B+C fused: every lane forward-solves the (<= 2) columns of [G | qu] its own outputs
+        // need (Y = L^-1 [G | qu], Z = D^-1 Y); no LDS round trip / barrier between the factorisation
+        // and the update.  P_k = Q_k + delta I + M - Y'Z ; p_k = q_k + A'p - Y'z_u ; lam_k = q_k + A'lam
+        auto solve_col = [&](int c, double (&y)[4], double (&z)[4]) {
+            const double g0 = c < SD ? sm[L.G + c] : sm[L.qu + 0];
+            const double g1 = c < SD ? sm[L.G + 10 + c] : sm[L.qu + 1];
+            const double g2 = c < SD ? sm[L.G + 20 + c] : sm[L.qu + 2];
+            const double g3 = c < SD ? sm[L.G + 30 + c] : sm[L.qu + 3];
+            y[0] = g0;
+            y[1] = g1 - Lm[0] * y[0];
+            y[2] = g2 - Lm[1] * y[0] - Lm[2] * y[1];
+            y[3] = g3 - Lm[3] * y[0] - Lm[4] * y[1] - Lm[5] * y[2];
+            z[0] = y[0] * Di[0]; z[1] = y[1] * Di[1]; z[2] = y[2] * Di[2]; z[3] = y[3] * Di[3];
+        };
+        if (lane <= SD) {  // gains: x = L^-T Z(:,c), K(:,c) = -x (column 10 = feed-forward)
+            double y[4], z[4];
+            solve_col(lane, y, z);
+            const double x3 = z[3];
+            const double x2 = z[2] - Lm[5] * x3;
+            const double x1 = z[1] - Lm[2] * x2 - Lm[4] * x3;
+            const double x0 = z[0] - Lm[0] * x1 - Lm[1] * x2 - Lm[3] * x3;
             double *kk = sm + L.Kk + k * 44;
-            kk[j] = -x0; kk[11 + j] = -x1; kk[22 + j] = -x2; kk[33 + j] = -x3;
+            kk[lane] = -x0; kk[11 + lane] = -x1; kk[22 + lane] = -x2; kk[33 + lane] = -x3;
         }
-        __syncthreads();
-        // ---- round C: P_k = Q_k + delta I + M - Y'D^-1 Y ; p_k = q_k + A'p - Y'D^-1 yv ; lam_k = q_k + A'lam
         if (k > 0) {
-            const double *Y = sm + L.Y, *Z = sm + L.Z;
             const int i = lp.ci;
+            double yi[4], zi[4], yj[4], zj[4];
+            solve_col(i, yi, zi);
+            solve_col(lane < 55 ? lp.cj : SD, yj, zj);
+            const double ww = yi[0] * zj[0] + yi[1] * zj[1] + yi[2] * zj[2] + yi[3] * zj[3];
             if (lane < 55) {
                 const int j = lp.cj, st = k - 1;
-                const double ww = Y[i] * Z[j] + Y[11 + i] * Z[11 + j] + Y[22 + i] * Z[22 + j] + Y[33 + i] * Z[33 + j];
                 double qe = lp.qdiag + (i == j ? delta : 0.0);
                 if (lp.rot_off >= 0) qe += sm[L.rotQ + st * 6 + lp.rot_off];
                 if (lp.h6_off >= 0) qe += sm[L.H6 + st * 36 + lp.h6_off];
@@ -493,11 +507,13 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
                 P[i * 10 + j] = val;
                 P[j * 10 + i] = val;
             } else {  // p entries 0..8
-                const double wv = Y[i] * Z[10] + Y[11 + i] * Z[21] + Y[22 + i] * Z[32] + Y[33 + i] * Z[43];
-                pv[i] = sm[L.q + k * SD + i] + sm[L.Atp + i] - wv;
+                pv[i] = sm[L.q + k * SD + i] + sm[L.Atp + i] - ww;
             }
             if (lane == 0) {  // p entry 9
-                const double wv = Y[9] * Z[10] + Y[20] * Z[21] + Y[31] * Z[32] + Y[42] * Z[43];
+                double y9[4], z9[4], yu[4], zu[4];
+                solve_col(9, y9, z9);
+                solve_col(SD, yu, zu);
+                const double wv = y9[0] * zu[0] + y9[1] * zu[1] + y9[2] * zu[2] + y9[3] * zu[3];
                 pv[9] = sm[L.q + k * SD + 9] + sm[L.Atp + 9] - wv;
             } else if (lane <= SD) {  // lam entries
                 const int ii = lane - 1;
