@@ -76,9 +76,10 @@ struct TimedLaunch {  // RAII: records an event before and after the enclosed la
 struct amk_kd {
     int n_scenes = 0;
     int max_points = 0;
-    int cap = 0;  // per-scene SoA capacity, multiple of 256 with >= 256 floats of NaN padding
+    int cap = 0;  // per-scene SoA capacity, multiple of 256 with >= 1024 floats of NaN padding
     amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded
     amk::DevBuf<int> size;       // [S] cloud.pts.size() after the NaN-x filter
+    amk::DevBuf<float> pmax;     // [S] max |coordinate| of the kept points (bounds the fp32 pre-filter error)
     // staging for the *_host conveniences
     amk::DevBuf<float> stage_xyz;
     amk::DevBuf<int> stage_counts;

@@ -73,7 +73,7 @@ constexpr int kCompactThreads = 1024;
 __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
     const float *__restrict__ xyz, int point_stride, long long scene_stride,
     const int *__restrict__ counts, int max_points, float *__restrict__ X, float *__restrict__ Y,
-    float *__restrict__ Z, int cap, int *__restrict__ size_out) {
+    float *__restrict__ Z, int cap, int *__restrict__ size_out, float *__restrict__ pmax_out) {
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
     n = n < 0 ? 0 : (n > max_points ? max_points : n);
 
     __shared__ int wave_tot[kCompactThreads / kWave];
+    __shared__ float wave_max[kCompactThreads / kWave];
+    float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
         const int i = c0 + tid;
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
             xs[o] = px;
             ys[o] = py;
             zs[o] = pz;
+            amax = fmaxf(amax, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
         }
         base += tot;
         __syncthreads();
@@ -121,57 +124,67 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
         ys[i] = qnan;
         zs[i] = qnan;
     }
-    if (tid == 0) size_out[s] = base;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) wave_max[w] = amax;
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int j = 0; j < kCompactThreads / kWave; ++j) m = fmaxf(m, wave_max[j]);
+        size_out[s] = base;
+        pmax_out[s] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
 // search: one wavefront per (scene, group of QPW queries); device scan in kd_device.h
 // ------------------------------------------------------------------------------------------------
 template <int QPW>
-__global__ __launch_bounds__(kWave) void kd_scan_kernel(
+__global__ __launch_bounds__(512) void kd_scan_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
-    const int *__restrict__ sizes, int n_scenes, const double *__restrict__ queries, int n_queries,
-    int k, int *__restrict__ out_idx, double *__restrict__ out_d2, float *__restrict__ out_pts,
-    int *__restrict__ out_cnt) {
-    // XCD-aware placement: the dispatcher puts block b on XCD b % 8, so all query groups of one
-    // scene are mapped to the same XCD and share that XCD's L2 copy of the scene's cloud.
+    const int *__restrict__ sizes, const float *__restrict__ pmaxs, int n_scenes,
+    const double *__restrict__ queries, int n_queries, int k, int *__restrict__ out_idx,
+    double *__restrict__ out_d2, float *__restrict__ out_pts, int *__restrict__ out_cnt) {
+    // One wavefront per (scene, group of QPW queries); the waves of a block are consecutive groups of
+    // ONE scene, so they stream the same tiles at the same pace and share them in the CU's L1.
+    // XCD-aware placement: the dispatcher puts block b on XCD b % 8, so all blocks of one scene are
+    // mapped to the same XCD and share that XCD's L2 copy of the scene's cloud.
     const int groups = (n_queries + QPW - 1) / QPW;
+    const int wpb = blockDim.x >> 6;
+    const int bps = (groups + wpb - 1) / wpb;  // blocks per scene
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
-    const int s = (j / groups) * 8 + xcd;
-    const int g = j % groups;
-    if (s >= n_scenes) return;
-    const int lane = threadIdx.x;
+    const int s = (j / bps) * 8 + xcd;
+    const int w = threadIdx.x >> 6;
+    const int g = (j % bps) * wpb + w;
+    if (s >= n_scenes || g >= groups) return;
+    const int lane = threadIdx.x & 63;
     const int size = sizes[s];
     const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
 
-    double qx[QPW], qy[QPW], qz[QPW];
-    double ld[QPW];  // lane i < k: i-th best squared distance
-    int li[QPW];     //             and its index
-#pragma unroll
-    for (int qq = 0; qq < QPW; ++qq) {
-        int q = g * QPW + qq;
-        q = q < n_queries ? q : n_queries - 1;  // tail group recomputes the last query; not stored
-        const double *qp = queries + ((size_t)s * n_queries + q) * 3;
-        qx[qq] = qp[0];
-        qy[qq] = qp[1];
-        qz[qq] = qp[2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+    amk::ScanLds<QPW> *ws = reinterpret_cast<amk::ScanLds<QPW> *>(scan_smem) + w;
+    double *qt = reinterpret_cast<double *>(reinterpret_cast<amk::ScanLds<QPW> *>(scan_smem) + wpb) + w * QPW * 3;
+    const int q0 = g * QPW;
+    const int nvalid = n_queries - q0 < QPW ? n_queries - q0 : QPW;
+    // stage this group's queries (a ragged tail group pads with copies of its last query; not stored)
+    if (lane < QPW * 3) {
+        const int qq = lane / 3 < nvalid ? lane / 3 : nvalid - 1;
+        qt[lane] = queries[((size_t)s * n_queries + q0 + qq) * 3 + lane % 3];
     }
-    amk::scan_cloud<QPW>(xs, ys, zs, size, qx, qy, qz, k, ld, li);
+    amk::scan_cloud<QPW>(xs, ys, zs, size, pmaxs[s], qt, 3, k, ws);
 
     // KDTreeTwo::SearchForNearest count rule, kd_tree_two.h:119-124
     const int cnt = size < k ? size : (size > k ? k : 0);
-#pragma unroll
-    for (int qq = 0; qq < QPW; ++qq) {
-        const int q = g * QPW + qq;
-        if (q >= n_queries) break;
-        const size_t row = (size_t)s * n_queries + q;
+    for (int qq = 0; qq < nvalid; ++qq) {
+        const size_t row = (size_t)s * n_queries + q0 + qq;
         if (lane == 0 && out_cnt) out_cnt[row] = cnt;
         if (lane < k) {
-            const bool ok = lane < cnt && li[qq] != amk::kNoIndex;
-            const int idx = ok ? li[qq] : -1;
+            const int li = ws->li[qq][lane];
+            const bool ok = lane < cnt && li != amk::kNoIndex;
+            const int idx = ok ? li : -1;
             if (out_idx) out_idx[row * k + lane] = idx;
-            if (out_d2) out_d2[row * k + lane] = ok ? ld[qq] : DBL_MAX;
+            if (out_d2) out_d2[row * k + lane] = ok ? ws->ld[qq][lane] : DBL_MAX;
             if (out_pts) {
                 float *o = out_pts + (row * k + lane) * 3;
                 o[0] = ok ? xs[idx] : 0.f;
@@ -215,11 +228,12 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
     amk_kd *kd = new amk_kd();
     kd->n_scenes = n_scenes;
     kd->max_points = max_points;
-    kd->cap = amk::round_up(max_points, 256) + 256;
+    kd->cap = amk::round_up(max_points, 256) + 1024;  // NaN padding: full vector loads + 3-tile look-ahead
     const size_t tot = (size_t)n_scenes * kd->cap;
     hipError_t e;
     if ((e = kd->x.alloc(tot)) != hipSuccess || (e = kd->y.alloc(tot)) != hipSuccess ||
-        (e = kd->z.alloc(tot)) != hipSuccess || (e = kd->size.alloc(n_scenes)) != hipSuccess) {
+        (e = kd->z.alloc(tot)) != hipSuccess || (e = kd->size.alloc(n_scenes)) != hipSuccess ||
+        (e = kd->pmax.alloc(n_scenes)) != hipSuccess || (e = hipMemset(kd->pmax.p, 0, sizeof(float) * n_scenes)) != hipSuccess) {
         delete kd;
         return amk::hip_fail(e);
     }
@@ -243,7 +257,7 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
     amk::TimedLaunch tl(amk::KC_COMPACT, (hipStream_t)stream);
     hipLaunchKernelGGL(kd_compact_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
                        point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
-                       kd->size.p);
+                       kd->size.p, kd->pmax.p);
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }
@@ -259,19 +273,17 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
                   float *d_pts, int *d_counts, void *stream) {
     if (!kd || !d_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
     if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
-    // Two queries per wavefront halve the cloud traffic and the f32->f64 conversions per distance;
-    // single queries (GetNearestDistance, the edge snap) run one per wavefront.
-    const int qpw = n_queries >= 2 ? 2 : 1;
-    const int groups = (n_queries + qpw - 1) / qpw;
-    const int blocks = (kd->n_scenes + 7) / 8 * 8 * groups;
-    if (qpw == 2)
-        hipLaunchKernelGGL(kd_scan_kernel<2>, dim3(blocks), dim3(kWave), 0, (hipStream_t)stream, kd->x.p, kd->y.p,
-                           kd->z.p, kd->cap, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist,
-                           d_pts, d_counts);
-    else
-        hipLaunchKernelGGL(kd_scan_kernel<1>, dim3(blocks), dim3(kWave), 0, (hipStream_t)stream, kd->x.p, kd->y.p,
-                           kd->z.p, kd->cap, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist,
-                           d_pts, d_counts);
+    int qpw, groups, wpb;
+    amk::scan_geometry(n_queries, qpw, groups, wpb);
+    const int bps = (groups + wpb - 1) / wpb;
+    const int blocks = (kd->n_scenes + 7) / 8 * 8 * bps;
+#define AMK_LAUNCH_SCAN(Q)                                                                                      \
+    hipLaunchKernelGGL(kd_scan_kernel<Q>, dim3(blocks), dim3(wpb * kWave), amk::scan_lds_bytes<Q>(wpb),          \
+                       (hipStream_t)stream, kd->x.p, kd->y.p, kd->z.p, kd->cap, kd->size.p, kd->pmax.p,          \
+                       kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts)
+    if (qpw == 1) AMK_LAUNCH_SCAN(1);
+    else AMK_LAUNCH_SCAN(5);
+#undef AMK_LAUNCH_SCAN
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }

@@ -31,45 +31,45 @@ __global__ void step_begin_kernel(int S, int *__restrict__ done, int *__restrict
 // n_queries reference points per scene; queries are read in place from the reference path
 // (stride 10 doubles).  Empty slots: distance DBL_MAX.
 template <int QPW>
-__global__ __launch_bounds__(kWave) void step_scan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
-                                                          const float *__restrict__ Z, int cap,
-                                                          const int *__restrict__ sizes, int n_scenes,
-                                                          const double *__restrict__ ref_path, int N, int n_queries,
-                                                          int k, float *__restrict__ out_pts,
-                                                          double *__restrict__ out_d2, const int *__restrict__ done) {
+__global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+                                                        const float *__restrict__ Z, int cap,
+                                                        const int *__restrict__ sizes,
+                                                        const float *__restrict__ pmaxs, int n_scenes,
+                                                        const double *__restrict__ ref_path, int N, int n_queries,
+                                                        int k, float *__restrict__ out_pts,
+                                                        double *__restrict__ out_d2, const int *__restrict__ done) {
     const int groups = (n_queries + QPW - 1) / QPW;
+    const int wpb = blockDim.x >> 6;
+    const int bps = (groups + wpb - 1) / wpb;
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
-    const int s = (j / groups) * 8 + xcd;  // all query groups of a scene share one XCD's L2
-    const int g = j % groups;
-    if (s >= n_scenes || done[s]) return;
-    const int lane = threadIdx.x;
+    const int s = (j / bps) * 8 + xcd;  // all blocks of a scene share one XCD's L2; its waves one CU's L1
+    const int w = threadIdx.x >> 6;
+    const int g = (j % bps) * wpb + w;
+    if (s >= n_scenes || g >= groups || done[s]) return;
+    const int lane = threadIdx.x & 63;
     const int size = sizes[s];
     const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
-    double qx[QPW], qy[QPW], qz[QPW], ld[QPW];
-    int li[QPW];
-#pragma unroll
-    for (int qq = 0; qq < QPW; ++qq) {
-        int q = g * QPW + qq;
-        q = q < n_queries ? q : n_queries - 1;
-        const double *qp = ref_path + ((size_t)s * N + q) * SD;
-        qx[qq] = qp[0];
-        qy[qq] = qp[1];
-        qz[qq] = qp[2];
+    extern __shared__ __attribute__((aligned(16))) unsigned char scan_smem[];
+    ScanLds<QPW> *ws = reinterpret_cast<ScanLds<QPW> *>(scan_smem) + w;
+    double *qt = reinterpret_cast<double *>(reinterpret_cast<ScanLds<QPW> *>(scan_smem) + wpb) + w * QPW * 3;
+    const int q0 = g * QPW;
+    const int nvalid = n_queries - q0 < QPW ? n_queries - q0 : QPW;
+    if (lane < QPW * 3) {  // queries = positions of the reference points (stride 10 in mRefPath)
+        const int qq = lane / 3 < nvalid ? lane / 3 : nvalid - 1;
+        qt[lane] = ref_path[((size_t)s * N + q0 + qq) * SD + lane % 3];
     }
-    scan_cloud<QPW>(xs, ys, zs, size, qx, qy, qz, k, ld, li);
-#pragma unroll
-    for (int qq = 0; qq < QPW; ++qq) {
-        const int q = g * QPW + qq;
-        if (q >= n_queries) break;
-        const size_t row = (size_t)s * n_queries + q;
+    scan_cloud<QPW>(xs, ys, zs, size, pmaxs[s], qt, 3, k, ws);
+    for (int qq = 0; qq < nvalid; ++qq) {
+        const size_t row = (size_t)s * n_queries + q0 + qq;
         if (lane < k) {
-            const bool ok = li[qq] != kNoIndex;
-            out_d2[row * k + lane] = ok ? ld[qq] : DBL_MAX;
+            const int li = ws->li[qq][lane];
+            const bool ok = li != kNoIndex;
+            out_d2[row * k + lane] = ok ? ws->ld[qq][lane] : DBL_MAX;
             float *o = out_pts + (row * k + lane) * 3;
-            o[0] = ok ? xs[li[qq]] : 0.f;
-            o[1] = ok ? ys[li[qq]] : 0.f;
-            o[2] = ok ? zs[li[qq]] : 0.f;
+            o[0] = ok ? xs[li] : 0.f;
+            o[1] = ok ? ys[li] : 0.f;
+            o[2] = ok ? zs[li] : 0.f;
         }
     }
 }
@@ -78,6 +78,7 @@ __global__ __launch_bounds__(kWave) void step_scan_kernel(const float *__restric
 __global__ __launch_bounds__(kWave) void step_plan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
+                                                          const float *__restrict__ pmax_obs,
                                                           const int *__restrict__ sizes_edge, int N, int K,
                                                           double safety_distance, double *__restrict__ ref_path,
                                                           float *__restrict__ knn_pts, double *__restrict__ knn_d2,
@@ -103,17 +104,18 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(const float *__restric
             const double ex = (double)edge_pt[3 * s + 0], ey = (double)edge_pt[3 * s + 1], ez = (double)edge_pt[3 * s + 2];
             // the snapped point is what ProcessWaypoints queries next (:210-215): redo query 0
             const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
-            const double qx[1] = {ex}, qy[1] = {ey}, qz[1] = {ez};
-            double ld[1];
-            int li[1];
-            scan_cloud<1>(xs, ys, zs, size_o, qx, qy, qz, K, ld, li);
+            __shared__ ScanLds<1> ws1;
+            __shared__ double q1[3];
+            q1[0] = ex; q1[1] = ey; q1[2] = ez;  // every lane stores the same values
+            scan_cloud<1>(xs, ys, zs, size_o, pmax_obs[s], q1, 3, K, &ws1);
             if (lane < K) {
-                const bool ok = li[0] != kNoIndex;
-                knn_d2[(size_t)s * N * K + lane] = ok ? ld[0] : DBL_MAX;
+                const int li = ws1.li[0][lane];
+                const bool ok = li != kNoIndex;
+                knn_d2[(size_t)s * N * K + lane] = ok ? ws1.ld[0][lane] : DBL_MAX;
                 float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
-                o[0] = ok ? xs[li[0]] : 0.f;
-                o[1] = ok ? ys[li[0]] : 0.f;
-                o[2] = ok ? zs[li[0]] : 0.f;
+                o[0] = ok ? xs[li] : 0.f;
+                o[1] = ok ? ys[li] : 0.f;
+                o[2] = ok ? zs[li] : 0.f;
             }
             if (lane == 0) {
                 p1[0] = ex;
@@ -193,20 +195,23 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     }
     { TimedLaunch tl(KC_BEGIN, stream);
     hipLaunchKernelGGL(step_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u); }
-    const int groups = (N + 1) / 2;
+    int qpw, groups, wpb;
+    scan_geometry(N, qpw, groups, wpb);
+    const int bps = (groups + wpb - 1) / wpb;
     const int S8 = (S + 7) / 8 * 8;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         { TimedLaunch tl(KC_SCAN_OBS, stream);
-        hipLaunchKernelGGL(step_scan_kernel<2>, dim3(S8 * groups), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
-                           obstacle->z.p, obstacle->cap, obstacle->size.p, S, d_ref_path, N, N, K, mpc->knn_pts.p,
-                           mpc->knn_d2.p, mpc->done.p); }
+        hipLaunchKernelGGL(step_scan_kernel<5>, dim3(S8 * bps), dim3(wpb * kWave), scan_lds_bytes<5>(wpb), stream,
+                           obstacle->x.p, obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p,
+                           obstacle->pmax.p, S, d_ref_path, N, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->done.p); }
         { TimedLaunch tl(KC_SCAN_EDGE, stream);
-        hipLaunchKernelGGL(step_scan_kernel<1>, dim3(S8), dim3(kWave), 0, stream, edge->x.p, edge->y.p, edge->z.p,
-                           edge->cap, edge->size.p, S, d_ref_path, N, 1, 1, mpc->edge_pt.p, mpc->edge_d2.p,
-                           mpc->done.p); }
+        hipLaunchKernelGGL(step_scan_kernel<1>, dim3(S8), dim3(kWave), scan_lds_bytes<1>(1), stream, edge->x.p,
+                           edge->y.p, edge->z.p, edge->cap, edge->size.p, edge->pmax.p, S, d_ref_path, N, 1, 1,
+                           mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         { TimedLaunch tl(KC_PLAN, stream);
         hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
-                           obstacle->z.p, obstacle->cap, obstacle->size.p, edge->size.p, N, K, prm->safety_distance,
+                           obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N, K,
+                           prm->safety_distance,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p,
                            d_flags); }
         { TimedLaunch tl(KC_PACK, stream);

@@ -114,6 +114,30 @@ def test_ties_follow_lowest_index_policy(torch_cuda, oracle):
                 assert np.array_equal(r["sqdist"][0, i], t.search_raw(q, k)[1])   # same distances as nanoflann
 
 
+def test_fp32_prefilter_is_conservative(torch_cuda, oracle):
+    """The scan rejects most points with an fp32 distance test; it must never reject a true neighbour.
+    Stress it where fp32 is weakest: coordinates of magnitude 1e3..1e6 (fp32 ulp 6e-5..6e-2) with
+    neighbours much closer to each other than an ulp of the query, queries far outside the cloud,
+    and a cloud so small that fp32 squares go denormal."""
+    rng = np.random.default_rng(12)
+    cases = []
+    for mag in (1e3, 1e5, 1e6):
+        c = (mag + rng.uniform(-1.0, 1.0, (4000, 3))).astype(np.float32)
+        q = mag + rng.uniform(-1.5, 1.5, (22, 3))
+        cases.append((c, q))
+    c = rng.uniform(-1, 1, (3000, 3)).astype(np.float32)
+    cases.append((c, rng.uniform(-1, 1, (22, 3)) + np.array([1e7, 0, 0])))         # far query
+    cases.append((c * 1e-20, rng.uniform(-1, 1, (22, 3)) * 1e-20))                  # tiny scale (fp32 denormal squares)
+    for cloud, qs in cases:
+        t = _oracle.kd_oracle(cloud)
+        for k in (1, 8):
+            r = _gpu_search(torch_cuda, [cloud], qs[None], k)
+            for i, q in enumerate(qs):
+                ib, db = t.bruteforce(q, k)                                         # ties possible at 1e6: index order
+                assert np.array_equal(r["indices"][0, i, :len(ib)], ib)
+                assert np.array_equal(r["sqdist"][0, i, :len(ib)].view(np.int64), db.view(np.int64))
+
+
 def test_single_query_and_host_api(torch_cuda, oracle):
     from avoid_mpc_amd.host import KdBatch
     cloud = synth.make_cloud(5000, 77)[0]
