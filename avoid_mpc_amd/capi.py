@@ -89,6 +89,7 @@ def load():
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
     }
+    sig["amk__kd_set_mode"] = (i, [vp, i])  # internal: 0 bucketed index, 1 streaming scan
     for name, (res, args) in sig.items():
         fn = getattr(lib, name, None)
         if fn is None:

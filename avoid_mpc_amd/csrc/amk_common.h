@@ -58,7 +58,7 @@ __device__ __forceinline__ double readlane_f64(double v, int src) {
 
 // ---- optional per-kernel-class timing with HIP events on the launch stream (bench.py's roofline leg).
 // Off by default; internal (amk__timing_* are not part of the C ABI in include/avoid_mpc_amd.h).
-enum KernelClass { KC_COMPACT = 0, KC_SCAN_OBS, KC_SCAN_EDGE, KC_PLAN, KC_PACK, KC_SOLVE, KC_BEGIN, KC_COUNT };
+enum KernelClass { KC_COMPACT = 0, KC_SCAN_OBS, KC_SCAN_EDGE, KC_PLAN, KC_PACK, KC_SOLVE, KC_BEGIN, KC_GRID, KC_COUNT };
 struct Timing;
 Timing &timing();
 struct TimedLaunch {  // RAII: records an event before and after the enclosed launch when enabled
@@ -80,6 +80,12 @@ struct amk_kd {
     amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded
     amk::DevBuf<int> size;       // [S] cloud.pts.size() after the NaN-x filter
     amk::DevBuf<float> pmax;     // [S] max |coordinate| of the kept points (bounds the fp32 pre-filter error)
+    // bucketed index (kd_grid.h): bucket-contiguous copy of the points, their cloud indices, bucket starts
+    amk::DevBuf<float4> gpt;         // [S][cap]  (x, y, z, cloud index)
+    amk::DevBuf<float> bbox;         // [S][6]    min xyz, max xyz of the finite points
+    amk::DevBuf<int> cell_start;     // [S][kGridMaxCells + 2]
+    amk::DevBuf<double> gparams;     // [S][8]
+    int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
     // staging for the *_host conveniences
     amk::DevBuf<float> stage_xyz;
     amk::DevBuf<int> stage_counts;

@@ -1,0 +1,289 @@
+// Bucketed spatial index of an amk_kd scene and the exact kNN search over it (gfx950).
+//
+// Role in the reference: nanoflann's buildIndex / findNeighbors (AM/include/nanoflann_two.hpp:1518-1541,
+// 1563-1586, 1729-1793) behind KDTreeTwo::InitializeNew / SearchForNearest (AM/include/kd_tree_two.h).
+// Only the *results* of a search must equal the reference's (exact k nearest, ascending), so the tree
+// shape is free.  On a GPU a pointer tree with 10-point leaves is the wrong shape:
+// the build here is a counting sort of the points into the cells of a uniform grid (bucket-contiguous
+// reordered SoA copy, ~8 points per cell, <= 8192 cells), the search one wavefront per query that
+// visits the cells in growing Chebyshev rings around the query's cell -- 64 lanes evaluate 64 bucket
+// points at a time -- and stops as soon as the k-th best squared distance is below the squared distance
+// to everything not yet visited.  That is the same branch-and-bound argument as nanoflann's
+// searchLevel (mindist <= worstDist, :1780-1790), applied to rings instead of half-spaces.
+#pragma once
+#include "kd_device.h"
+
+namespace amk {
+
+constexpr int kGridMaxCells = 8192;
+constexpr int kGridBuildThreads = 1024;
+constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz
+
+// ------------------------------------------------------------------------------------------------
+// build: one block per scene over the compacted SoA planes
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool finite3(float x, float y, float z) {
+    return fabsf(x) <= 3.0e38f && fabsf(y) <= 3.0e38f && fabsf(z) <= 3.0e38f;  // false for NaN and inf
+}
+
+__device__ __forceinline__ int cell_of(double p, double bbmin, double inv_h, int g) {
+    double c = floor((p - bbmin) * inv_h);
+    c = c < 0.0 ? 0.0 : c;
+    const double gm = (double)(g - 1);
+    c = c > gm ? gm : c;  // NaN never gets here (finite3), +-inf query coordinates clamp
+    return (int)c;
+}
+
+static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
+    const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP,
+    int *__restrict__ cell_start, double *__restrict__ gparams) {
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = sizes[s];
+    const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+    float4 *gpt4 = GP + (size_t)s * cap;  // bucket-contiguous points: (x, y, z, cloud index as int bits)
+    int *cs = cell_start + (size_t)s * (kGridMaxCells + 2);
+    double *gp = gparams + (size_t)s * kGridParamDoubles;
+
+    __shared__ int hist[kGridMaxCells + 2];
+    __shared__ int wsum[kGridBuildThreads / 64];
+    __shared__ double geo[kGridParamDoubles];
+
+    // 1. bounding box of the finite points: reduced by the compaction kernel (bbox[s][6] = min xyz, max xyz)
+    // 2. grid geometry: ~8 points per cell, <= kGridMaxCells cells, cubic cells of edge h
+    if (tid == 0) {
+        double lo[3], hi[3], ext[3], emax = 0.0;
+        for (int a = 0; a < 3; ++a) {
+            float m0 = bbox[6 * s + a], m1 = bbox[6 * s + 3 + a];
+            if (!(m1 >= m0)) { m0 = 0.f; m1 = 0.f; }  // no finite point at all
+            lo[a] = m0; hi[a] = m1;
+            ext[a] = (double)m1 - (double)m0;
+            emax = fmax(emax, ext[a]);
+        }
+        const double efloor = fmax(emax * 1e-6, 1e-30);
+        double vol = 1.0;
+        for (int a = 0; a < 3; ++a) vol *= fmax(ext[a], efloor);
+        double target = fmin(fmax((double)n / 8.0, 1.0), (double)kGridMaxCells);
+        double h = cbrt(vol / target);
+        if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
+        int g[3];
+        for (int it = 0; it < 64; ++it) {
+            long long prod = 1;
+            for (int a = 0; a < 3; ++a) {
+                double c = ceil(fmax(ext[a], efloor) / h);
+                g[a] = (int)fmin(fmax(c, 1.0), 1024.0);
+                prod *= g[a];
+            }
+            if (prod <= kGridMaxCells) break;
+            h *= 1.26;
+        }
+        if ((long long)g[0] * g[1] * g[2] > kGridMaxCells) { g[0] = g[1] = g[2] = 1; }
+        geo[0] = lo[0]; geo[1] = lo[1]; geo[2] = lo[2];
+        geo[3] = h; geo[4] = 1.0 / h;
+        geo[5] = g[0]; geo[6] = g[1]; geo[7] = g[2];
+        for (int a = 0; a < kGridParamDoubles; ++a) gp[a] = geo[a];
+    }
+    __syncthreads();
+    const double b0 = geo[0], b1 = geo[1], b2 = geo[2], inv_h = geo[4];
+    const int g0 = (int)geo[5], g1 = (int)geo[6], g2 = (int)geo[7];
+    const int ncell = g0 * g1 * g2;  // + one trash bucket (index ncell) for non-finite points
+    for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) hist[i] = 0;
+    __syncthreads();
+    // 3. histogram
+    for (int i = tid; i < n; i += kGridBuildThreads) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+        int c = ncell;
+        if (finite3(x, y, z))
+            c = (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0);
+        atomicAdd(&hist[c], 1);
+    }
+    __syncthreads();
+    // 4. exclusive scan of hist[0 .. ncell] -> bucket starts (global) and scatter cursors (LDS)
+    {
+        const int per = (ncell + 1 + kGridBuildThreads - 1) / kGridBuildThreads;
+        const int i0 = tid * per;
+        int loc = 0;
+        for (int j = 0; j < per; ++j)
+            if (i0 + j <= ncell) loc += hist[i0 + j];
+        int incl = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int wbase = 0;
+        for (int j = 0; j < w; ++j) wbase += wsum[j];
+        int run = wbase + incl - loc;
+        for (int j = 0; j < per; ++j)
+            if (i0 + j <= ncell) {
+                const int c = hist[i0 + j];
+                hist[i0 + j] = run;
+                cs[i0 + j] = run;
+                run += c;
+            }
+        if (tid == 0) cs[ncell + 1] = n;
+    }
+    __syncthreads();
+    // 5. scatter into bucket-contiguous order (order inside a bucket is irrelevant: results are ordered by
+    // (distance, original index))
+    for (int i = tid; i < n; i += kGridBuildThreads) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+        int c = ncell;
+        if (finite3(x, y, z))
+            c = (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0);
+        const int pos = atomicAdd(&hist[c], 1);
+        gpt4[pos] = make_float4(x, y, z, __int_as_float(i));  // one 16-byte store per point
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// search: one wavefront per query
+// ------------------------------------------------------------------------------------------------
+struct GridScene {
+    const float4 *pt;           // bucket-contiguous points (x, y, z, index in the NaN-x-filtered cloud)
+    const int *cs;              // bucket starts, [ncell + 2]
+    const double *gp;           // geometry
+};
+
+struct GridPtrs {  // the batch: what a kernel needs to find scene s
+    const float4 *pt;
+    const int *cs;
+    const double *gp;
+    int cap;
+    __device__ __forceinline__ GridScene scene(int s) const {
+        GridScene g;
+        g.pt = pt + (size_t)s * cap;
+        g.cs = cs + (size_t)s * (kGridMaxCells + 2);
+        g.gp = gp + (size_t)s * kGridParamDoubles;
+        return g;
+    }
+};
+
+struct GridWaveLds {  // per-wavefront scratch: ranges of the rows of the current ring
+    int pre[65];
+    int sA[64], lA[64], sB[64];
+};
+
+// Exact k nearest neighbours of (qx,qy,qz).  On return lane i < k holds the i-th best (squared
+// distance, index) in (ld, li); empty slots hold (DBL_MAX, kNoIndex).  Ties order by index.
+__device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double qy, double qz, int k, double &ld,
+                                         int &li, GridWaveLds *ws) {
+    const int lane = threadIdx.x & 63;
+    const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
+    const double h = gs.gp[3], inv_h = gs.gp[4];
+    const int g[3] = {(int)gs.gp[5], (int)gs.gp[6], (int)gs.gp[7]};
+    const double q[3] = {qx, qy, qz};
+    int c[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) c[a] = (q[a] == q[a]) ? cell_of(q[a], b[a], inv_h, g[a]) : 0;
+    ld = DBL_MAX;
+    li = kNoIndex;
+    double tau = DBL_MAX;
+    int rmax = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g[a] - 1 - c[a]));
+    // rounding slack of the cell boundaries (cell_of is evaluated in fp64 on fp32 coordinates)
+    const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
+    for (int r = 0; r <= rmax; ++r) {
+        const int side = 2 * r + 1, nrows = side * side;
+        for (int row0 = 0; row0 < nrows; row0 += 64) {
+            // lane -> one (iy, iz) row of the ring: a full run of cells if the row is on the ring's
+            // y/z faces, else only the two end cells ix = cx -+ r
+            const int j = row0 + lane;
+            int sA = 0, lA = 0, sB = 0, lB = 0;
+            if (j < nrows) {
+                const int dy = j % side - r, dz = j / side - r;
+                const int iy = c[1] + dy, iz = c[2] + dz;
+                if (iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2]) {
+                    const int rowbase = (iz * g[1] + iy) * g[0];
+                    const int x0 = c[0] - r, x1 = c[0] + r;
+                    if (dy == -r || dy == r || dz == -r || dz == r) {
+                        const int a0 = max(x0, 0), a1 = min(x1, g[0] - 1);
+                        if (a0 <= a1) {
+                            sA = gs.cs[rowbase + a0];
+                            lA = gs.cs[rowbase + a1 + 1] - sA;
+                        }
+                    } else {
+                        if (x0 >= 0) {
+                            sA = gs.cs[rowbase + x0];
+                            lA = gs.cs[rowbase + x0 + 1] - sA;
+                        }
+                        if (x1 < g[0] && r > 0) {
+                            sB = gs.cs[rowbase + x1];
+                            lB = gs.cs[rowbase + x1 + 1] - sB;
+                        }
+                    }
+                }
+            }
+            // flatten the <= 128 ranges into one index space so that every lane gets a point
+            int incl = lA + lB;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            const int total = __builtin_amdgcn_readlane(incl, 63);
+            ws->pre[lane] = incl - (lA + lB);
+            ws->sA[lane] = sA; ws->lA[lane] = lA; ws->sB[lane] = sB;
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                const int t = t0 + lane;
+                double d = __builtin_nan("");
+                int ic = kNoIndex;
+                if (t < total) {
+                    int lo = 0, hi = 64;  // largest o with pre[o] <= t
+#pragma unroll
+                    for (int it = 0; it < 6; ++it) {
+                        const int mid = (lo + hi) >> 1;
+                        if (ws->pre[mid] <= t) lo = mid; else hi = mid;
+                    }
+                    const int u = t - ws->pre[lo];
+                    const int la = ws->lA[lo];
+                    const int pos = u < la ? ws->sA[lo] + u : ws->sB[lo] + (u - la);
+                    const float4 p4 = gs.pt[pos];
+                    d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
+                    ic = __float_as_int(p4.w);
+                }
+                unsigned long long m = __ballot(d <= tau);
+                while (m) {  // a lane beats (or ties) the current k-th best
+                    const int src = __ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const double dc = readlane_f64(d, src);
+                    const int icc = __builtin_amdgcn_readlane(ic, src);
+                    // rank of the candidate in (distance, index) order among the kept entries
+                    const bool lt = (lane < k) && (ld < dc || (ld == dc && li < icc));
+                    const int pos = __popcll(__ballot(lt));
+                    if (pos < k && dc < DBL_MAX) {
+                        const double up_d = shfl_up1_f64(ld);
+                        const int up_i = __shfl_up(li, 1);
+                        if (lane > pos) {
+                            ld = up_d;
+                            li = up_i;
+                        } else if (lane == pos) {
+                            ld = dc;
+                            li = icc;
+                        }
+                        tau = readlane_f64(ld, k - 1);
+                    }
+                }
+            }
+        }
+        // everything within Chebyshev radius r of the query's cell has been seen.  A cell outside that box
+        // differs by more than r along some axis, so it lies beyond one of the box's faces; stop when the
+        // k-th best is closer than the nearest face that still has cells behind it.
+        if (tau < DBL_MAX) {
+            double dmin = DBL_MAX;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - r > 0) dmin = fmin(dmin, fmax(0.0, q[a] - (b[a] + (double)(c[a] - r) * h)));
+                if (c[a] + r < g[a] - 1) dmin = fmin(dmin, fmax(0.0, (b[a] + (double)(c[a] + r + 1) * h) - q[a]));
+            }
+            if (dmin == DBL_MAX) break;  // the box covers the whole grid
+            dmin = fmax(0.0, dmin - slack);
+            if (tau < dmin * dmin) break;
+        }
+    }
+}
+
+}  // namespace amk

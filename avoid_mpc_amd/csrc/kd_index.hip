@@ -14,7 +14,7 @@
 // ballot to find the (rare) lanes that beat it and a shuffle-based insertion into a sorted top-k
 // list that lives in lanes 0..k-1.  Only *results* must equal the reference's;
 // the tree shape is free.
-#include "kd_device.h"
+#include "kd_grid.h"
 
 namespace amk {
 thread_local int g_last_hip_error = 0;
@@ -73,7 +73,8 @@ constexpr int kCompactThreads = 1024;
 __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
     const float *__restrict__ xyz, int point_stride, long long scene_stride,
     const int *__restrict__ counts, int max_points, float *__restrict__ X, float *__restrict__ Y,
-    float *__restrict__ Z, int cap, int *__restrict__ size_out, float *__restrict__ pmax_out) {
+    float *__restrict__ Z, int cap, int *__restrict__ size_out, float *__restrict__ pmax_out,
+    float *__restrict__ bbox_out) {
     const int s = blockIdx.x;
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
@@ -84,7 +85,9 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
 
     __shared__ int wave_tot[kCompactThreads / kWave];
     __shared__ float wave_max[kCompactThreads / kWave];
+    __shared__ float wave_bb[6][kCompactThreads / kWave];
     float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
+    float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};  // bbox of the finite points
     int base = 0;
     for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
         const int i = c0 + tid;
@@ -114,6 +117,11 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
             ys[o] = py;
             zs[o] = pz;
             amax = fmaxf(amax, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
+            if (amk::finite3(px, py, pz)) {
+                bmn[0] = fminf(bmn[0], px); bmx[0] = fmaxf(bmx[0], px);
+                bmn[1] = fminf(bmn[1], py); bmx[1] = fmaxf(bmx[1], py);
+                bmn[2] = fminf(bmn[2], pz); bmx[2] = fmaxf(bmx[2], pz);
+            }
         }
         base += tot;
         __syncthreads();
@@ -125,14 +133,30 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
         zs[i] = qnan;
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-    if (lane == 0) wave_max[w] = amax;
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], off));
+            bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], off));
+        }
+    }
+    if (lane == 0) {
+        wave_max[w] = amax;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wave_bb[a][w] = bmn[a]; wave_bb[3 + a][w] = bmx[a]; }
+    }
     __syncthreads();
     if (tid == 0) {
         float m = 0.f;
         for (int j = 0; j < kCompactThreads / kWave; ++j) m = fmaxf(m, wave_max[j]);
         size_out[s] = base;
         pmax_out[s] = m;
+    }
+    if (tid < 6) {
+        float v = wave_bb[tid][0];
+        for (int j = 1; j < kCompactThreads / kWave; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
+        bbox_out[6 * s + tid] = v;
     }
 }
 
@@ -195,6 +219,53 @@ __global__ __launch_bounds__(512) void kd_scan_kernel(
     }
 }
 
+// search over the bucketed index: one wavefront per (scene, query), four queries of a scene per block
+__global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, const float *__restrict__ X,
+                                                             const float *__restrict__ Y,
+                                                             const float *__restrict__ Z,
+                                                             const int *__restrict__ sizes, int n_scenes,
+                                                             const double *__restrict__ queries, int n_queries,
+                                                             int k, int *__restrict__ out_idx,
+                                                             double *__restrict__ out_d2,
+                                                             float *__restrict__ out_pts, int *__restrict__ out_cnt) {
+    __shared__ amk::GridWaveLds wl[4];
+    const int bps = (n_queries + 3) / 4;  // blocks per scene
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / bps) * 8 + xcd;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (j % bps) * 4 + w;
+    if (s >= n_scenes || q >= n_queries) return;
+    const size_t row = (size_t)s * n_queries + q;
+    const double *qp = queries + row * 3;
+    double ld;
+    int li;
+    amk::grid_knn(gpt.scene(s), qp[0], qp[1], qp[2], k, ld, li, &wl[w]);
+    const int size = sizes[s];
+    const int cnt = size < k ? size : (size > k ? k : 0);  // kd_tree_two.h:119-124
+    if (lane == 0 && out_cnt) out_cnt[row] = cnt;
+    if (lane < k) {
+        const bool ok = lane < cnt && li != amk::kNoIndex;
+        const int idx = ok ? li : -1;
+        if (out_idx) out_idx[row * k + lane] = idx;
+        if (out_d2) out_d2[row * k + lane] = ok ? ld : DBL_MAX;
+        if (out_pts) {
+            const size_t base = (size_t)s * gpt.cap;
+            float *o = out_pts + (row * k + lane) * 3;
+            o[0] = ok ? X[base + idx] : 0.f;
+            o[1] = ok ? Y[base + idx] : 0.f;
+            o[2] = ok ? Z[base + idx] : 0.f;
+        }
+    }
+}
+
+// internal (tests / benchmarks): 0 = bucketed index (default), 1 = streaming scan
+extern "C" int amk__kd_set_mode(amk_kd *kd, int mode) {
+    if (!kd) return AMK_ERR_INVALID_ARG;
+    kd->mode = mode;
+    return AMK_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------
@@ -237,7 +308,12 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
         delete kd;
         return amk::hip_fail(e);
     }
-    if ((e = hipMemset(kd->size.p, 0, sizeof(int) * n_scenes)) != hipSuccess) {
+    if ((e = hipMemset(kd->size.p, 0, sizeof(int) * n_scenes)) != hipSuccess ||
+        (e = kd->gpt.alloc(tot)) != hipSuccess || (e = kd->bbox.alloc((size_t)n_scenes * 6)) != hipSuccess ||
+        (e = kd->cell_start.alloc((size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
+        (e = kd->gparams.alloc((size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess ||
+        (e = hipMemset(kd->cell_start.p, 0, sizeof(int) * (size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
+        (e = hipMemset(kd->gparams.p, 0, sizeof(double) * (size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess) {
         delete kd;
         return amk::hip_fail(e);
     }
@@ -254,10 +330,17 @@ int amk_kd_destroy(amk_kd *kd) {
 int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
                  const int *d_counts, void *stream) {
     if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
-    amk::TimedLaunch tl(amk::KC_COMPACT, (hipStream_t)stream);
+    { amk::TimedLaunch tl(amk::KC_COMPACT, (hipStream_t)stream);
     hipLaunchKernelGGL(kd_compact_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
                        point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
-                       kd->size.p, kd->pmax.p);
+                       kd->size.p, kd->pmax.p, kd->bbox.p); }
+    AMK_HIP(hipGetLastError());
+    {
+        amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
+        hipLaunchKernelGGL(amk::kd_grid_build_kernel, dim3(kd->n_scenes), dim3(amk::kGridBuildThreads), 0,
+                           (hipStream_t)stream, kd->x.p, kd->y.p, kd->z.p, kd->cap, kd->size.p, kd->bbox.p, kd->gpt.p,
+                           kd->cell_start.p, kd->gparams.p);
+    }
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }
@@ -273,6 +356,15 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
                   float *d_pts, int *d_counts, void *stream) {
     if (!kd || !d_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
     if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
+    if (kd->mode == 0) {
+        const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap};
+        const int blocks = (kd->n_scenes + 7) / 8 * 8 * ((n_queries + 3) / 4);
+        hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->x.p, kd->y.p,
+                           kd->z.p, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts,
+                           d_counts);
+        AMK_HIP(hipGetLastError());
+        return AMK_OK;
+    }
     int qpw, groups, wpb;
     amk::scan_geometry(n_queries, qpw, groups, wpb);
     const int bps = (groups + wpb - 1) / wpb;

@@ -9,7 +9,7 @@
 //   step_plan_kernel     PlanWapionts: nearest-obstacle test, snap to the edge point, re-query (:259-281)
 //   step_pack_kernel     ProcessWaypoints padding/needReplan, early exit, GetRefStates         (:216-257,333-335)
 //   mpc_solve_kernel     Solve + refill of the reference path                                  (:337-342)
-#include "kd_device.h"
+#include "kd_grid.h"
 #include "mpc_handle.h"
 
 using namespace amk;
@@ -74,8 +74,57 @@ __global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict_
     }
 }
 
+// Same outputs through the bucketed indices (kd_grid.h), both trees in one launch: wavefront q < N answers
+// the K-NN of reference point q in the obstacle index, wavefront q == N the 1-NN of reference point 0 in
+// the edge index (the Edge-KD-tree query of PlanWapionts, :270).
+__global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridPtrs gedge, const float *__restrict__ Xo,
+                                                            const float *__restrict__ Yo,
+                                                            const float *__restrict__ Zo,
+                                                            const float *__restrict__ Xe,
+                                                            const float *__restrict__ Ye,
+                                                            const float *__restrict__ Ze, int n_scenes,
+                                                            const double *__restrict__ ref_path, int N, int K,
+                                                            float *__restrict__ knn_pts, double *__restrict__ knn_d2,
+                                                            float *__restrict__ edge_pt, double *__restrict__ edge_d2,
+                                                            const int *__restrict__ done) {
+    __shared__ GridWaveLds wl[4];
+    const int nq = N + 1;
+    const int bps = (nq + 3) / 4;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / bps) * 8 + xcd;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (j % bps) * 4 + w;
+    if (s >= n_scenes || q >= nq || done[s]) return;
+    const bool is_edge = q == N;
+    const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;  // read in place from mRefPath
+    const int k = is_edge ? 1 : K;
+    double ld;
+    int li;
+    grid_knn(is_edge ? gedge.scene(s) : gobs.scene(s), qp[0], qp[1], qp[2], k, ld, li, &wl[w]);
+    if (lane < k) {
+        const bool ok = li != kNoIndex;
+        if (is_edge) {
+            const size_t base = (size_t)s * gedge.cap;
+            edge_d2[s] = ok ? ld : DBL_MAX;
+            edge_pt[3 * s + 0] = ok ? Xe[base + li] : 0.f;
+            edge_pt[3 * s + 1] = ok ? Ye[base + li] : 0.f;
+            edge_pt[3 * s + 2] = ok ? Ze[base + li] : 0.f;
+        } else {
+            const size_t base = (size_t)s * gobs.cap;
+            const size_t row = (size_t)s * N + q;
+            knn_d2[row * K + lane] = ok ? ld : DBL_MAX;
+            float *o = knn_pts + (row * K + lane) * 3;
+            o[0] = ok ? Xo[base + li] : 0.f;
+            o[1] = ok ? Yo[base + li] : 0.f;
+            o[2] = ok ? Zo[base + li] : 0.f;
+        }
+    }
+}
+
 // PlanWapionts (:259-281) for reference point 0; one wavefront per scene.
-__global__ __launch_bounds__(kWave) void step_plan_kernel(const float *__restrict__ X, const float *__restrict__ Y,
+__global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_grid,
+                                                          const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
                                                           const float *__restrict__ pmax_obs,
@@ -105,13 +154,20 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(const float *__restric
             // the snapped point is what ProcessWaypoints queries next (:210-215): redo query 0
             const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
             __shared__ ScanLds<1> ws1;
+            __shared__ GridWaveLds wl1;
             __shared__ double q1[3];
-            q1[0] = ex; q1[1] = ey; q1[2] = ez;  // every lane stores the same values
-            scan_cloud<1>(xs, ys, zs, size_o, pmax_obs[s], q1, 3, K, &ws1);
+            double gld = DBL_MAX;
+            int gli = kNoIndex;
+            if (use_grid) {
+                grid_knn(gpt.scene(s), ex, ey, ez, K, gld, gli, &wl1);
+            } else {
+                q1[0] = ex; q1[1] = ey; q1[2] = ez;  // every lane stores the same values
+                scan_cloud<1>(xs, ys, zs, size_o, pmax_obs[s], q1, 3, K, &ws1);
+            }
             if (lane < K) {
-                const int li = ws1.li[0][lane];
+                const int li = use_grid ? gli : ws1.li[0][lane];
                 const bool ok = li != kNoIndex;
-                knn_d2[(size_t)s * N * K + lane] = ok ? ws1.ld[0][lane] : DBL_MAX;
+                knn_d2[(size_t)s * N * K + lane] = ok ? (use_grid ? gld : ws1.ld[0][lane]) : DBL_MAX;
                 float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
                 o[0] = ok ? xs[li] : 0.f;
                 o[1] = ok ? ys[li] : 0.f;
@@ -199,7 +255,16 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     scan_geometry(N, qpw, groups, wpb);
     const int bps = (groups + wpb - 1) / wpb;
     const int S8 = (S + 7) / 8 * 8;
+    const int use_grid = (obstacle->mode == 0 && edge->mode == 0) ? 1 : 0;
+    const GridPtrs gobs{obstacle->gpt.p, obstacle->cell_start.p, obstacle->gparams.p, obstacle->cap};
+    const GridPtrs gedge{edge->gpt.p, edge->cell_start.p, edge->gparams.p, edge->cap};
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
+        if (use_grid) {
+            TimedLaunch tl(KC_SCAN_OBS, stream);
+            hipLaunchKernelGGL(step_knn_grid_kernel, dim3(S8 * ((N + 4) / 4)), dim3(256), 0, stream, gobs, gedge,
+                               obstacle->x.p, obstacle->y.p, obstacle->z.p, edge->x.p, edge->y.p, edge->z.p, S, d_ref_path,
+                               N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p);
+        } else {
         { TimedLaunch tl(KC_SCAN_OBS, stream);
         hipLaunchKernelGGL(step_scan_kernel<5>, dim3(S8 * bps), dim3(wpb * kWave), scan_lds_bytes<5>(wpb), stream,
                            obstacle->x.p, obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p,
@@ -208,8 +273,9 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
         hipLaunchKernelGGL(step_scan_kernel<1>, dim3(S8), dim3(kWave), scan_lds_bytes<1>(1), stream, edge->x.p,
                            edge->y.p, edge->z.p, edge->cap, edge->size.p, edge->pmax.p, S, d_ref_path, N, 1, 1,
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
+        }
         { TimedLaunch tl(KC_PLAN, stream);
-        hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->x.p, obstacle->y.p,
+        hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, obstacle->x.p, obstacle->y.p,
                            obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N, K,
                            prm->safety_distance,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p,

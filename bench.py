@@ -23,7 +23,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-KCLASS = ["kd_compact", "scan_obstacle", "scan_edge", "plan", "pack", "mpc_solve", "begin"]
+KCLASS = ["kd_compact", "knn_obstacle", "knn_edge", "plan", "pack", "mpc_solve", "begin", "kd_grid_build"]
 
 
 def alg_bytes_per_step(n, ne, N, K):
@@ -220,7 +220,7 @@ def main():
         lib.amk__timing_enable(0)
         reps = max(3, args.steps // 4)
         breakdown = {KCLASS[i]: {"ms_per_step": round(ms2[i] / reps, 4), "launches_per_step": cnt2[i] / reps}
-                     for i in range(7)}
+                     for i in range(8)}
 
     if rank == 0:
         total_scenes = S * world * args.steps

@@ -20,8 +20,20 @@ def torch_cuda():
     return torch
 
 
+MODES = {"grid": 0, "scan": 1}      # bucketed index (default product path) / streaming scan (cross-check)
+MODE = ["grid"]
+
+
+@pytest.fixture(autouse=True, params=["grid", "scan"])
+def search_mode(request):
+    MODE[0] = request.param
+    yield
+    MODE[0] = "grid"
+
+
 def _gpu_search(torch, clouds, queries, k, counts=None, stride=3):
     """clouds: list of [n_i,3] float32 -> batched device search; returns host arrays."""
+    from avoid_mpc_amd import capi
     from avoid_mpc_amd.host import KdBatch
     S = len(clouds)
     nmax = max(max(len(c) for c in clouds), 1)
@@ -31,6 +43,7 @@ def _gpu_search(torch, clouds, queries, k, counts=None, stride=3):
         buf[s, :len(c), :3] = c
         cnt[s] = len(c)
     kd = KdBatch(S, nmax)
+    capi.load().amk__kd_set_mode(kd.h, MODES[MODE[0]])
     kd.build(torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda())
     out = kd.search(torch.from_numpy(np.ascontiguousarray(queries, np.float64)).cuda(), k)
     torch.cuda.synchronize()
@@ -143,6 +156,8 @@ def test_single_query_and_host_api(torch_cuda, oracle):
     cloud = synth.make_cloud(5000, 77)[0]
     t = _oracle.kd_oracle(cloud)
     kd = KdBatch(1, 5000)
+    from avoid_mpc_amd import capi
+    capi.load().amk__kd_set_mode(kd.h, MODES[MODE[0]])
     kd.build_host(cloud[None])
     rng = np.random.default_rng(8)
     for Q, k in ((1, 1), (1, 8), (3, 3), (30, 10), (64, 64)):
