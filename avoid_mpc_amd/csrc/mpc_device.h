@@ -72,13 +72,15 @@ struct LdsMap {
         auto take = [&](int n) { int b = o; o += (n + 1) & ~1; return b; };
         prm = take(PRM_LEN); xinit = take(SD); target = take(SD); cy = take(N); sy = take(N);
         X = take((N + 1) * SD); U = take(N * UD); zl = take(N * UD); zu = take(N * UD);
-        dX = take((N + 1) * SD); dU = take(N * UD); dzl = take(N * UD); dzu = take(N * UD);
-        Xt = take((N + 1) * SD); Ut = take(N * UD);
+        dX = take((N + 1) * SD); dU = take(N * UD);
         q = take((N + 1) * SD); r = take(N * UD); rb = take(N * UD); Rb = take(N * UD); gU = take(N * UD);
-        H6 = take(N * 36); rotQ = take(N * 6);
+        // buffers with disjoint lifetimes share storage: the derivative blocks q, r, r_bar, R_bar are dead once
+        // the backward sweep has run; the dual steps and the line-search trial point are born after it
+        Xt = q; Ut = rb; dzl = Rb; dzu = r;
+        H6 = take(N * 21); rotQ = take(N * 6);
         P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
-        Atp = take(SD); Atl = take(SD); qu = take(UD); Y = take(44); Z = take(44); D = take(UD + 6 + 2);
-        Kk = take(N * 44); red = take(64);
+        Atp = take(SD); Atl = take(SD); qu = take(UD); Y = 0; Z = 0; D = 0;
+        Kk = take(N * 44); red = take(16);
         total = o;
     }
 };
@@ -254,15 +256,9 @@ __device__ __forceinline__ double evaluate(double *sm, const LdsMap &L, const Sc
         if (j == 0 && k < N - 1) {
             Jloc += c;
             if (DERIV) {
-                double *h6 = sm + L.H6 + k * 36;
+                double *h6 = sm + L.H6 + k * 21;  // lower triangle, row-major
 #pragma unroll
-                for (int i = 0; i < 6; ++i)
-#pragma unroll
-                    for (int jj = 0; jj <= i; ++jj) {
-                        const double h = H[i * (i + 1) / 2 + jj];
-                        h6[i * 6 + jj] = h;
-                        h6[jj * 6 + i] = h;
-                    }
+                for (int e = 0; e < 21; ++e) h6[e] = H[e];
                 double *qk = sm + L.q + (k + 1) * SD;  // collision part; the stage lane adds the rest
 #pragma unroll
                 for (int i = 0; i < 6; ++i) qk[pv_of(i)] = g6[i];
@@ -347,7 +343,7 @@ __device__ __forceinline__ double q_elem(const double *sm, const LdsMap &L, int 
         v = 2.0 * prm[PRM_W + 10 + i];
     }
     const int pi = pv_inv(i), pj = pv_inv(j);
-    if (pi >= 0 && pj >= 0) v += sm[L.H6 + st * 36 + pi * 6 + pj];
+    if (pi >= 0 && pj >= 0) v += sm[L.H6 + st * 21 + (pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi)];
     return v;
 }
 
@@ -404,7 +400,7 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
         if (bi >= 0 && bi == bj) lp.rot_off = bi * 3 + ((i == 1 || i == 5) ? 1 : 0) + ((j == 1 || j == 5) ? 1 : 0);
         else if (i == j) lp.qdiag = 2.0 * prm[PRM_W + 10 + i];
         const int pi = pv_inv(i), pj = pv_inv(j);
-        if (pi >= 0 && pj >= 0) lp.h6_off = pi * 6 + pj;
+        if (pi >= 0 && pj >= 0) lp.h6_off = pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi;
     }
 }
 
@@ -418,8 +414,13 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
 // control block is not positive definite.  Gains go to L.Kk ([k][a*11 + j], column 10 = feed-forward).
-__device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, const LanePlan &lp, int N, double delta) {
+__device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, const double *plan_coef,
+                                                 const int *plan_meta, int N, double delta) {
     const int lane = threadIdx.x;
+    // the lane's plan is (re)loaded per sweep -- 44 L2-resident words -- instead of being held for the whole
+    // solve: it is dead weight (60 VGPRs) during the objective evaluation, which sets the register peak
+    LanePlan lp;
+    load_lane_plan(lp, plan_coef, plan_meta, sm + L.prm);
     double *P = sm + L.P, *pv = sm + L.p, *lam = sm + L.lam;
     // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
     for (int e = lane; e < 100; e += 64) {
@@ -431,6 +432,7 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
         lam[lane] = pv[lane];
     }
     __syncthreads();
+#pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
         // ---- round A: the two plan items of this lane
 #pragma unroll
@@ -438,9 +440,11 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
             double v[PLAN_TERMS];
 #pragma unroll
             for (int t = 0; t < PLAN_TERMS; ++t) v[t] = sm[lp.idx[h][t]];
-            double acc = 0.0;
-#pragma unroll
-            for (int t = 0; t < PLAN_TERMS; ++t) acc = fma(lp.coef[h][t], v[t], acc);
+            // three partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
+            double a0 = lp.coef[h][0] * v[0], a1 = lp.coef[h][1] * v[1], a2 = lp.coef[h][2] * v[2];
+            a0 = fma(lp.coef[h][3], v[3], a0); a1 = fma(lp.coef[h][4], v[4], a1); a2 = fma(lp.coef[h][5], v[5], a2);
+            a0 = fma(lp.coef[h][6], v[6], a0); a1 = fma(lp.coef[h][7], v[7], a1); a2 = fma(lp.coef[h][8], v[8], a2);
+            double acc = (a0 + a1) + a2;
             if (lp.aux[h] >= 0) acc += sm[lp.aux[h] + 4 * k];
             if (lp.aux_delta[h]) acc += delta;
             sm[lp.out[h] + k * lp.out_kstride[h]] = acc;
@@ -502,7 +506,7 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
                 const int j = lp.cj, st = k - 1;
                 double qe = lp.qdiag + (i == j ? delta : 0.0);
                 if (lp.rot_off >= 0) qe += sm[L.rotQ + st * 6 + lp.rot_off];
-                if (lp.h6_off >= 0) qe += sm[L.H6 + st * 36 + lp.h6_off];
+                if (lp.h6_off >= 0) qe += sm[L.H6 + st * 21 + lp.h6_off];
                 const double val = qe + sm[L.M + lane] - ww;
                 P[i * 10 + j] = val;
                 P[j * 10 + i] = val;
@@ -540,6 +544,7 @@ __device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int
     const int a = lane < UD ? lane : 0;
     double dx = 0.0;  // dX_k[lane]
     if (lane < SD) sm[L.dX + lane] = 0.0;
+#pragma unroll 1
     for (int k = 0; k < N; ++k) {
         const double *kk = sm + L.Kk + k * 44 + a * 11;
         double krow[SD + 1];
@@ -584,8 +589,6 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
     }
     __syncthreads();
     const double *prm = sm + L.prm;
-    LanePlan lp;
-    load_lane_plan(lp, plan_coef, plan_meta, prm);
     for (int e = lane; e < 56 + 10 + 40; e += 64) sm[L.M + e] = 0.0;  // structurally-zero outputs stay zero
     if (lane < N - 1) {  // constant part of Q on the rotated (px,py) and (vx,vy) blocks
         const double cy = sm[L.cy + lane], sy = sm[L.sy + lane];
@@ -630,6 +633,7 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
     double delta_last = 0.0, a_last = 0.0;
     int status = 1, n_reg = 0, ls_fail = 0, it = 0;
     const int nvar = UD * N;
+#pragma unroll 1
     for (it = 0; it < opt.max_iter; ++it) {
         const long long t0 = AMK_CLK();
         long long tclk[3] = {0, 0, 0};
@@ -648,14 +652,14 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
         __syncthreads();
         double delta = 0.0;
         int reg_now = 0;
-        bool ok = riccati_backward(sm, L, lp, N, delta);
+        bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
         while (!ok) {
             __syncthreads();
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1e-4 : fmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
             ++reg_now;
             if (delta > 1e40) break;
-            ok = riccati_backward(sm, L, lp, N, delta);
+            ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
         }
         if (!ok) { status = 2; break; }
         // KKT error E_0 at the current iterate (gU from the adjoint sweep inside the backward pass)

@@ -217,6 +217,19 @@ int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_
 }
 }  // namespace amk
 
+// internal: resident solve blocks per CU as the runtime computes it (diagnostics)
+extern "C" int amk__solve_occupancy(amk_mpc *m) {
+    int nb = -1;
+    const void *f = m->N == 10 ? (const void *)mpc_solve_kernel<10> : m->N == 20 ? (const void *)mpc_solve_kernel<20>
+                  : m->N == 30 ? (const void *)mpc_solve_kernel<30> : (const void *)mpc_solve_kernel<0>;
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, f) == hipSuccess)
+        printf("solve kernel N=%d: numRegs %d, sharedSizeBytes %zu, localSizeBytes %zu, maxDynamicShared %d, lds request %zu\n", m->N,
+               fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fa.maxDynamicSharedSizeBytes, m->lds_bytes);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 64, m->lds_bytes) != hipSuccess) return -2;
+    return nb;
+}
+
 extern "C" {
 
 int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out) {
