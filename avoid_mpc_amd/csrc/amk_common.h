@@ -86,6 +86,8 @@ struct amk_kd {
     amk::DevBuf<int> cell_start;     // [S][kGridMaxCells + 2]
     amk::DevBuf<double> gparams;     // [S][8]
     int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
+    amk::DevBuf<unsigned char> flags; // [S][cap] keyframe sweep: 1 = outlier
+    amk::DevBuf<int> sweep_cnt;       // [S][2]   {outliers, rebuilt}
     // staging for the *_host conveniences
     amk::DevBuf<float> stage_xyz;
     amk::DevBuf<int> stage_counts;

@@ -286,4 +286,66 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     }
 }
 
+// 1-NN squared distance of q, one THREAD per query (the n-queries-on-n-points keyframe sweep,
+// AM/src/FrameKDMap.cpp:466-476): same ring walk and stopping rule as grid_knn with k = 1, scalar per lane.
+// Returns DBL_MAX when the index holds no point with a finite distance to q.
+__device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx, double qy, double qz) {
+    const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
+    const double h = gs.gp[3], inv_h = gs.gp[4];
+    const int g[3] = {(int)gs.gp[5], (int)gs.gp[6], (int)gs.gp[7]};
+    const double q[3] = {qx, qy, qz};
+    if (!(qx == qx && qy == qy && qz == qz)) return DBL_MAX;
+    int c[3], rmax = 0;
+    for (int a = 0; a < 3; ++a) {
+        c[a] = cell_of(q[a], b[a], inv_h, g[a]);
+        rmax = max(rmax, max(c[a], g[a] - 1 - c[a]));
+    }
+    const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
+    double best = DBL_MAX;
+    for (int r = 0; r <= rmax; ++r) {
+        for (int dz = -r; dz <= r; ++dz) {
+            const int iz = c[2] + dz;
+            if (iz < 0 || iz >= g[2]) continue;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int iy = c[1] + dy;
+                if (iy < 0 || iy >= g[1]) continue;
+                const int rowbase = (iz * g[1] + iy) * g[0];
+                const bool face = (dy == -r || dy == r || dz == -r || dz == r);
+                const int x0 = c[0] - r, x1 = c[0] + r;
+                for (int part = 0; part < 2; ++part) {
+                    int s0, s1;
+                    if (face) {
+                        if (part == 1) break;
+                        const int a0 = max(x0, 0), a1 = min(x1, g[0] - 1);
+                        if (a0 > a1) break;
+                        s0 = gs.cs[rowbase + a0];
+                        s1 = gs.cs[rowbase + a1 + 1];
+                    } else {
+                        const int ix = part == 0 ? x0 : x1;
+                        if (ix < 0 || ix >= g[0] || (part == 1 && r == 0)) continue;
+                        s0 = gs.cs[rowbase + ix];
+                        s1 = gs.cs[rowbase + ix + 1];
+                    }
+                    for (int pos = s0; pos < s1; ++pos) {
+                        const float4 p4 = gs.pt[pos];
+                        const double d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
+                        best = d < best ? d : best;
+                    }
+                }
+            }
+        }
+        if (best < DBL_MAX) {
+            double dmin = DBL_MAX;
+            for (int a = 0; a < 3; ++a) {
+                if (c[a] - r > 0) dmin = fmin(dmin, fmax(0.0, q[a] - (b[a] + (double)(c[a] - r) * h)));
+                if (c[a] + r < g[a] - 1) dmin = fmin(dmin, fmax(0.0, (b[a] + (double)(c[a] + r + 1) * h) - q[a]));
+            }
+            if (dmin == DBL_MAX) break;
+            dmin = fmax(0.0, dmin - slack);
+            if (best < dmin * dmin) break;
+        }
+    }
+    return best;
+}
+
 }  // namespace amk

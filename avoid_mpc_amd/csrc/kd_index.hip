@@ -259,6 +259,184 @@ __global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// keyframe sweep (FrameKDMap::KeyframeThreadWorker, AM/src/FrameKDMap.cpp:462-485)
+// ------------------------------------------------------------------------------------------------
+// one thread per keyframe point: outlier iff its nearest neighbour in the current frame is farther than th
+__global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
+                                                            const float *__restrict__ KX, const float *__restrict__ KY,
+                                                            const float *__restrict__ KZ, int kcap,
+                                                            const int *__restrict__ ksizes, double th_dist,
+                                                            unsigned char *__restrict__ flags) {
+    const int s = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = ksizes[s];
+    if (i >= n) return;
+    const size_t o = (size_t)s * kcap + i;
+    unsigned char f = 0;
+    if (cur_sizes[s] > 1) {  // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
+        const double d2 = amk::grid_nn1_thread(cur.scene(s), (double)KX[o], (double)KY[o], (double)KZ[o]);
+        if (d2 < DBL_MAX && sqrt(d2) > th_dist) f = 1;
+    }
+    flags[o] = f;
+}
+
+// one block per scene: count the outliers; with >= th_count of them compact the keyframe's planes in place
+// (order preserved: the write cursor never passes the read cursor) and refresh size / bbox / max|coordinate|
+__global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
+    float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Z, int cap, int *__restrict__ sizes,
+    float *__restrict__ pmax_out, float *__restrict__ bbox_out, const unsigned char *__restrict__ flags, int th_count,
+    int *__restrict__ sweep_cnt, int *__restrict__ out_outliers, int *__restrict__ out_rebuilt) {
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
+    const unsigned char *fl = flags + (size_t)s * cap;
+    const int n = sizes[s];
+    __shared__ int wave_tot[kCompactThreads / kWave];
+    __shared__ float wave_max[kCompactThreads / kWave];
+    __shared__ float wave_bb[6][kCompactThreads / kWave];
+    __shared__ int total_sh;
+    int cnt = 0;
+    for (int i = tid; i < n; i += kCompactThreads) cnt += fl[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
+    if (lane == 0) wave_tot[w] = cnt;
+    __syncthreads();
+    if (tid == 0) {
+        int t = 0;
+        for (int j = 0; j < kCompactThreads / kWave; ++j) t += wave_tot[j];
+        total_sh = t;
+    }
+    __syncthreads();
+    const int total = total_sh;
+    const int rebuilt = total >= th_count ? 1 : 0;  // :477-479
+    if (tid == 0) {
+        sweep_cnt[2 * s] = total;
+        sweep_cnt[2 * s + 1] = rebuilt;
+        if (out_outliers) out_outliers[s] = total;
+        if (out_rebuilt) out_rebuilt[s] = rebuilt;
+    }
+    if (!rebuilt) return;
+    float amax = 0.f, bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    int base = 0;
+    for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
+        const int i = c0 + tid;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        bool valid = false;
+        if (i < n) {
+            px = xs[i]; py = ys[i]; pz = zs[i];
+            valid = fl[i] != 0;
+        }
+        const unsigned long long m = __ballot(valid);
+        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
+        __syncthreads();  // every read of this chunk is done before anybody writes (in-place)
+        if (lane == 0) wave_tot[w] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < kCompactThreads / kWave; ++j) {
+            const int t = wave_tot[j];
+            woff += (j < w) ? t : 0;
+            tot += t;
+        }
+        if (valid) {
+            const int o = base + woff + prefix;
+            xs[o] = px; ys[o] = py; zs[o] = pz;
+            amax = fmaxf(amax, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
+            if (amk::finite3(px, py, pz)) {
+                bmn[0] = fminf(bmn[0], px); bmx[0] = fmaxf(bmx[0], px);
+                bmn[1] = fminf(bmn[1], py); bmx[1] = fmaxf(bmx[1], py);
+                bmn[2] = fminf(bmn[2], pz); bmx[2] = fmaxf(bmx[2], pz);
+            }
+        }
+        base += tot;
+        __syncthreads();
+    }
+    const float qnan = __builtin_nanf("");
+    for (int i = base + tid; i < n + 1024 && i < cap; i += kCompactThreads) { xs[i] = qnan; ys[i] = qnan; zs[i] = qnan; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        amax = fmaxf(amax, __shfl_xor(amax, off));
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], off));
+            bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], off));
+        }
+    }
+    if (lane == 0) {
+        wave_max[w] = amax;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { wave_bb[a][w] = bmn[a]; wave_bb[3 + a][w] = bmx[a]; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float m = 0.f;
+        for (int j = 0; j < kCompactThreads / kWave; ++j) m = fmaxf(m, wave_max[j]);
+        sizes[s] = base;
+        pmax_out[s] = m;
+    }
+    if (tid < 6) {
+        float v = wave_bb[tid][0];
+        for (int j = 1; j < kCompactThreads / kWave; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
+        bbox_out[6 * s + tid] = v;
+    }
+}
+
+extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double th_dist, int th_count, int *d_outliers,
+                                     int *d_rebuilt, void *stream_) {
+    if (!keyframe || !current || keyframe == current || keyframe->n_scenes != current->n_scenes) return AMK_ERR_INVALID_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int S = keyframe->n_scenes;
+    if (!keyframe->flags.p) {
+        AMK_HIP(keyframe->flags.alloc((size_t)S * keyframe->cap));
+        AMK_HIP(keyframe->sweep_cnt.alloc((size_t)S * 2));
+    }
+    const amk::GridPtrs cur{current->gpt.p, current->cell_start.p, current->gparams.p, current->cap};
+    if (keyframe->max_points > 0) {
+        hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((keyframe->max_points + 255) / 256, S), dim3(256), 0, stream, cur,
+                           current->size.p, keyframe->x.p, keyframe->y.p, keyframe->z.p, keyframe->cap, keyframe->size.p,
+                           th_dist, keyframe->flags.p);
+    }
+    hipLaunchKernelGGL(kd_sweep_compact_kernel, dim3(S), dim3(kCompactThreads), 0, stream, keyframe->x.p, keyframe->y.p,
+                       keyframe->z.p, keyframe->cap, keyframe->size.p, keyframe->pmax.p, keyframe->bbox.p, keyframe->flags.p,
+                       th_count, keyframe->sweep_cnt.p, d_outliers, d_rebuilt);
+    // the bucketed index of every scene is rebuilt (a no-op in effect for the untouched ones)
+    hipLaunchKernelGGL(amk::kd_grid_build_kernel, dim3(S), dim3(amk::kGridBuildThreads), 0, stream, keyframe->x.p,
+                       keyframe->y.p, keyframe->z.p, keyframe->cap, keyframe->size.p, keyframe->bbox.p, keyframe->gpt.p,
+                       keyframe->cell_start.p, keyframe->gparams.p);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+extern "C" int amk_kd_keyframe_sweep_host(amk_kd *keyframe, amk_kd *current, double th_dist, int th_count,
+                                          int *h_outliers, int *h_rebuilt) {
+    int st = amk_kd_keyframe_sweep(keyframe, current, th_dist, th_count, nullptr, nullptr, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    std::vector<int> tmp((size_t)keyframe->n_scenes * 2);
+    AMK_HIP(hipMemcpy(tmp.data(), keyframe->sweep_cnt.p, sizeof(int) * tmp.size(), hipMemcpyDeviceToHost));
+    for (int s = 0; s < keyframe->n_scenes; ++s) {
+        if (h_outliers) h_outliers[s] = tmp[2 * s];
+        if (h_rebuilt) h_rebuilt[s] = tmp[2 * s + 1];
+    }
+    return AMK_OK;
+}
+
+extern "C" int amk_kd_points_host(amk_kd *kd, float *h_xyz, int *h_sizes) {
+    if (!kd || !h_xyz || !h_sizes) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h_sizes, kd->size.p, sizeof(int) * kd->n_scenes, hipMemcpyDeviceToHost));
+    std::vector<float> plane((size_t)kd->cap);
+    for (int s = 0; s < kd->n_scenes; ++s) {
+        const int n = h_sizes[s];
+        const float *src[3] = {kd->x.p, kd->y.p, kd->z.p};
+        for (int c = 0; c < 3; ++c) {
+            if (n > 0) AMK_HIP(hipMemcpy(plane.data(), src[c] + (size_t)s * kd->cap, sizeof(float) * n, hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i) h_xyz[((size_t)s * kd->max_points + i) * 3 + c] = plane[i];
+        }
+    }
+    return AMK_OK;
+}
+
 // internal (tests / benchmarks): 0 = bucketed index (default), 1 = streaming scan
 extern "C" int amk__kd_set_mode(amk_kd *kd, int mode) {
     if (!kd) return AMK_ERR_INVALID_ARG;

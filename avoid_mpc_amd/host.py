@@ -68,6 +68,16 @@ class KdBatch:
                                           capi.dptr(out["counts"]), capi.stream_ptr(stream)), "amk_kd_search")
         return out
 
+    def keyframe_sweep(self, current, th_dist, th_count, stream=None):
+        """KeyframeThreadWorker's sweep: self = last keyframe, rebuilt from its outliers w.r.t. `current`.
+        -> (outliers int32 [S], rebuilt int32 [S]) device tensors"""
+        dev = _dev()
+        outl = torch.empty(self.S, dtype=torch.int32, device=dev)
+        reb = torch.empty(self.S, dtype=torch.int32, device=dev)
+        capi.check(self.lib.amk_kd_keyframe_sweep(self.h, current.h, float(th_dist), int(th_count), capi.dptr(outl),
+                                                  capi.dptr(reb), capi.stream_ptr(stream)), "amk_kd_keyframe_sweep")
+        return outl, reb
+
     # host-buffer conveniences ---------------------------------------------------------------
     def build_host(self, xyz, counts=None):
         xyz = np.ascontiguousarray(xyz, np.float32)

@@ -78,6 +78,24 @@ int amk_kd_sizes(amk_kd *kd, int *h_sizes, void *stream);
 int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int *d_indices,
                   double *d_sqdist, float *d_pts, int *d_counts, void *stream);
 
+/* Keyframe sweep of FrameKDMap::KeyframeThreadWorker (AM/src/FrameKDMap.cpp:462-485), for every scene:
+ * for each point of `keyframe` the nearest-neighbour distance in `current` (SearchForNearest(pt, 1));
+ * points with sqrt(d2) > th_dist are outliers (a point gets no result, hence is no outlier, when `current`
+ * holds <= 1 point, kd_tree_two.h:119-124).  A scene with >= th_count outliers has its `keyframe` rebuilt
+ * from them (InitializeNew(newCloud), order preserved) and d_rebuilt[s] = 1; otherwise `keyframe` is left
+ * untouched and d_rebuilt[s] = 0.  d_outliers[s] = number of outliers (either may be NULL).
+ * Both handles must hold the same number of scenes.                                               */
+int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double th_dist, int th_count,
+                          int *d_outliers, int *d_rebuilt, void *stream);
+
+/* Same, synchronising, with the per-scene results in host memory.                                 */
+int amk_kd_keyframe_sweep_host(amk_kd *keyframe, amk_kd *current, double th_dist, int th_count,
+                               int *h_outliers, int *h_rebuilt);
+
+/* GetPointCloud().pts (kd_tree_two.h:134-136): the handle's copy of the cloud (points whose x is not NaN,
+ * in order) as packed xyz, h_xyz[s*max_points*3 + i*3 + c], and the per-scene sizes.  Synchronises.  */
+int amk_kd_points_host(amk_kd *kd, float *h_xyz, int *h_sizes);
+
 /* Host-buffer conveniences (stage through internal device buffers, synchronise).                 */
 int amk_kd_build_host(amk_kd *kd, const float *h_xyz, int point_stride, long long scene_stride,
                       const int *h_counts);

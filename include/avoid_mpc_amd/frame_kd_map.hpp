@@ -112,6 +112,44 @@ public:
         }
     }
 
+    // One pass of KeyframeThreadWorker's body (:443-486) -- the caller owns the 30 ms cadence and the
+    // "new frame arrived" flag.  dronePos / bodyX: translation of Twb = Twc * Tbc^-1 and the world
+    // direction of the body x axis (first column of Rwb), what DroneBehindPts (:233-252) derives.
+    // The n x 1-NN sweep and the rebuild run on the GPU (amk_kd_keyframe_sweep).
+    void KeyframeUpdate(const Vector3d &dronePos, const Vector3d &bodyX, double depthMin, double keyframeThDist,
+                        int keyframeThCount, int maxFrameCount) {
+        std::lock_guard<std::mutex> lock(mMtxKdTree);
+        if (!mCurFrame.pointCloud) return;
+        if (mKeyFrameMap.empty()) {  // :446-449
+            mKeyFrameMap.push_back(mCurFrame);
+            UpdateQueryVector();
+            return;
+        }
+        while (!mKeyFrameMap.empty()) {  // :450-459
+            Frame &oldest = mKeyFrameMap.front();
+            if ((int)mKeyFrameMap.size() > maxFrameCount || !DroneBehindPts(dronePos, bodyX, depthMin, oldest)) {
+                oldest.pointCloud->Clear();
+                mKeyFrameMap.pop_front();
+                UpdateQueryVector();
+            } else {
+                break;
+            }
+        }
+        if (mKeyFrameMap.empty()) return;
+        PtCloudKdPtr last = mKeyFrameMap.back().pointCloud;
+        if (last == mCurFrame.pointCloud) return;  // the reference would sweep a tree against itself: no outliers
+        int outliers = 0, rebuilt = 0;
+        amk_throw(amk_kd_keyframe_sweep_host(last->handle(), mCurFrame.pointCloud->handle(), keyframeThDist,
+                                             keyframeThCount, &outliers, &rebuilt), "amk_kd_keyframe_sweep_host");
+        mLastSweepOutliers = outliers;
+        if (!rebuilt) return;  // :477-479
+        last->SyncFromDevice();  // :480-485 rebuilt the tree from the outliers
+        mKeyFrameMap.push_back(mCurFrame);  // InsertKeyFrame :486
+        UpdateQueryVector();
+    }
+    int LastSweepOutliers() const { return mLastSweepOutliers; }
+    size_t KeyFrameCount() const { return mKeyFrameMap.size(); }
+
     double GetNearestDistance(const Vector3d &point) {  // :400-427
         double nearestDistance = DBL_MAX;
         std::lock_guard<std::mutex> lock(mMtxKdTree);
@@ -126,6 +164,16 @@ public:
     }
 
 private:
+    bool DroneBehindPts(const Vector3d &twb, const Vector3d &bodyX, double depthMin, const Frame &frame) {  // :233-252
+        const int ptsCount = std::min((int)frame.pointCloud->GetPointCloud().pts.size(), 10);
+        frame.pointCloud->SearchForNearest(vx(twb), vy(twb), vz(twb), ptsCount);
+        for (const auto &pt : frame.pointCloud->closest_pts) {
+            const double ptbx = vx(bodyX) * (pt.x - vx(twb)) + vy(bodyX) * (pt.y - vy(twb)) + vz(bodyX) * (pt.z - vz(twb));
+            if (ptbx <= depthMin) return false;
+        }
+        return true;
+    }
+    int mLastSweepOutliers = 0;
     void UpdateQueryVector() {  // :64-74: current frame + all key frames but the newest
         mVecQueryVector.clear();
         mVecQueryVector.push_back(mCurFrame);

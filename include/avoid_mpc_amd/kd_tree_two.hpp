@@ -90,6 +90,15 @@ public:
     PointCloudTwo<num_t> const &GetPointCloud() { return cloud; }
     std::vector<int> const &GetColors() { return colors; }
     amk_kd *handle() { return kd_; }  // for batched / fused use through the C ABI
+    // after a device-side rebuild (amk_kd_keyframe_sweep): refresh the host copy behind GetPointCloud()
+    void SyncFromDevice() {
+        if (!kd_) return;
+        std::vector<float> xyz((size_t)capacity_ * 3);
+        int n = 0;
+        amk_throw(amk_kd_points_host(kd_, xyz.data(), &n), "amk_kd_points_host");
+        cloud.pts.resize(n);
+        for (int i = 0; i < n; ++i) cloud.pts[i] = PointXYZ(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    }
 
 private:
     void Rebuild() {

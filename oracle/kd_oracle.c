@@ -372,3 +372,36 @@ int kdo_bruteforce(void *h, double x, double y, double z, int k, int *indices, d
     free(rd);
     return cnt;
 }
+
+/* Keyframe sweep, FrameKDMap::KeyframeThreadWorker (AM/src/FrameKDMap.cpp:462-485): for every point of the
+ * last keyframe a SearchForNearest(pt, 1) in the current frame's tree; outlier when a result exists and
+ * sqrt(d2) > th_dist (:468-475); with fewer than th_count outliers nothing happens (:477-479), else the
+ * keyframe's tree is rebuilt from the outliers in their original order (:480-485).
+ * Returns 1 when rebuilt; *n_outliers = number of outliers. */
+int kdo_keyframe_sweep(void *keyframe, void *current, double th_dist, int th_count, int *n_outliers) {
+    kdo_tree *kf = (kdo_tree *)keyframe;
+    int *out = (int *)malloc(sizeof(int) * (size_t)(kf->n > 0 ? kf->n : 1));
+    int m = 0;
+    for (uint32_t i = 0; i < kf->n; ++i) {
+        int idx[1];
+        double d2[1];
+        float pf[3];
+        int cnt = kdo_search(current, kf->pts[3 * (size_t)i], kf->pts[3 * (size_t)i + 1], kf->pts[3 * (size_t)i + 2], 1, idx,
+                             d2, pf);
+        if (cnt > 0 && sqrt(d2[0]) > th_dist) out[m++] = (int)i;
+    }
+    if (n_outliers) *n_outliers = m;
+    if (m < th_count) {
+        free(out);
+        return 0;
+    }
+    for (int j = 0; j < m; ++j) { /* out[j] >= j: forward in-place copy is safe */
+        kf->pts[3 * (size_t)j + 0] = kf->pts[3 * (size_t)out[j] + 0];
+        kf->pts[3 * (size_t)j + 1] = kf->pts[3 * (size_t)out[j] + 1];
+        kf->pts[3 * (size_t)j + 2] = kf->pts[3 * (size_t)out[j] + 2];
+    }
+    kf->n = (uint32_t)m;
+    build_index(kf);
+    free(out);
+    return 1;
+}

@@ -60,6 +60,12 @@ class KdHandle:
         cnt = self.lib.kdo_bruteforce(self.h, q[0], q[1], q[2], k, idx, d2)
         return idx[:cnt].copy(), d2[:cnt].copy()
 
+    def keyframe_sweep(self, current, th_dist, th_count):
+        """self = last keyframe's tree (kdo only).  -> (rebuilt, n_outliers)"""
+        n = C.c_int(0)
+        r = self.lib.kdo_keyframe_sweep(self.h, current.h, th_dist, th_count, C.byref(n))
+        return r, n.value
+
     def rebuild(self, reps):
         getattr(self.lib, self.p + "_rebuild")(self.h, reps)
 
@@ -100,6 +106,8 @@ def load_oracle():
         _decl_kd(lib, "kdo")
         lib.kdo_bruteforce.restype = C.c_int
         lib.kdo_bruteforce.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, _i32p, _f64p]
+        lib.kdo_keyframe_sweep.restype = C.c_int
+        lib.kdo_keyframe_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.POINTER(C.c_int)]
         if hasattr(lib, "mpco_p_len"):
             _decl_mpc(lib)
         _ORACLE = lib

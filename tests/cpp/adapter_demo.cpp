@@ -105,6 +105,32 @@ int main(int argc, char **argv) {
         mpc.Solve(vecRef, u, x0, true);
         wr(o, vecRef.data(), vecRef.size()); wr(o, u.data(), 4); wr(o, mpc.LastSolveInfo(), 4);
     }
+    // 5. keyframes (FrameKDMap.cpp:437-488) + multi-frame QueryNearest (:347-375): three frames = the same cloud
+    //    seen from a camera that moves 1.5 m per frame; the second and third update sweep + rebuild on the GPU
+    {
+        FrameKDMap kmap;
+        kmap.ptIsInCurFrame = [](const Vector3d &) { return false; };  // force the multi-frame path
+        int th_count = 10;
+        double th_dist = 0.1;
+        for (int f = 0; f < 3; ++f) {
+            auto cf = std::make_shared<Cloud>(), ef = std::make_shared<Cloud>();
+            for (int i = 0; i < n; ++i)
+                if (cl[3 * i] >= 1.5f * f && cl[3 * i] < 1.5f * f + 12.f) cf->points.emplace_back(cl[3 * i], cl[3 * i + 1], cl[3 * i + 2]);
+            for (int i = 0; i < ne; ++i) ef->points.emplace_back(ed[3 * i], ed[3 * i + 1], ed[3 * i + 2]);
+            kmap.AddVertex(cf, ef);
+            kmap.KeyframeUpdate(Vector3d(1.5 * f - 30.0, 0, 1.5), Vector3d(1, 0, 0), 0.1, th_dist, th_count, 100);
+            int kc = (int)kmap.KeyFrameCount(), lo = kmap.LastSweepOutliers();
+            wr(o, &kc, 1); wr(o, &lo, 1);
+        }
+        for (int i = 0; i < nq; ++i) {
+            Vector3d p(qs[3 * i], qs[3 * i + 1], qs[3 * i + 2]);
+            std::vector<Vector3d> pts; std::vector<double> d2;
+            kmap.QueryNearest(p, K, pts, d2);
+            double nd = kmap.GetNearestDistance(p);
+            int c = (int)d2.size();
+            wr(o, &c, 1); wr(o, d2.data(), c); wr(o, &nd, 1);
+        }
+    }
     fclose(o);
     return 0;
 }

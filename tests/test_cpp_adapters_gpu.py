@@ -75,4 +75,28 @@ def test_adapters_match_oracle(tmp_path):
     m2 = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m2.configure(prm)
     uc, _, ic = m2.Solve(vec.copy(), True)
     assert np.abs(u - uc).max() <= 1e-6 and np.array_equal(info, ic)
+    # 5. keyframes + multi-frame merge
+    frames = [sc["cloud"][(sc["cloud"][:, 0] >= 1.5 * f) & (sc["cloud"][:, 0] < 1.5 * f + 12.0)] for f in range(3)]
+    trees = [_oracle.kd_oracle(fr) for fr in frames]
+    keyframes = []
+    exp = []
+    for f in range(3):
+        cur = trees[f]
+        if not keyframes:
+            keyframes.append(cur); exp.append((1, 0)); continue
+        last = keyframes[-1]
+        r, n_out = last.keyframe_sweep(cur, 0.1, 10)
+        if r:
+            keyframes.append(cur)
+        exp.append((len(keyframes), n_out))
+    for f in range(3):
+        kc, lo = take(np.int32, 2)
+        assert (kc, lo) == exp[f], (f, kc, lo, exp[f])
+    query_frames = [trees[2]] + keyframes[:-1]                    # UpdateQueryVector: cur + all key frames but the newest
+    for q in qs:
+        c = int(take(np.int32, 1)[0]); d2 = take(np.float64, c); nd = take(np.float64, 1)[0]
+        alld = np.sort(np.concatenate([t.search(q, min(K, t.size()))[1] for t in query_frames]))[:K]
+        assert np.array_equal(d2, alld)
+        nn = min([t.search(q, 1)[1][0] for t in query_frames if t.size() > 1] or [np.finfo(np.float64).max])
+        assert nd == np.sqrt(nn)
     assert off == len(buf)

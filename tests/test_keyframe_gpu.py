@@ -1,0 +1,57 @@
+"""GPU: the keyframe maintenance sweep (FrameKDMap::KeyframeThreadWorker,
+AM/src/FrameKDMap.cpp:462-485) -- n 1-NN queries of the last keyframe's points against the current
+frame's index, outlier filter, rebuild -- against the oracle's restatement."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_sweep_matches_oracle():
+    import torch
+    from avoid_mpc_amd.host import KdBatch
+    rng = np.random.default_rng(5)
+    th_dist, th_count = 0.1, 10                       # keyframe_th_dist / keyframe_th_count, mpc_parameters.yaml:69-70
+    scenes = []
+    for s in range(6):
+        cur = synth.make_cloud(20000, 700 + s)[0]
+        kf = synth.make_cloud(20000, 700 + s)[0].copy()
+        # the keyframe is the previous frame: mostly the same surface points (shifted a little) plus a
+        # region the current frame no longer sees
+        kf += rng.normal(0, 0.02 if s % 2 == 0 else 0.2, kf.shape).astype(np.float32)
+        kf[:3000, 0] -= 6.0
+        if s == 4:
+            kf = cur.copy()                           # identical: no outliers -> no rebuild
+        if s == 5:
+            cur = cur[:1]                             # current tree with one point: SearchForNearest(.,1) gives nothing
+        scenes.append((kf.astype(np.float32), cur.astype(np.float32)))
+    S = len(scenes)
+    nk = max(len(k) for k, _ in scenes); nc = max(len(c) for _, c in scenes)
+    kb = np.zeros((S, nk, 3), np.float32); cb = np.zeros((S, nc, 3), np.float32)
+    kn = np.zeros(S, np.int32); cn = np.zeros(S, np.int32)
+    for s, (k, c) in enumerate(scenes):
+        kb[s, :len(k)] = k; kn[s] = len(k); cb[s, :len(c)] = c; cn[s] = len(c)
+    kd_k, kd_c = KdBatch(S, nk), KdBatch(S, nc)
+    kd_k.build(torch.from_numpy(kb).cuda(), torch.from_numpy(kn).cuda())
+    kd_c.build(torch.from_numpy(cb).cuda(), torch.from_numpy(cn).cuda())
+    outl, reb = kd_k.keyframe_sweep(kd_c, th_dist, th_count)
+    torch.cuda.synchronize()
+    outl, reb, sizes = outl.cpu().numpy(), reb.cpu().numpy(), kd_k.sizes()
+    qs = np.stack([rng.uniform(0, 20, (S, 16)), rng.uniform(-6, 6, (S, 16)), rng.uniform(0, 4, (S, 16))], -1)
+    res = kd_k.search(torch.from_numpy(qs).cuda(), 8)
+    torch.cuda.synchronize()
+    for s, (k, c) in enumerate(scenes):
+        tk, tc = _oracle.kd_oracle(k), _oracle.kd_oracle(c)
+        r, n_out = tk.keyframe_sweep(tc, th_dist, th_count)
+        assert outl[s] == n_out and reb[s] == r, (s, outl[s], n_out, reb[s], r)
+        assert sizes[s] == tk.size()
+        for q in range(16):                            # the rebuilt (or untouched) keyframe answers like the oracle's
+            ia, da, pa = tk.search(qs[s, q], 8)
+            cnt = res["counts"][s, q].item()
+            assert cnt == len(ia)
+            assert np.array_equal(res["indices"][s, q, :cnt].cpu().numpy(), ia)
+            assert np.array_equal(res["sqdist"][s, q, :cnt].cpu().numpy(), da)
+    assert reb[4] == 0 and outl[4] == 0 and reb[5] == 0 and reb[0] == 1
