@@ -155,23 +155,26 @@ struct SceneIO {
     const double *obs;     // [N][K][3] obstacle points           (P[10+10N : ...])
 };
 
-// ---- one obstacle term, ACCUMULATED into cost and, when DERIV, gradient (6) + model Hessian (21 unique,
-// row-major lower triangle of the (p,v) 6x6 block).  Mirrors oracle collide_point statement by statement.
+// ---- one obstacle term: its cost is returned; when DERIV its gradient (6) and model Hessian (21 unique,
+// row-major lower triangle of the (p,v) 6x6 block) are ADDED to the stage's LDS cells with ds_add_f64 --
+// no per-lane accumulators (they were the register peak of the kernel) and no cross-lane reduction.
+// Lanes of one wave-instruction that hit the same cell are applied in lane order, so the sums are
+// reproducible.  Mirrors oracle collide_point statement by statement.
 template <bool DERIV>
-__device__ __forceinline__ void collide_point(const double p[3], const double v[3], const double o[3], double lam,
-                                              double radius, double &cost, double g6[6], double H[21]) {
+__device__ __forceinline__ double collide_point(const double p[3], const double v[3], const double o[3], double lam,
+                                                double radius, double *gq, double *h21) {
     const double d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
     const double rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    const double ir = 1.0 / rho;
-    const double n[3] = {d0 * ir, d1 * ir, d2 * ir};
-    const double s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
     const double x = -32.0 * (rho - radius);
     const double ex = exp(x);
     const double g = log(1.0 + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
+    const double ir = 1.0 / rho;
+    const double n[3] = {d0 * ir, d1 * ir, d2 * ir};
+    const double s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
     const double as = fabs(s);
-    cost += lam * g * as;
-    if (!DERIV) return;
-    const double sg = 1.0 / (1.0 + exp(-x));
+    const double cost = lam * g * as;
+    if (!DERIV) return cost;
+    const double sg = ex / (1.0 + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
     const double gp = -32.0 * sg;
     const double gpp = 1024.0 * sg * (1.0 - sg);
     const double sgn = (s > 0.0) ? 1.0 : ((s < 0.0) ? -1.0 : 0.0);
@@ -179,8 +182,8 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
     const double ls = lam * sgn;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        g6[i] += ls * (gp * (-n[i]) * s + g * (-t[i] * ir));
-        g6[3 + i] += ls * g * n[i];
+        unsafeAtomicAdd(gq + i, ls * (gp * (-n[i]) * s + g * (-t[i] * ir)));       // state slots 0,1,2 = p
+        unsafeAtomicAdd(gq + 4 + i, ls * g * n[i]);                                // state slots 4,5,6 = v
     }
     const double gs[6] = {-t[0] * ir, -t[1] * ir, -t[2] * ir, n[0], n[1], n[2]};
     const double wk = lam * g / (as > kAbsEps ? as : kAbsEps);
@@ -201,8 +204,9 @@ __device__ __forceinline__ void collide_point(const double p[3], const double v[
                 const double Pn = (a == j ? 1.0 : 0.0) - nn;
                 h += ls * (-gp * nn - g * Pn * ir);
             }
-            H[i * (i + 1) / 2 + j] += h;
+            unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
         }
+    return cost;
 }
 
 // Evaluate the objective on (Xs, Us) held in LDS.  DERIV: also q, r, H6 (36 per stage, full
@@ -214,57 +218,26 @@ __device__ __forceinline__ double evaluate(double *sm, const LdsMap &L, const Sc
     const double *prm = sm + L.prm;
     const double lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
     double Jloc = 0.0;
-    // ---- collision terms: Lp lanes per stage (power of two, all N-1 stages in one round when they fit),
-    // each lane accumulates a contiguous block of `per` obstacle points before the cross-lane reduction
-    // (a 28-value DPP reduction per level costs more than a whole collide_point evaluation)
-    int Lp = 1;
-    while (Lp * 2 <= Kpad && (N - 1) * (Lp * 2) <= 64) Lp *= 2;
-    const int per = (K + Lp - 1) / Lp;
-    const int spr = 64 / Lp;
-    for (int k0 = 0; k0 < N - 1; k0 += spr) {
-        const int k = k0 + lane / Lp, jl = lane % Lp;
-        const long long tc0 = AMK_CLK();
-        double c = 0.0, g6[6] = {0, 0, 0, 0, 0, 0}, H[21];
-        if (DERIV) {
-#pragma unroll
-            for (int e = 0; e < 21; ++e) H[e] = 0.0;
-        }
-        if (k < N - 1) {
+    // ---- collision terms: lane = (stage, obstacle point), 64 terms per round
+    if (DERIV) {  // the cells the terms add into
+        for (int e = lane; e < (N - 1) * 21; e += 64) sm[L.H6 + e] = 0.0;
+        for (int e = lane; e < (N - 1) * 6; e += 64) sm[L.q + (e / 6 + 1) * SD + pv_of(e % 6)] = 0.0;
+        __syncthreads();
+    }
+    const long long tc0 = AMK_CLK();
+    const int nterm = (N - 1) * K;
+    for (int t0 = 0; t0 < nterm; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < nterm) {
+            const int k = t / K;
             const double *xk = Xs + (k + 1) * SD;
             const double p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
-            for (int jj = 0; jj < per; ++jj) {
-                const int j = jl * per + jj;
-                if (j < K) {
-                    const double *op = io.obs + ((size_t)k * K + j) * 3;
-                    const double o[3] = {op[0], op[1], op[2]};
-                    collide_point<DERIV>(p, v, o, lamw, radius, c, g6, H);
-                }
-            }
-        }
-        const int j = jl;
-        const int Kpad_red = Lp;
-        const long long tc1 = AMK_CLK();
-        c = seg_sum(c, Kpad_red);
-        if (DERIV) {
-#pragma unroll
-            for (int e = 0; e < 6; ++e) g6[e] = seg_sum(g6[e], Kpad_red);
-#pragma unroll
-            for (int e = 0; e < 21; ++e) H[e] = seg_sum(H[e], Kpad_red);
-        }
-        const long long tc2 = AMK_CLK();
-        if (kTrace && tclk) { tclk[0] += tc1 - tc0; tclk[1] += tc2 - tc1; }
-        if (j == 0 && k < N - 1) {
-            Jloc += c;
-            if (DERIV) {
-                double *h6 = sm + L.H6 + k * 21;  // lower triangle, row-major
-#pragma unroll
-                for (int e = 0; e < 21; ++e) h6[e] = H[e];
-                double *qk = sm + L.q + (k + 1) * SD;  // collision part; the stage lane adds the rest
-#pragma unroll
-                for (int i = 0; i < 6; ++i) qk[pv_of(i)] = g6[i];
-            }
+            const double *op = io.obs + (size_t)t * 3;  // [k][j][3]
+            const double o[3] = {op[0], op[1], op[2]};
+            Jloc += collide_point<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
         }
     }
+    if (kTrace && tclk) tclk[0] += AMK_CLK() - tc0;
     if (DERIV) __syncthreads();
     const long long tc3 = AMK_CLK();
     // ---- per-stage quadratic terms: lane = stage

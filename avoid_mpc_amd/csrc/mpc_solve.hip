@@ -159,7 +159,7 @@ extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
 
 // grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total doubles
 template <int NT>  // NT > 0: horizon baked in (LDS offsets become immediates, as the reference bakes N into its plugin)
-__global__ __launch_bounds__(64) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
+__global__ __launch_bounds__(64, 2) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
                                                        SolveOpts opt, const double *__restrict__ ref_states,
                                                        double *__restrict__ w0, double *__restrict__ u_out,
                                                        double *__restrict__ x0array, int *__restrict__ info,
