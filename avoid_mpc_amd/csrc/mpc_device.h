@@ -300,26 +300,6 @@ __device__ __forceinline__ double evaluate(double *sm, const LdsMap &L, const Sc
     return wave_sum(Jloc);
 }
 
-// Q_k[i][j] for the state X_k, 1 <= k <= N (cost stage k-1 attaches to X_k)
-__device__ __forceinline__ double q_elem(const double *sm, const LdsMap &L, int N, int k, int i, int j) {
-    const double *prm = sm + L.prm;
-    if (k >= N) return i == j ? 2.0 * prm[PRM_W + i] : 0.0;  // goal: diag(2 Qgoal)
-    const int st = k - 1;
-    double v = 0.0;
-    const int bi = (i == 0 || i == 1) ? 0 : ((i == 4 || i == 5) ? 1 : -1);
-    const int bj = (j == 0 || j == 1) ? 0 : ((j == 4 || j == 5) ? 1 : -1);
-    if (bi >= 0 && bi == bj) {
-        const int li = (i == 1 || i == 5) ? 1 : 0;  // local index inside the 2x2 block
-        const int lj = (j == 1 || j == 5) ? 1 : 0;
-        v = sm[L.rotQ + st * 6 + bi * 3 + (li + lj)];   // [xx, xy, yy]
-    } else if (i == j) {
-        v = 2.0 * prm[PRM_W + 10 + i];
-    }
-    const int pi = pv_inv(i), pj = pv_inv(j);
-    if (pi >= 0 && pj >= 0) v += sm[L.H6 + st * 21 + (pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi)];
-    return v;
-}
-
 // ---- Riccati plan: which LDS cells each lane combines in "round A" of a backward stage.  The affine
 // dynamics are constant, so every entry of A'PA, B'PB, B'PA, A'p, A'lam, B'p, B'lam is a fixed <= 9-term
 // linear combination of entries of P / p / lam; the host enumerates the terms once per handle
@@ -327,54 +307,51 @@ __device__ __forceinline__ double q_elem(const double *sm, const LdsMap &L, int 
 constexpr int PLAN_ITEMS = 128;
 constexpr int PLAN_TERMS = 9;
 struct PlanItemMeta {            // one per item, ints
-    int idx[PLAN_TERMS];         // LDS offsets (doubles) of the source cells
+    int idx[PLAN_TERMS];         // LDS offsets (doubles) of the source cells (unused terms: the zero cell)
     int out;                     // LDS offset of the result (+ k * out_kstride)
     int out_kstride;
-    int aux;                     // LDS offset of a per-stage addend (+ 4 k), or -1
-    int aux_delta;               // 1: also add the regularisation shift (diagonal of the control block)
+    int aux;                     // LDS offset of a per-stage addend (+ k * aux_kstride); the zero cell if none
+    int aux_kstride;
+};
+// coefficients: [PLAN_ITEMS][PLAN_TERMS + 1] doubles, the last one multiplies the regularisation shift delta
+
+// What a lane does in rounds B/C of a backward stage (host-built, build_plan): value = base - G(:,ci)' Hm^-1 g,
+// with g = G(:,cj) for an entry of P and g = qu for an entry of p.  Everything is an index so that the round is
+// branch-free: lanes without a role read the zero cell and write the dummy cell.
+constexpr int LANE_META_INTS = 16;
+struct LaneRole {
+    int gi, gi_stride;           // column "i": sm[gi + a * gi_stride], a < 4
+    int gj, gj_stride;           // column "j"
+    int b_idx[3], b_ks[3];       // base = bconst + bdelta * delta + sum_n sm[b_idx[n] + k * b_ks[n]]
+    int out1, out2;              // where the value goes (P[i][j] and P[j][i]; p[i] twice)
+    int gain_col;                // >= 0: this lane also stores column gain_col of the gains (-Hm^-1 g)
+    int lam_src, lam_dst;        // lam_k copy ridden by lanes 0..9
+    int pad;
 };
 
-struct LanePlan {                // the two items of this lane, in registers for the whole solve
-    double coef[2][PLAN_TERMS];
+struct LanePlan {                // the two items + the role of this lane, in registers for one backward sweep
+    double coef[2][PLAN_TERMS + 1];
     int idx[2][PLAN_TERMS];
-    int out[2], out_kstride[2], aux[2], aux_delta[2];
-    // round C: (i, j) of the P entry owned by this lane and how to assemble Q_k[i][j]
-    int ci, cj;                  // lane < 55: lower-triangular entry; 55..63: p entry ci
-    double qdiag;                // constant diagonal part (2 Qpen[i] outside the rotated blocks)
-    int rot_off, h6_off;         // offsets into rotQ[st*6 + .] / H6[st*36 + .] or -1
+    int out[2], out_kstride[2], aux[2], aux_kstride[2];
+    LaneRole role;
+    double bconst, bdelta;
 };
 
-__device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_coef, const int *plan_meta,
-                                               const double *prm) {
+__device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_coef, const int *plan_meta) {
     const int lane = threadIdx.x;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int e = lane + 64 * h;
         const PlanItemMeta *m = reinterpret_cast<const PlanItemMeta *>(plan_meta) + e;
 #pragma unroll
-        for (int t = 0; t < PLAN_TERMS; ++t) {
-            lp.coef[h][t] = plan_coef[e * PLAN_TERMS + t];
-            lp.idx[h][t] = m->idx[t];
-        }
-        lp.out[h] = m->out; lp.out_kstride[h] = m->out_kstride; lp.aux[h] = m->aux; lp.aux_delta[h] = m->aux_delta;
+        for (int t = 0; t < PLAN_TERMS; ++t) lp.idx[h][t] = m->idx[t];
+#pragma unroll
+        for (int t = 0; t <= PLAN_TERMS; ++t) lp.coef[h][t] = plan_coef[e * (PLAN_TERMS + 1) + t];
+        lp.out[h] = m->out; lp.out_kstride[h] = m->out_kstride; lp.aux[h] = m->aux; lp.aux_kstride[h] = m->aux_kstride;
     }
-    int i = 0, j = 0;
-    if (lane < 55) {
-        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
-        j = lane - i * (i + 1) / 2;
-    } else {
-        i = lane - 55;
-    }
-    lp.ci = i; lp.cj = j;
-    lp.qdiag = 0.0; lp.rot_off = -1; lp.h6_off = -1;
-    if (lane < 55) {
-        const int bi = (i == 0 || i == 1) ? 0 : ((i == 4 || i == 5) ? 1 : -1);
-        const int bj = (j == 0 || j == 1) ? 0 : ((j == 4 || j == 5) ? 1 : -1);
-        if (bi >= 0 && bi == bj) lp.rot_off = bi * 3 + ((i == 1 || i == 5) ? 1 : 0) + ((j == 1 || j == 5) ? 1 : 0);
-        else if (i == j) lp.qdiag = 2.0 * prm[PRM_W + 10 + i];
-        const int pi = pv_inv(i), pj = pv_inv(j);
-        if (pi >= 0 && pj >= 0) lp.h6_off = pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi;
-    }
+    lp.role = reinterpret_cast<const LaneRole *>(plan_meta + PLAN_ITEMS * (PLAN_TERMS + 4))[lane];
+    lp.bconst = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane];
+    lp.bdelta = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane + 1];
 }
 
 // 1/x to full double precision: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~4x longer)
@@ -387,13 +364,17 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 // Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
 // control block is not positive definite.  Gains go to L.Kk ([k][a*11 + j], column 10 = feed-forward).
+//
+// A stage is two LDS rounds.  Both are straight-line code (every lane runs the same instructions on its own
+// host-built indices) so that the loads of a round are all in flight before the first dependent fp64 op: this
+// sweep is a chain of dependent fp64 operations (32 cycles each here) and LDS round trips, nothing else.
 __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, const double *plan_coef,
                                                  const int *plan_meta, int N, double delta) {
     const int lane = threadIdx.x;
-    // the lane's plan is (re)loaded per sweep -- 44 L2-resident words -- instead of being held for the whole
-    // solve: it is dead weight (60 VGPRs) during the objective evaluation, which sets the register peak
+    // the lane's plan is (re)loaded per sweep -- L2-resident words -- instead of being held for the whole
+    // solve: it is dead weight (~90 VGPRs) during the objective evaluation, which sets the register peak
     LanePlan lp;
-    load_lane_plan(lp, plan_coef, plan_meta, sm + L.prm);
+    load_lane_plan(lp, plan_coef, plan_meta);
     double *P = sm + L.P, *pv = sm + L.p, *lam = sm + L.lam;
     // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
     for (int e = lane; e < 100; e += 64) {
@@ -404,97 +385,68 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
         pv[lane] = sm[L.q + N * SD + lane];
         lam[lane] = pv[lane];
     }
+    if (lane == 0) sm[L.red + 10] = 0.0;  // the zero cell of the plan
     __syncthreads();
+    const LaneRole &R = lp.role;
 #pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
-        // ---- round A: the two plan items of this lane
+        // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, q + A'lam,
+        // r_bar + B'p, r + B'lam)
+        {
+            double v[2][PLAN_TERMS], ax[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            double v[PLAN_TERMS];
+            for (int h = 0; h < 2; ++h) {
 #pragma unroll
-            for (int t = 0; t < PLAN_TERMS; ++t) v[t] = sm[lp.idx[h][t]];
-            // three partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
-            double a0 = lp.coef[h][0] * v[0], a1 = lp.coef[h][1] * v[1], a2 = lp.coef[h][2] * v[2];
-            a0 = fma(lp.coef[h][3], v[3], a0); a1 = fma(lp.coef[h][4], v[4], a1); a2 = fma(lp.coef[h][5], v[5], a2);
-            a0 = fma(lp.coef[h][6], v[6], a0); a1 = fma(lp.coef[h][7], v[7], a1); a2 = fma(lp.coef[h][8], v[8], a2);
-            double acc = (a0 + a1) + a2;
-            if (lp.aux[h] >= 0) acc += sm[lp.aux[h] + 4 * k];
-            if (lp.aux_delta[h]) acc += delta;
-            sm[lp.out[h] + k * lp.out_kstride[h]] = acc;
+                for (int t = 0; t < PLAN_TERMS; ++t) v[h][t] = sm[lp.idx[h][t]];
+                ax[h] = sm[lp.aux[h] + k * lp.aux_kstride[h]];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // four partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
+                const double *c = lp.coef[h];
+                double a0 = c[0] * v[h][0], a1 = c[1] * v[h][1], a2 = c[2] * v[h][2], a3 = fma(c[PLAN_TERMS], delta, ax[h]);
+                a0 = fma(c[3], v[h][3], a0); a1 = fma(c[4], v[h][4], a1); a2 = fma(c[5], v[h][5], a2);
+                a0 = fma(c[6], v[h][6], a0); a1 = fma(c[7], v[h][7], a1); a2 = fma(c[8], v[h][8], a2);
+                sm[lp.out[h] + k * lp.out_kstride[h]] = (a0 + a1) + (a2 + a3);
+            }
         }
         __syncthreads();
-        // ---- round B: LDL' of Hm (every lane, wave-uniform), Y = L^-1 [G | qu], gains
-        double Lm[6], Di[4];  // L10 L20 L21 L30 L31 L32 ; reciprocals of D
+        // ---- rounds B+C: Hm = blkdiag(3x3, h33) because the yaw chain is decoupled (build_plan checks).  With
+        // adj = adjugate of the 3x3 block:  G(:,i)' Hm^-1 g = (G(0:3,i)' adj g(0:3)) / det + G(3,i) g(3) / h33.
+        // The products with adj run beside det -> 1/det (ONE reciprocal on the critical path; an LDL' has four
+        // sequential pivots).  Positive definite <=> leading principal minors > 0, the test an LDL' makes.
         {
             const double *h = sm + L.Hm;  // lower: h00 h10 h11 h20 h21 h22 h30 h31 h32 h33
-            const double d0 = h[0];
-            if (!(d0 > 0.0)) return false;
-            Di[0] = fast_rcp(d0);
-            Lm[0] = h[1] * Di[0]; Lm[1] = h[3] * Di[0]; Lm[3] = h[6] * Di[0];
-            const double d1 = h[2] - Lm[0] * h[1];
-            if (!(d1 > 0.0)) return false;
-            Di[1] = fast_rcp(d1);
-            Lm[2] = (h[4] - Lm[1] * h[1]) * Di[1];
-            Lm[4] = (h[7] - Lm[3] * h[1]) * Di[1];
-            const double l21d1 = Lm[2] * d1;
-            const double d2 = h[5] - Lm[1] * h[3] - Lm[2] * l21d1;
-            if (!(d2 > 0.0)) return false;
-            Di[2] = fast_rcp(d2);
-            Lm[5] = (h[8] - Lm[3] * h[3] - Lm[4] * l21d1) * Di[2];
-            const double d3 = h[9] - Lm[3] * h[6] - Lm[4] * (Lm[4] * d1) - Lm[5] * (Lm[5] * d2);
-            if (!(d3 > 0.0)) return false;
-            Di[3] = fast_rcp(d3);
-        }
-        // ---- rounds B+C fused: every lane forward-solves the (<= 2) columns of [G | qu] its own outputs
-        // need (Y = L^-1 [G | qu], Z = D^-1 Y); no LDS round trip / barrier between the factorisation
-        // and the update.  P_k = Q_k + delta I + M - Y'Z ; p_k = q_k + A'p - Y'z_u ; lam_k = q_k + A'lam
-        auto solve_col = [&](int c, double (&y)[4], double (&z)[4]) {
-            const double g0 = c < SD ? sm[L.G + c] : sm[L.qu + 0];
-            const double g1 = c < SD ? sm[L.G + 10 + c] : sm[L.qu + 1];
-            const double g2 = c < SD ? sm[L.G + 20 + c] : sm[L.qu + 2];
-            const double g3 = c < SD ? sm[L.G + 30 + c] : sm[L.qu + 3];
-            y[0] = g0;
-            y[1] = g1 - Lm[0] * y[0];
-            y[2] = g2 - Lm[1] * y[0] - Lm[2] * y[1];
-            y[3] = g3 - Lm[3] * y[0] - Lm[4] * y[1] - Lm[5] * y[2];
-            z[0] = y[0] * Di[0]; z[1] = y[1] * Di[1]; z[2] = y[2] * Di[2]; z[3] = y[3] * Di[3];
-        };
-        if (lane <= SD) {  // gains: x = L^-T Z(:,c), K(:,c) = -x (column 10 = feed-forward)
-            double y[4], z[4];
-            solve_col(lane, y, z);
-            const double x3 = z[3];
-            const double x2 = z[2] - Lm[5] * x3;
-            const double x1 = z[1] - Lm[2] * x2 - Lm[4] * x3;
-            const double x0 = z[0] - Lm[0] * x1 - Lm[1] * x2 - Lm[3] * x3;
-            double *kk = sm + L.Kk + k * 44;
-            kk[lane] = -x0; kk[11 + lane] = -x1; kk[22 + lane] = -x2; kk[33 + lane] = -x3;
-        }
-        if (k > 0) {
-            const int i = lp.ci;
-            double yi[4], zi[4], yj[4], zj[4];
-            solve_col(i, yi, zi);
-            solve_col(lane < 55 ? lp.cj : SD, yj, zj);
-            const double ww = yi[0] * zj[0] + yi[1] * zj[1] + yi[2] * zj[2] + yi[3] * zj[3];
-            if (lane < 55) {
-                const int j = lp.cj, st = k - 1;
-                double qe = lp.qdiag + (i == j ? delta : 0.0);
-                if (lp.rot_off >= 0) qe += sm[L.rotQ + st * 6 + lp.rot_off];
-                if (lp.h6_off >= 0) qe += sm[L.H6 + st * 21 + lp.h6_off];
-                const double val = qe + sm[L.M + lane] - ww;
-                P[i * 10 + j] = val;
-                P[j * 10 + i] = val;
-            } else {  // p entries 0..8
-                pv[i] = sm[L.q + k * SD + i] + sm[L.Atp + i] - ww;
+            const double h00 = h[0], h10 = h[1], h11 = h[2], h20 = h[3], h21 = h[4], h22 = h[5], h33 = h[9];
+            double gi[4], gj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                gi[a] = sm[R.gi + a * R.gi_stride];
+                gj[a] = sm[R.gj + a * R.gj_stride];
             }
-            if (lane == 0) {  // p entry 9
-                double y9[4], z9[4], yu[4], zu[4];
-                solve_col(9, y9, z9);
-                solve_col(SD, yu, zu);
-                const double wv = y9[0] * zu[0] + y9[1] * zu[1] + y9[2] * zu[2] + y9[3] * zu[3];
-                pv[9] = sm[L.q + k * SD + 9] + sm[L.Atp + 9] - wv;
-            } else if (lane <= SD) {  // lam entries
-                const int ii = lane - 1;
-                lam[ii] = sm[L.q + k * SD + ii] + sm[L.Atl + ii];
+            const double b0 = sm[R.b_idx[0] + k * R.b_ks[0]], b1 = sm[R.b_idx[1] + k * R.b_ks[1]];
+            const double b2 = sm[R.b_idx[2] + k * R.b_ks[2]];
+            const double lamv = sm[R.lam_src];
+            const double c00 = h11 * h22 - h21 * h21, c10 = h21 * h20 - h10 * h22, c20 = h10 * h21 - h11 * h20;
+            const double c11 = h00 * h22 - h20 * h20, c21 = h10 * h20 - h00 * h21, c22 = h00 * h11 - h10 * h10;
+            const double det = (h00 * c00 + h10 * c10) + h20 * c20;
+            if (!(h00 > 0.0 && c22 > 0.0 && det > 0.0 && h33 > 0.0)) return false;
+            const double rd = fast_rcp(det), r33 = fast_rcp(h33);
+            const double u0 = (c00 * gj[0] + c10 * gj[1]) + c20 * gj[2];
+            const double u1 = (c10 * gj[0] + c11 * gj[1]) + c21 * gj[2];
+            const double u2 = (c20 * gj[0] + c21 * gj[1]) + c22 * gj[2];
+            const double u3 = gj[3] * r33;
+            const double t = (gi[0] * u0 + gi[1] * u1) + gi[2] * u2;
+            const double base = (fma(lp.bdelta, delta, lp.bconst) + b0) + (b1 + b2);
+            const double val = fma(-t, rd, fma(-gi[3], u3, base));
+            if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward)
+                double *kk = sm + L.Kk + k * 44 + R.gain_col;
+                kk[0] = -u0 * rd; kk[11] = -u1 * rd; kk[22] = -u2 * rd; kk[33] = -u3;
+            }
+            if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
+                sm[R.out1] = val;
+                sm[R.out2] = val;
+                sm[R.lam_dst] = lamv;
             }
         }
         __syncthreads();
@@ -526,16 +478,18 @@ __device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int
         double xs[SD];
 #pragma unroll
         for (int j = 0; j < SD; ++j) xs[j] = readlane_f64(dx, j);
-        double du = krow[SD];
-#pragma unroll
-        for (int j = 0; j < SD; ++j) du = fma(krow[j], xs[j], du);
+        // partial sums: four short dependent chains instead of one of ten
+        double d0 = fma(krow[0], xs[0], krow[SD]), d1 = krow[1] * xs[1], d2 = krow[2] * xs[2], d3 = krow[3] * xs[3];
+        d0 = fma(krow[4], xs[4], d0); d1 = fma(krow[5], xs[5], d1); d2 = fma(krow[6], xs[6], d2);
+        d3 = fma(krow[7], xs[7], d3); d0 = fma(krow[8], xs[8], d0); d1 = fma(krow[9], xs[9], d1);
+        const double du = (d0 + d1) + (d2 + d3);
         if (lane < UD) sm[L.dU + k * UD + lane] = du;
-        double acc = 0.0;
-#pragma unroll
-        for (int j = 0; j < SD; ++j) acc = fma(arow[j], xs[j], acc);
-#pragma unroll
-        for (int j = 0; j < UD; ++j) acc = fma(brow[j], readlane_f64(du, j), acc);
-        dx = acc;
+        double a0 = arow[0] * xs[0], a1 = arow[1] * xs[1], a2 = arow[2] * xs[2], a3 = arow[3] * xs[3];
+        a0 = fma(arow[4], xs[4], a0); a1 = fma(arow[5], xs[5], a1); a2 = fma(arow[6], xs[6], a2);
+        a3 = fma(arow[7], xs[7], a3); a0 = fma(arow[8], xs[8], a0); a1 = fma(arow[9], xs[9], a1);
+        a2 = fma(brow[0], readlane_f64(du, 0), a2); a3 = fma(brow[1], readlane_f64(du, 1), a3);
+        a0 = fma(brow[2], readlane_f64(du, 2), a0); a1 = fma(brow[3], readlane_f64(du, 3), a1);
+        dx = (a0 + a1) + (a2 + a3);
         if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = dx;
     }
     __syncthreads();
@@ -679,7 +633,6 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
         a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi); phi0 = J + wave_sum(phi0);
         // backtracking Armijo line search on the barrier function
         const long long t4 = AMK_CLK();
-        int n_ls = 0;
         double a = a_pr;
         bool accepted = false;
         for (int ls = 0; ls < opt.max_ls; ++ls) {
@@ -687,7 +640,6 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
             for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
             for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
             __syncthreads();
-            ++n_ls;
             double phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
             double lg = 0.0;
             for (int e = lane; e < nvar; e += 64) {

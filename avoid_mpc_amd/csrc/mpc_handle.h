@@ -11,8 +11,8 @@ struct amk_mpc {
     size_t lds_bytes = 0;
     amk::DevBuf<double> prm;  // [PRM_LEN]
     amk::DevBuf<double> w0;   // [S][nx]  mNlpW0
-    amk::DevBuf<double> plan_coef;  // [PLAN_ITEMS][PLAN_TERMS]  Riccati plan (mpc_device.h)
-    amk::DevBuf<int> plan_meta;     // [PLAN_ITEMS] PlanItemMeta
+    amk::DevBuf<double> plan_coef;  // item coefficients + lane-role constants of the Riccati plan (mpc_device.h)
+    amk::DevBuf<int> plan_meta;     // [PLAN_ITEMS] PlanItemMeta + [64] LaneRole
     // staging for amk_mpc_solve_host
     amk::DevBuf<double> st_ref, st_u, st_x0;
     amk::DevBuf<int> st_info;

@@ -64,8 +64,8 @@ void refresh_dynamics(amk_mpc *m) {
 }
 
 // Enumerates, for every entry of A'PA, B'PB(+R), B'PA, A'p, A'lam, B'p(+r_bar), B'lam(+r), the <= 9 source cells
-// and coefficients (mpc_device.h "Riccati plan").  Generic in the non-zeros of A and B; the yaw chain
-// is decoupled from the others (checked), so P[yaw][other] == 0 for every stage and those terms drop out.
+// and coefficients (mpc_device.h "Riccati plan").  Generic in the non-zeros of A and B except that the yaw chain
+// must be decoupled from the others (checked; it is for every tau/gain of the model), so P[yaw][other] == 0 for every stage and those terms drop out.
 int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
     const double *A = m->h_prm + PRM_A, *B = m->h_prm + PRM_B;
     const LdsMap L(m->N);
@@ -76,8 +76,10 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
         if (B[3 * UD + a] != 0.0) yaw_free = false;
     for (int i = 0; i < SD; ++i)
         if (i != 3 && B[i * UD + 3] != 0.0) yaw_free = false;
-    auto zeroP = [&](int l, int mm) { return yaw_free && ((l == 3) != (mm == 3)); };
-    struct Item { std::vector<std::pair<int, double>> t; int out, ks, aux, auxd; };
+    if (!yaw_free) return AMK_ERR_UNSUPPORTED;  // the control block is inverted as blkdiag(3x3, 1x1) (riccati_backward)
+    auto zeroP = [&](int l, int mm) { return (l == 3) != (mm == 3); };
+    const int ZERO = L.red + 10, DUMMY = L.red + 8;  // a cell that always holds 0.0 / a write-only cell
+    struct Item { std::vector<std::pair<int, double>> t; int out, ks, aux, aux_ks; double dflag; };
     std::vector<Item> items;
     auto tri = [](int i, int j) { return i * (i + 1) / 2 + j; };
     auto mat_terms = [&](const double *Lf, int ls, int ci, const double *Rf, int rs, int cj) {
@@ -100,46 +102,98 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
     for (int i = 0; i < SD; ++i)
         for (int j = 0; j <= i; ++j) {
             auto t = mat_terms(A, SD, i, A, SD, j);
-            if (!t.empty()) items.push_back({t, L.M + tri(i, j), 0, -1, 0});
+            if (!t.empty()) items.push_back({t, L.M + tri(i, j), 0, ZERO, 0, 0.0});
         }
     for (int a = 0; a < UD; ++a)
         for (int b = 0; b <= a; ++b) {
             auto t = mat_terms(B, UD, a, B, UD, b);
-            if (!t.empty() || a == b) items.push_back({t, L.Hm + tri(a, b), 0, a == b ? L.Rb + a : -1, a == b ? 1 : 0});
+            if (a == b) items.push_back({t, L.Hm + tri(a, b), 0, L.Rb + a, UD, 1.0});  // + R_bar_k + delta
+            else if (!t.empty()) items.push_back({t, L.Hm + tri(a, b), 0, ZERO, 0, 0.0});
         }
     for (int a = 0; a < UD; ++a)
         for (int j = 0; j < SD; ++j) {
             auto t = mat_terms(B, UD, a, A, SD, j);
-            if (!t.empty()) items.push_back({t, L.G + a * 10 + j, 0, -1, 0});
+            if (!t.empty()) items.push_back({t, L.G + a * 10 + j, 0, ZERO, 0, 0.0});
         }
-    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.p), L.Atp + i, 0, -1, 0});
-    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.lam), L.Atl + i, 0, -1, 0});
-    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.p), L.qu + a, 0, L.rb + a, 0});
-    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.lam), L.gU + a, UD, L.r + a, 0});
+    // q_k + A'p and q_k + A'lam (= lam_k): the stage gradient rides in as the per-stage addend
+    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.p), L.Atp + i, 0, L.q + i, SD, 0.0});
+    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.lam), L.Atl + i, 0, L.q + i, SD, 0.0});
+    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.p), L.qu + a, 0, L.rb + a, UD, 0.0});
+    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.lam), L.gU + a, UD, L.r + a, UD, 0.0});
     if ((int)items.size() > PLAN_ITEMS) return AMK_ERR_UNSUPPORTED;
-    coef.assign((size_t)PLAN_ITEMS * PLAN_TERMS, 0.0);
-    meta.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 4), 0);
+    coef.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2, 0.0);
+    meta.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS, 0);
     for (int e = 0; e < PLAN_ITEMS; ++e) {
         int *mt = meta.data() + (size_t)e * (PLAN_TERMS + 4);
-        for (int t = 0; t < PLAN_TERMS; ++t) mt[t] = L.P;
-        mt[PLAN_TERMS + 0] = L.red + 8;  // dummy output cell
+        for (int t = 0; t < PLAN_TERMS; ++t) mt[t] = ZERO;
+        mt[PLAN_TERMS + 0] = DUMMY;
         mt[PLAN_TERMS + 1] = 0;
-        mt[PLAN_TERMS + 2] = -1;
+        mt[PLAN_TERMS + 2] = ZERO;
         mt[PLAN_TERMS + 3] = 0;
         if (e >= (int)items.size()) continue;
         const Item &it = items[e];
         if ((int)it.t.size() > PLAN_TERMS) return AMK_ERR_UNSUPPORTED;
         for (size_t t = 0; t < it.t.size(); ++t) {
             mt[t] = it.t[t].first;
-            coef[(size_t)e * PLAN_TERMS + t] = it.t[t].second;
+            coef[(size_t)e * (PLAN_TERMS + 1) + t] = it.t[t].second;
         }
-        mt[PLAN_TERMS + 0] = it.out; mt[PLAN_TERMS + 1] = it.ks; mt[PLAN_TERMS + 2] = it.aux; mt[PLAN_TERMS + 3] = it.auxd;
+        coef[(size_t)e * (PLAN_TERMS + 1) + PLAN_TERMS] = it.dflag;
+        mt[PLAN_TERMS + 0] = it.out; mt[PLAN_TERMS + 1] = it.ks; mt[PLAN_TERMS + 2] = it.aux; mt[PLAN_TERMS + 3] = it.aux_ks;
+    }
+    // ---- round B/C roles (mpc_device.h LaneRole): 46 lanes own the entries of P that are not structurally
+    // zero, 10 own p, the rest idle; the lanes on the diagonal of P / on p_0 also store a column of the gains
+    int *lm = meta.data() + (size_t)PLAN_ITEMS * (PLAN_TERMS + 4);
+    double *lc = coef.data() + (size_t)PLAN_ITEMS * (PLAN_TERMS + 1);
+    std::vector<int> free_lanes;
+    auto pv_inv_h = [](int s) { return s < 3 ? s : (s >= 4 && s <= 6 ? s - 1 : -1); };
+    for (int lane = 0; lane < 64; ++lane) {
+        int *r = lm + lane * LANE_META_INTS;
+        // defaults: idle lane (zero columns, zero base, writes to the dummy cell)
+        r[0] = ZERO; r[1] = 0; r[2] = ZERO; r[3] = 0;
+        for (int t = 0; t < 3; ++t) { r[4 + t] = ZERO; r[7 + t] = 0; }
+        r[10] = DUMMY; r[11] = DUMMY; r[12] = -1; r[13] = ZERO; r[14] = DUMMY;
+        if (lane >= 55) { free_lanes.push_back(lane); continue; }
+        int i = 0;
+        while ((i + 1) * (i + 2) / 2 <= lane) ++i;
+        const int j = lane - i * (i + 1) / 2;
+        if (zeroP(i, j)) { free_lanes.push_back(lane); continue; }
+        r[0] = L.G + i; r[1] = 10; r[2] = L.G + j; r[3] = 10;
+        int nb = 0;
+        r[4 + nb] = L.M + lane; r[7 + nb] = 0; ++nb;
+        const int bi = (i == 0 || i == 1) ? 0 : ((i == 4 || i == 5) ? 1 : -1);
+        const int bj = (j == 0 || j == 1) ? 0 : ((j == 4 || j == 5) ? 1 : -1);
+        if (bi >= 0 && bi == bj) {  // rotated 2x2 blocks of Q_k, stage k-1: rotQ[(k-1)*6 + .]
+            r[4 + nb] = L.rotQ - 6 + bi * 3 + ((i == 1 || i == 5) ? 1 : 0) + ((j == 1 || j == 5) ? 1 : 0); r[7 + nb] = 6; ++nb;
+        } else if (i == j) {
+            lc[lane * 2 + 0] = 2.0 * m->h_prm[PRM_W + 10 + i];
+        }
+        const int pi = pv_inv_h(i), pj = pv_inv_h(j);
+        if (pi >= 0 && pj >= 0) {   // collision Hessian, stage k-1: H6[(k-1)*21 + .]
+            r[4 + nb] = L.H6 - 21 + (pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi); r[7 + nb] = 21; ++nb;
+        }
+        lc[lane * 2 + 1] = (i == j) ? 1.0 : 0.0;  // + delta on the diagonal
+        r[10] = L.P + i * 10 + j; r[11] = L.P + j * 10 + i;
+        if (i == j) r[12] = i;
+    }
+    if ((int)free_lanes.size() < SD) return AMK_ERR_UNSUPPORTED;
+    for (int i = 0; i < SD; ++i) {  // p_k[i] = (q_k + A'p)[i] - G(:,i)' Hm^-1 qu
+        const int lane = free_lanes[i];
+        int *r = lm + lane * LANE_META_INTS;
+        r[0] = L.G + i; r[1] = 10; r[2] = L.qu; r[3] = 1;
+        r[4] = L.Atp + i; r[7] = 0;
+        r[10] = L.p + i; r[11] = L.p + i;
+        if (i == 0) r[12] = SD;  // feed-forward column
+    }
+    for (int i = 0; i < SD; ++i) {  // lam_k = q_k + A'lam_{k+1}: a copy, ridden by lanes 0..9
+        int *r = lm + i * LANE_META_INTS;
+        r[13] = L.Atl + i; r[14] = L.lam + i;
     }
     return AMK_OK;
 }
 
 int upload_params(amk_mpc *m) {
     static_assert(sizeof(PlanItemMeta) == sizeof(int) * (PLAN_TERMS + 4), "PlanItemMeta layout");
+    static_assert(sizeof(LaneRole) == sizeof(int) * LANE_META_INTS, "LaneRole layout");
     AMK_HIP(hipMemcpy(m->prm.p, m->h_prm, sizeof(double) * PRM_LEN, hipMemcpyHostToDevice));
     std::vector<double> coef;
     std::vector<int> meta;
@@ -259,8 +313,8 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     m->lds_bytes = sizeof(double) * (size_t)LdsMap(N).total;
     hipError_t e;
     if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess ||
-        (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * PLAN_TERMS)) != hipSuccess ||
-        (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4))) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
+        (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2)) != hipSuccess ||
+        (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = hipFuncSetAttribute(N == 10   ? (const void *)mpc_solve_kernel<10>
                                  : N == 20 ? (const void *)mpc_solve_kernel<20>
