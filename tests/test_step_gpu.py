@@ -70,11 +70,12 @@ def compare(gpu, cpu, tol=TOL):
     return worst
 
 
-@pytest.mark.parametrize("cfg,n", [("C1", 5000), ("C2", 50000)])
-def test_step_matches_oracle(cfg, n, torch_cuda):
+@pytest.mark.parametrize("cfg,n,scenes", [("C1", 5000, 12), ("C2", 50000, 12), ("C5", 200000, 4)])
+def test_step_matches_oracle(cfg, n, scenes, torch_cuda):
+    """BASELINE configs at their full sizes (C5 = 200k-point cloud + 20k-point edge cloud, N = 30), fp64."""
     c = synth.CONFIGS[cfg]
     prm = synth.MpcParams(T=c["T"], K=c["K"])
-    scenes = [synth.make_scene(n, 300 + i, prm) for i in range(12)]
+    scenes = [synth.make_scene(n, 300 + i, prm) for i in range(scenes)]
     gpu, cpu = run_both(torch_cuda, scenes, prm, n_steps=2)    # second step: warm start carried over
     w = compare(gpu, cpu)
     print(f"{cfg}: worst |gpu - oracle| = {w:.3e}; solves/step = {[r['flags'][1] for r in cpu[0]]}")
