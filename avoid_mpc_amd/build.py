@@ -38,6 +38,8 @@ def _deps():
 def build(force=False, verbose=False, extra_flags=()):
     if os.environ.get("AMK_SOLVE_TRACE"):
         extra_flags = tuple(extra_flags) + ("-DAMK_SOLVE_TRACE",)
+    if os.environ.get("AMK_HIPCC_FLAGS"):  # experiments only (e.g. -DAMK_SOLVE_WAVES=4)
+        extra_flags = tuple(extra_flags) + tuple(os.environ["AMK_HIPCC_FLAGS"].split())
     os.makedirs(OBJ, exist_ok=True)
     dep_mtime = max(os.path.getmtime(h) for h in _deps())
     objs, relink = [], force or not os.path.exists(LIB)

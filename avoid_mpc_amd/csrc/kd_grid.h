@@ -17,6 +17,7 @@ namespace amk {
 
 constexpr int kGridMaxCells = 8192;
 constexpr int kGridBuildThreads = 1024;
+constexpr int kGridUnroll = 4;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz
 
 // ------------------------------------------------------------------------------------------------
@@ -89,13 +90,24 @@ static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel
     const int ncell = g0 * g1 * g2;  // + one trash bucket (index ncell) for non-finite points
     for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) hist[i] = 0;
     __syncthreads();
-    // 3. histogram
-    for (int i = tid; i < n; i += kGridBuildThreads) {
-        const float x = xs[i], y = ys[i], z = zs[i];
-        int c = ncell;
-        if (finite3(x, y, z))
-            c = (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0);
-        atomicAdd(&hist[c], 1);
+    // 3. histogram.  Both point passes load kGridUnroll points per thread before touching them: with one
+    // 1024-thread block per CU the loop is bound by load latency, not bandwidth, unless several loads are in flight.
+    auto cell_id = [&](float x, float y, float z) {
+        return finite3(x, y, z)
+                   ? (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0)
+                   : ncell;
+    };
+    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
+        float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
+#pragma unroll
+        for (int j = 0; j < kGridUnroll; ++j) {
+            const int i = i0 + j * kGridBuildThreads;
+            const int ii = i < n ? i : i0;
+            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
+        }
+#pragma unroll
+        for (int j = 0; j < kGridUnroll; ++j)
+            if (i0 + j * kGridBuildThreads < n) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
     }
     __syncthreads();
     // 4. exclusive scan of hist[0 .. ncell] -> bucket starts (global) and scatter cursors (LDS)
@@ -128,13 +140,22 @@ static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel
     __syncthreads();
     // 5. scatter into bucket-contiguous order (order inside a bucket is irrelevant: results are ordered by
     // (distance, original index))
-    for (int i = tid; i < n; i += kGridBuildThreads) {
-        const float x = xs[i], y = ys[i], z = zs[i];
-        int c = ncell;
-        if (finite3(x, y, z))
-            c = (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0);
-        const int pos = atomicAdd(&hist[c], 1);
-        gpt4[pos] = make_float4(x, y, z, __int_as_float(i));  // one 16-byte store per point
+    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
+        float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
+#pragma unroll
+        for (int j = 0; j < kGridUnroll; ++j) {
+            const int i = i0 + j * kGridBuildThreads;
+            const int ii = i < n ? i : i0;
+            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
+        }
+#pragma unroll
+        for (int j = 0; j < kGridUnroll; ++j) {
+            const int i = i0 + j * kGridBuildThreads;
+            if (i < n) {
+                const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(i));  // one 16-byte store per point
+            }
+        }
     }
 }
 

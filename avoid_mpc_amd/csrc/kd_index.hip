@@ -83,47 +83,63 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
     int n = counts ? counts[s] : max_points;
     n = n < 0 ? 0 : (n > max_points ? max_points : n);
 
-    __shared__ int wave_tot[kCompactThreads / kWave];
-    __shared__ float wave_max[kCompactThreads / kWave];
-    __shared__ float wave_bb[6][kCompactThreads / kWave];
+    constexpr int NW = kCompactThreads / kWave;
+    constexpr int UNR = 4;  // points per thread per round: 12 independent loads in flight, one barrier pair per 4096 points
+    __shared__ int wave_tot[UNR][NW];
+    __shared__ float wave_max[NW];
+    __shared__ float wave_bb[6][NW];
     float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
     float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};  // bbox of the finite points
     int base = 0;
-    for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
-        const int i = c0 + tid;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        bool valid = false;
-        if (i < n) {
-            const float *p = src + (size_t)i * point_stride;
-            px = p[0];
-            py = p[1];
-            pz = p[2];
-            valid = !(px != px);  // only x is tested by the reference
-        }
-        const unsigned long long m = __ballot(valid);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        if (lane == 0) wave_tot[w] = __popcll(m);
-        __syncthreads();
-        int woff = 0, tot = 0;
+    for (int c0 = 0; c0 < n; c0 += UNR * kCompactThreads) {
+        float px[UNR], py[UNR], pz[UNR];
+        bool valid[UNR];
+        int prefix[UNR];
 #pragma unroll
-        for (int j = 0; j < kCompactThreads / kWave; ++j) {
-            const int t = wave_tot[j];
-            woff += (j < w) ? t : 0;
-            tot += t;
-        }
-        if (valid) {
-            const int o = base + woff + prefix;
-            xs[o] = px;
-            ys[o] = py;
-            zs[o] = pz;
-            amax = fmaxf(amax, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
-            if (amk::finite3(px, py, pz)) {
-                bmn[0] = fminf(bmn[0], px); bmx[0] = fmaxf(bmx[0], px);
-                bmn[1] = fminf(bmn[1], py); bmx[1] = fmaxf(bmx[1], py);
-                bmn[2] = fminf(bmn[2], pz); bmx[2] = fmaxf(bmx[2], pz);
+        for (int j = 0; j < UNR; ++j) {
+            const int i = c0 + j * kCompactThreads + tid;
+            px[j] = py[j] = pz[j] = 0.f;
+            if (i < n) {
+                const float *p = src + (size_t)i * point_stride;
+                px[j] = p[0];
+                py[j] = p[1];
+                pz[j] = p[2];
             }
         }
-        base += tot;
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            const int i = c0 + j * kCompactThreads + tid;
+            valid[j] = i < n && !(px[j] != px[j]);  // only x is tested by the reference
+            const unsigned long long m = __ballot(valid[j]);
+            prefix[j] = __popcll(m & ((1ull << lane) - 1ull));
+            if (lane == 0) wave_tot[j][w] = __popcll(m);
+        }
+        __syncthreads();
+        int run = base;
+#pragma unroll
+        for (int j = 0; j < UNR; ++j) {
+            int woff = 0, tot = 0;
+#pragma unroll
+            for (int ww = 0; ww < NW; ++ww) {
+                const int t = wave_tot[j][ww];
+                woff += (ww < w) ? t : 0;
+                tot += t;
+            }
+            if (valid[j]) {
+                const int o = run + woff + prefix[j];
+                xs[o] = px[j];
+                ys[o] = py[j];
+                zs[o] = pz[j];
+                amax = fmaxf(amax, fmaxf(fabsf(px[j]), fmaxf(fabsf(py[j]), fabsf(pz[j]))));
+                if (amk::finite3(px[j], py[j], pz[j])) {
+                    bmn[0] = fminf(bmn[0], px[j]); bmx[0] = fmaxf(bmx[0], px[j]);
+                    bmn[1] = fminf(bmn[1], py[j]); bmx[1] = fmaxf(bmx[1], py[j]);
+                    bmn[2] = fminf(bmn[2], pz[j]); bmx[2] = fmaxf(bmx[2], pz[j]);
+                }
+            }
+            run += tot;
+        }
+        base = run;
         __syncthreads();
     }
     const float qnan = __builtin_nanf("");
@@ -149,13 +165,13 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
     __syncthreads();
     if (tid == 0) {
         float m = 0.f;
-        for (int j = 0; j < kCompactThreads / kWave; ++j) m = fmaxf(m, wave_max[j]);
+        for (int j = 0; j < NW; ++j) m = fmaxf(m, wave_max[j]);
         size_out[s] = base;
         pmax_out[s] = m;
     }
     if (tid < 6) {
         float v = wave_bb[tid][0];
-        for (int j = 1; j < kCompactThreads / kWave; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
+        for (int j = 1; j < NW; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
         bbox_out[6 * s + tid] = v;
     }
 }

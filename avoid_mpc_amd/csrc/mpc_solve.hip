@@ -211,9 +211,15 @@ int upload_params(amk_mpc *m) {
 static double *g_trace = nullptr;
 extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
 
+#ifndef AMK_SOLVE_WAVES
+#define AMK_SOLVE_WAVES 2  // waves per SIMD the register budget is set for (256 VGPRs each)
+#endif
+#ifndef AMK_SOLVE_LDS_MIN
+#define AMK_SOLVE_LDS_MIN 0
+#endif
 // grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total doubles
 template <int NT>  // NT > 0: horizon baked in (LDS offsets become immediates, as the reference bakes N into its plugin)
-__global__ __launch_bounds__(64, 2) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
+__global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
                                                        SolveOpts opt, const double *__restrict__ ref_states,
                                                        double *__restrict__ w0, double *__restrict__ u_out,
                                                        double *__restrict__ x0array, int *__restrict__ info,
@@ -311,6 +317,7 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     m->opt.bound_push = 1e-3; m->opt.bound_frac = 1e-3; m->opt.kappa_mu = 0.2; m->opt.tau_min = 0.99;
     m->opt.eta_phi = 1e-8; m->opt.s_max = 100.0; m->opt.kappa_sigma = 1e10;
     m->lds_bytes = sizeof(double) * (size_t)LdsMap(N).total;
+    if (m->lds_bytes < (size_t)AMK_SOLVE_LDS_MIN) m->lds_bytes = AMK_SOLVE_LDS_MIN;
     hipError_t e;
     if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess ||
         (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2)) != hipSuccess ||
