@@ -182,13 +182,34 @@ struct GridPtrs {  // the batch: what a kernel needs to find scene s
     }
 };
 
-struct GridWaveLds {  // per-wavefront scratch: ranges of the rows of the current ring
+struct GridWaveLds {  // per-wavefront scratch: ranges of the rows of the current shell
     int pre[65];
     int sA[64], lA[64], sB[64];
 };
 
+// DPP data movement inside the wavefront (no LDS crossbar, no s_waitcnt): whole-wave shift by one lane and the
+// gfx9 inclusive-scan ladder (row_shr 1/2/4/8, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2, 3)
+__device__ __forceinline__ int wave_shr1_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ double wave_shr1_f64(double v) {
+    return __hiloint2double(wave_shr1_i32(__double2hiint(v)), wave_shr1_i32(__double2loint(v)));
+}
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
+    return v;
+}
+
 // Exact k nearest neighbours of (qx,qy,qz).  On return lane i < k holds the i-th best (squared
 // distance, index) in (ld, li); empty slots hold (DBL_MAX, kNoIndex).  Ties order by index.
+//
+// The cells are visited in Chebyshev rings around the query's cell (shell (rp, r] with r = rp + 1; two rings per
+// round were measured slower: the BASELINE clouds are dense enough that ring r + 1 is rarely needed).  Once k
+// candidates are known, a ring only visits the cells that the ball of the current k-th distance reaches: a row
+// (iy, iz) is skipped when its slab is farther than that, and its run of cells is clipped to the ball's x extent.
 __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double qy, double qz, int k, double &ld,
                                          int &li, GridWaveLds *ws) {
     const int lane = threadIdx.x & 63;
@@ -207,11 +228,12 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g[a] - 1 - c[a]));
     // rounding slack of the cell boundaries (cell_of is evaluated in fp64 on fp32 coordinates)
     const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
-    for (int r = 0; r <= rmax; ++r) {
+    int rp = -1;  // everything within Chebyshev radius rp of the query's cell has been seen
+    for (int r = 0;; ) {
         const int side = 2 * r + 1, nrows = side * side;
         for (int row0 = 0; row0 < nrows; row0 += 64) {
-            // lane -> one (iy, iz) row of the ring: a full run of cells if the row is on the ring's
-            // y/z faces, else only the two end cells ix = cx -+ r
+            // lane -> one (iy, iz) row of the shell (rp, r]: the whole run of cells x in [cx - r, cx + r] if the
+            // row lies outside the box already seen, else the two end runs left and right of that box
             const int j = row0 + lane;
             int sA = 0, lA = 0, sB = 0, lB = 0;
             if (j < nrows) {
@@ -219,39 +241,47 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                 const int iy = c[1] + dy, iz = c[2] + dz;
                 if (iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2]) {
                     const int rowbase = (iz * g[1] + iy) * g[0];
-                    const int x0 = c[0] - r, x1 = c[0] + r;
-                    if (dy == -r || dy == r || dz == -r || dz == r) {
-                        const int a0 = max(x0, 0), a1 = min(x1, g[0] - 1);
-                        if (a0 <= a1) {
-                            sA = gs.cs[rowbase + a0];
-                            lA = gs.cs[rowbase + a1 + 1] - sA;
+                    int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g[0] - 1);
+                    if (tau < DBL_MAX) {  // clip to the ball of radius sqrt(tau) (conservatively: + slack)
+                        const double ey = dy < 0 ? q[1] - (b[1] + (double)(iy + 1) * h) : (dy > 0 ? (b[1] + (double)iy * h) - q[1] : 0.0);
+                        const double ez = dz < 0 ? q[2] - (b[2] + (double)(iz + 1) * h) : (dz > 0 ? (b[2] + (double)iz * h) - q[2] : 0.0);
+                        const double fy = fmax(0.0, ey - slack), fz = fmax(0.0, ez - slack);
+                        const double rem = tau * (1.0 + 1e-12) - (fy * fy + fz * fz);
+                        if (rem < 0.0) {
+                            x1 = x0 - 1;  // the whole row is out of reach
+                        } else {
+                            const double rx = sqrt(rem) * (1.0 + 1e-12) + slack;
+                            x0 = max(x0, cell_of(q[0] - rx, b[0], inv_h, g[0]));
+                            x1 = min(x1, cell_of(q[0] + rx, b[0], inv_h, g[0]));
+                        }
+                    }
+                    if (dy < -rp || dy > rp || dz < -rp || dz > rp) {
+                        if (x0 <= x1) {
+                            sA = gs.cs[rowbase + x0];
+                            lA = gs.cs[rowbase + x1 + 1] - sA;
                         }
                     } else {
-                        if (x0 >= 0) {
+                        const int a1 = min(c[0] - rp - 1, x1), b0 = max(c[0] + rp + 1, x0);
+                        if (x0 <= a1) {
                             sA = gs.cs[rowbase + x0];
-                            lA = gs.cs[rowbase + x0 + 1] - sA;
+                            lA = gs.cs[rowbase + a1 + 1] - sA;
                         }
-                        if (x1 < g[0] && r > 0) {
-                            sB = gs.cs[rowbase + x1];
+                        if (b0 <= x1) {
+                            sB = gs.cs[rowbase + b0];
                             lB = gs.cs[rowbase + x1 + 1] - sB;
                         }
                     }
                 }
             }
+            if (__ballot(lA + lB > 0) == 0) continue;  // nothing but empty buckets in these rows
             // flatten the <= 128 ranges into one index space so that every lane gets a point
-            int incl = lA + lB;
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int v = __shfl_up(incl, off);
-                if (lane >= off) incl += v;
-            }
+            const int incl = wave_incl_scan_i32(lA + lB);
             const int total = __builtin_amdgcn_readlane(incl, 63);
             ws->pre[lane] = incl - (lA + lB);
             ws->sA[lane] = sA; ws->lA[lane] = lA; ws->sB[lane] = sB;
-            for (int t0 = 0; t0 < total; t0 += 64) {
-                const int t = t0 + lane;
-                double d = __builtin_nan("");
-                int ic = kNoIndex;
+            auto fetch = [&](int t, double &d, int &ic) {
+                d = __builtin_nan("");
+                ic = kNoIndex;
                 if (t < total) {
                     int lo = 0, hi = 64;  // largest o with pre[o] <= t
 #pragma unroll
@@ -266,6 +296,12 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
                     ic = __float_as_int(p4.w);
                 }
+            };
+            double d, dn;
+            int ic, icn;
+            fetch(lane, d, ic);
+            for (int t0 = 0; t0 < total; t0 += 64) {
+                if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn);  // next batch in flight while this one is merged
                 unsigned long long m = __ballot(d <= tau);
                 while (m) {  // a lane beats (or ties) the current k-th best
                     const int src = __ffsll((long long)m) - 1;
@@ -276,8 +312,8 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     const bool lt = (lane < k) && (ld < dc || (ld == dc && li < icc));
                     const int pos = __popcll(__ballot(lt));
                     if (pos < k && dc < DBL_MAX) {
-                        const double up_d = shfl_up1_f64(ld);
-                        const int up_i = __shfl_up(li, 1);
+                        const double up_d = wave_shr1_f64(ld);
+                        const int up_i = wave_shr1_i32(li);
                         if (lane > pos) {
                             ld = up_d;
                             li = up_i;
@@ -288,6 +324,8 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                         tau = readlane_f64(ld, k - 1);
                     }
                 }
+                d = dn;
+                ic = icn;
             }
         }
         // everything within Chebyshev radius r of the query's cell has been seen.  A cell outside that box
@@ -304,6 +342,9 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             dmin = fmax(0.0, dmin - slack);
             if (tau < dmin * dmin) break;
         }
+        if (r >= rmax) break;
+        rp = r;
+        r = r + 1;
     }
 }
 
