@@ -203,6 +203,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
+    t_enq = time.perf_counter() - t0       # host time to enqueue everything (diagnostic: launch-bound if ~= dt)
     barrier()
     dt = time.perf_counter() - t0
     ms = (C.c_double * 8)(); cnt = (C.c_int * 8)()
@@ -253,7 +254,8 @@ def main():
                                    f"every step", "scenes_per_gpu": S, "points": n, "horizon": N, "K": prm.K,
                        "mpc_max_iter": prm.max_iter, "ipm_max_iter": 10,
                        "solves_per_step": round(solves, 3), "ipm_iters_per_step": round(ipm_iters, 2),
-                       "streams_in_flight": len(slots),
+                       "streams_in_flight": len(slots), "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
                        "parallelism": f"scenes sharded over {world} GPU(s); all_gather of u" if world > 1
                        else "single GPU"},
             "roofline": {"bound": "hbm", "kernel": "mpc_solve_kernel", "achieved": round(achieved, 3),
