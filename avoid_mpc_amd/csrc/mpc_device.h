@@ -61,6 +61,9 @@ struct SolveOpts {
 };
 
 // LDS carve-up for one scene (offsets in doubles).  All per-scene state of the solve lives here.
+constexpr int KK_ROW = 12;              // gains row: 10 feedback entries, the feed-forward term, one pad (16-byte rows)
+constexpr int KK_STAGE = 4 * KK_ROW;
+
 struct LdsMap {
     int prm, xinit, target, cy, sy;
     int X, U, zl, zu, dX, dU, dzl, dzu, Xt, Ut;
@@ -80,7 +83,7 @@ struct LdsMap {
         H6 = take(N * 21); rotQ = take(N * 6);
         P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
         Atp = take(SD); Atl = take(SD); qu = take(UD); Y = 0; Z = 0; D = 0;
-        Kk = take(N * 44); red = take(16);
+        Kk = take(N * KK_STAGE); red = take(16);
         total = o;
     }
 };
@@ -100,6 +103,14 @@ constexpr int DPP_XOR1 = 0xB1;         // quad_perm:[1,0,3,2]
 constexpr int DPP_XOR2 = 0x4E;         // quad_perm:[2,3,0,1]
 constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7-i inside each 8 lanes
 constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15-i inside each row of 16
+
+// 1/x to full double precision: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~4x longer)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
 
 struct OpSum { __device__ __forceinline__ static double f(double a, double b) { return a + b; } };
 struct OpMin { __device__ __forceinline__ static double f(double a, double b) { return fmin(a, b); } };
@@ -168,13 +179,13 @@ __device__ __forceinline__ double collide_point(const double p[3], const double 
     const double x = -32.0 * (rho - radius);
     const double ex = exp(x);
     const double g = log(1.0 + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
-    const double ir = 1.0 / rho;
+    const double ir = fast_rcp(rho);
     const double n[3] = {d0 * ir, d1 * ir, d2 * ir};
     const double s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
     const double as = fabs(s);
     const double cost = lam * g * as;
     if (!DERIV) return cost;
-    const double sg = ex / (1.0 + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
+    const double sg = ex * fast_rcp(1.0 + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
     const double gp = -32.0 * sg;
     const double gpp = 1024.0 * sg * (1.0 - sg);
     const double sgn = (s > 0.0) ? 1.0 : ((s < 0.0) ? -1.0 : 0.0);
@@ -186,7 +197,7 @@ __device__ __forceinline__ double collide_point(const double p[3], const double 
         unsafeAtomicAdd(gq + 4 + i, ls * g * n[i]);                                // state slots 4,5,6 = v
     }
     const double gs[6] = {-t[0] * ir, -t[1] * ir, -t[2] * ir, n[0], n[1], n[2]};
-    const double wk = lam * g / (as > kAbsEps ? as : kAbsEps);
+    const double wk = lam * g * fast_rcp(as > kAbsEps ? as : kAbsEps);
     // lower triangle, row-major: (i,j), j <= i, index i(i+1)/2 + j
 #pragma unroll
     for (int i = 0; i < 6; ++i)
@@ -354,16 +365,8 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
     lp.bdelta = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane + 1];
 }
 
-// 1/x to full double precision: v_rcp_f64 + two Newton steps (the IEEE division sequence is ~4x longer)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
 // Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
-// control block is not positive definite.  Gains go to L.Kk ([k][a*11 + j], column 10 = feed-forward).
+// control block is not positive definite.  Gains go to L.Kk ([k][a*KK_ROW + j], column 10 = feed-forward).
 //
 // A stage is two LDS rounds.  Both are straight-line code (every lane runs the same instructions on its own
 // host-built indices) so that the loads of a round are all in flight before the first dependent fp64 op: this
@@ -440,8 +443,8 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
             const double base = (fma(lp.bdelta, delta, lp.bconst) + b0) + (b1 + b2);
             const double val = fma(-t, rd, fma(-gi[3], u3, base));
             if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward)
-                double *kk = sm + L.Kk + k * 44 + R.gain_col;
-                kk[0] = -u0 * rd; kk[11] = -u1 * rd; kk[22] = -u2 * rd; kk[33] = -u3;
+                double *kk = sm + L.Kk + k * KK_STAGE + R.gain_col;
+                kk[0] = -u0 * rd; kk[KK_ROW] = -u1 * rd; kk[2 * KK_ROW] = -u2 * rd; kk[3 * KK_ROW] = -u3;
             }
             if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
                 sm[R.out1] = val;
@@ -454,9 +457,9 @@ __device__ __forceinline__ bool riccati_backward(double *sm, const LdsMap &L, co
     return true;
 }
 
-// forward roll of the Newton step, entirely in registers: lane i < 10 carries dX_k[i]; the values a
-// lane needs from other lanes are wave-uniform broadcasts (v_readlane), no LDS round trip per stage.
-// dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k
+// forward roll of the Newton step: dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k.
+// Lane i < 10 owns dX[i], lane a < 4 owns dU[a]; a stage is two LDS broadcasts (dX_k to every lane, then dU_k).
+// The v_readlane version of the same exchange cost 56 VALU issue slots per stage -- more than its arithmetic.
 __device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int N) {
     const int lane = threadIdx.x;
     const double *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
@@ -467,17 +470,17 @@ __device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int
 #pragma unroll
     for (int j = 0; j < UD; ++j) brow[j] = B[row * UD + j];
     const int a = lane < UD ? lane : 0;
-    double dx = 0.0;  // dX_k[lane]
     if (lane < SD) sm[L.dX + lane] = 0.0;
+    __syncthreads();
 #pragma unroll 1
     for (int k = 0; k < N; ++k) {
-        const double *kk = sm + L.Kk + k * 44 + a * 11;
-        double krow[SD + 1];
+        const double *kk = sm + L.Kk + k * KK_STAGE + a * KK_ROW;
+        const double *xk = sm + L.dX + k * SD;
+        double krow[SD + 1], xs[SD];
 #pragma unroll
         for (int j = 0; j <= SD; ++j) krow[j] = kk[j];
-        double xs[SD];
 #pragma unroll
-        for (int j = 0; j < SD; ++j) xs[j] = readlane_f64(dx, j);
+        for (int j = 0; j < SD; ++j) xs[j] = xk[j];
         // partial sums: four short dependent chains instead of one of ten
         double d0 = fma(krow[0], xs[0], krow[SD]), d1 = krow[1] * xs[1], d2 = krow[2] * xs[2], d3 = krow[3] * xs[3];
         d0 = fma(krow[4], xs[4], d0); d1 = fma(krow[5], xs[5], d1); d2 = fma(krow[6], xs[6], d2);
@@ -487,12 +490,13 @@ __device__ __forceinline__ void riccati_forward(double *sm, const LdsMap &L, int
         double a0 = arow[0] * xs[0], a1 = arow[1] * xs[1], a2 = arow[2] * xs[2], a3 = arow[3] * xs[3];
         a0 = fma(arow[4], xs[4], a0); a1 = fma(arow[5], xs[5], a1); a2 = fma(arow[6], xs[6], a2);
         a3 = fma(arow[7], xs[7], a3); a0 = fma(arow[8], xs[8], a0); a1 = fma(arow[9], xs[9], a1);
-        a2 = fma(brow[0], readlane_f64(du, 0), a2); a3 = fma(brow[1], readlane_f64(du, 1), a3);
-        a0 = fma(brow[2], readlane_f64(du, 2), a0); a1 = fma(brow[3], readlane_f64(du, 3), a1);
-        dx = (a0 + a1) + (a2 + a3);
-        if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = dx;
+        __syncthreads();
+        const double *uk = sm + L.dU + k * UD;
+        a2 = fma(brow[0], uk[0], a2); a3 = fma(brow[1], uk[1], a3);
+        a0 = fma(brow[2], uk[2], a0); a1 = fma(brow[3], uk[3], a1);
+        if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
     }
-    __syncthreads();
 }
 
 // The whole solve for one scene.  w0/w_out: decision vector [X_0,U_0,...,U_{N-1},X_N] in global
@@ -573,8 +577,9 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
             const int i = e % UD;
             const double u = sm[L.U + e];
             const double sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
-            sm[L.rb + e] = sm[L.r + e] - mu / sl + mu / su;
-            sm[L.Rb + e] = 2.0 * prm[PRM_W + 20 + i] + sm[L.zl + e] / sl + sm[L.zu + e] / su;
+            const double isl = fast_rcp(sl), isu = fast_rcp(su);
+            sm[L.rb + e] = sm[L.r + e] - mu * isl + mu * isu;
+            sm[L.Rb + e] = 2.0 * prm[PRM_W + 20 + i] + sm[L.zl + e] * isl + sm[L.zu + e] * isu;
         }
         __syncthreads();
         double delta = 0.0;
@@ -619,16 +624,19 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
             const int i = e % UD;
             const double u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e], du = sm[L.dU + e];
             const double sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
-            const double dzl = mu / sl - zl - (zl / sl) * du;
-            const double dzu = mu / su - zu + (zu / su) * du;
+            const double isl = fast_rcp(sl), isu = fast_rcp(su);
+            const double dzl = mu * isl - zl - (zl * isl) * du;
+            const double dzu = mu * isu - zu + (zu * isu) * du;
             sm[L.dzl + e] = dzl;
             sm[L.dzu + e] = dzu;
-            if (du < 0.0) a_pr = fmin(a_pr, -tau * sl / du);
-            if (du > 0.0) a_pr = fmin(a_pr, tau * su / du);
-            if (dzl < 0.0) a_du = fmin(a_du, -tau * zl / dzl);
-            if (dzu < 0.0) a_du = fmin(a_du, -tau * zu / dzu);
-            dphi += (sm[L.gU + e] - mu / sl + mu / su) * du;
-            phi0 -= mu * (log(sl) + log(su));
+            // fraction to the boundary: one reciprocal per ratio, only the binding side of each bound
+            const double idu = fast_rcp(du);
+            if (du < 0.0) a_pr = fmin(a_pr, -tau * sl * idu);
+            if (du > 0.0) a_pr = fmin(a_pr, tau * su * idu);
+            if (dzl < 0.0) a_du = fmin(a_du, -tau * zl * fast_rcp(dzl));
+            if (dzu < 0.0) a_du = fmin(a_du, -tau * zu * fast_rcp(dzu));
+            dphi += (sm[L.gU + e] - mu * isl + mu * isu) * du;
+            phi0 -= mu * log(sl * su);  // both slacks are positive and bounded by the box: no overflow
         }
         a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi); phi0 = J + wave_sum(phi0);
         // backtracking Armijo line search on the barrier function
@@ -645,7 +653,7 @@ __device__ __forceinline__ void solve_scene(double *sm, const LdsMap &L, int N, 
             for (int e = lane; e < nvar; e += 64) {
                 const int i = e % UD;
                 const double u = sm[L.Ut + e];
-                lg -= mu * (log(u - prm[PRM_LB + i]) + log(prm[PRM_UB + i] - u));
+                lg -= mu * log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
             }
             phi += wave_sum(lg);
             if (phi <= phi0 + opt.eta_phi * a * dphi) { accepted = true; break; }
