@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libavoid_mpc_amd.so")
 
-AMK_OK = 0
+AMK_OK, AMK_ERR_INVALID_ARG, AMK_ERR_HIP, AMK_ERR_NO_DEVICE, AMK_ERR_UNSUPPORTED = 0, 1, 2, 3, 4   # include/avoid_mpc_amd.h
 AMK_MAX_K = 64
 AMK_MAX_QUERIES = 64
 AMK_MAX_HORIZON = 32
@@ -23,7 +23,7 @@ SYMBOLS = [
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
-    "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_solve",
+    "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_step_batch", "amk_step_batch_host",
 ]
@@ -85,6 +85,7 @@ def load():
         "amk_mpc_set_drone_radius": (i, [vp, d]),
         "amk_mpc_set_drone_accel_limits": (i, [vp, d, d, d, d]),
         "amk_mpc_set_solver_options": (i, [vp, d, i]),
+        "amk_mpc_set_precision": (i, [vp, i]),
         "amk_mpc_solve": (i, [vp, vp, vp, vp, vp, i, vp]),
         "amk_mpc_get_warm_start": (i, [vp, vp, vp]),
         "amk_mpc_set_warm_start": (i, [vp, vp, vp]),

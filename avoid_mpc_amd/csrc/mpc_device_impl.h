@@ -1,0 +1,589 @@
+// Type-generic body of the MPC device algorithm; included twice by mpc_device.h (AMK_REAL = double in namespace
+// amk, float in namespace amk32).  `real` is the arithmetic type of the NLP evaluation and the interior-point
+// method and the element type of the LDS scratchpad; everything that crosses global memory (parameters, P,
+// warm start, outputs, plan coefficients) stays double.  RL(x) is a literal of type real.
+namespace AMK_RNS {
+using namespace amk;
+typedef AMK_REAL real;
+#define RL(x) ((real)(x))
+constexpr real kGz = RL(9.81);   // mpc_obstacle_casadi.py:39
+constexpr real kAbsEps = RL(1e-3);
+
+// ---- cross-lane reductions on DPP (no LDS crossbar): quad_perm for lane^1 / lane^2, row_half_mirror and
+// row_mirror for the 8- and 16-lane levels (valid because every lane of the lower level already holds
+// that level's result), v_readlane for the four rows.  __shfl_xor would be two ds_bpermute_b32 + a wait
+// per double per level; the collision Hessian reduction alone is 28 values x 3 levels x 3 rounds.
+template <int CTRL>
+__device__ __forceinline__ real dpp_r(real v) {
+#if AMK_REAL_F32
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+#else
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+#endif
+}
+__device__ __forceinline__ real readlane_r(real v, int l) {
+#if AMK_REAL_F32
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+#else
+    return amk::readlane_f64(v, l);
+#endif
+}
+
+// 1/x to working precision: v_rcp + Newton steps (the IEEE division sequence is ~4x longer)
+__device__ __forceinline__ real fast_rcp(real x) {
+#if AMK_REAL_F32
+    real r = __builtin_amdgcn_rcpf(x);
+    r = fma(fma(-x, r, 1.0f), r, r);
+#else
+    real r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+#endif
+    return r;
+}
+
+struct OpSum { __device__ __forceinline__ static real f(real a, real b) { return a + b; } };
+struct OpMin { __device__ __forceinline__ static real f(real a, real b) { return fmin(a, b); } };
+struct OpMax { __device__ __forceinline__ static real f(real a, real b) { return fmax(a, b); } };
+
+template <class Op>
+__device__ __forceinline__ real row_reduce(real v) {  // every lane of a 16-lane row gets the row result
+    v = Op::f(v, dpp_r<DPP_XOR1>(v));
+    v = Op::f(v, dpp_r<DPP_XOR2>(v));
+    v = Op::f(v, dpp_r<DPP_HALF_MIRROR>(v));
+    v = Op::f(v, dpp_r<DPP_MIRROR>(v));
+    return v;
+}
+template <class Op>
+__device__ __forceinline__ real wave_reduce(real v) {
+    v = row_reduce<Op>(v);
+    const real r0 = readlane_r(v, 0), r1 = readlane_r(v, 16), r2 = readlane_r(v, 32), r3 = readlane_r(v, 48);
+    return Op::f(Op::f(r0, r1), Op::f(r2, r3));
+}
+__device__ __forceinline__ real wave_sum(real v) { return wave_reduce<OpSum>(v); }
+__device__ __forceinline__ real wave_min(real v) { return wave_reduce<OpMin>(v); }
+__device__ __forceinline__ real wave_max(real v) { return wave_reduce<OpMax>(v); }
+
+// sum over aligned segments of `seg` (power of two) consecutive lanes; every lane gets its segment's sum
+__device__ __forceinline__ real seg_sum(real v, int seg) {
+    if (seg >= 2) v += dpp_r<DPP_XOR1>(v);
+    if (seg >= 4) v += dpp_r<DPP_XOR2>(v);
+    if (seg >= 8) v += dpp_r<DPP_HALF_MIRROR>(v);
+    if (seg >= 16) v += dpp_r<DPP_MIRROR>(v);
+    if (seg >= 32) v += __shfl_xor(v, 16);
+    if (seg >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+// ---- one obstacle term: its cost is returned; when DERIV its gradient (6) and model Hessian (21 unique,
+// row-major lower triangle of the (p,v) 6x6 block) are ADDED to the stage's LDS cells with ds_add_f64 --
+// no per-lane accumulators (they were the register peak of the kernel) and no cross-lane reduction.
+// Lanes of one wave-instruction that hit the same cell are applied in lane order, so the sums are
+// reproducible.  Mirrors oracle collide_point statement by statement.
+template <bool DERIV>
+__device__ __forceinline__ real collide_point(const real p[3], const real v[3], const real o[3], real lam,
+                                                real radius, real *gq, real *h21) {
+    const real d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
+    const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const real x = -RL(32.0) * (rho - radius);
+    const real ex = exp(x);
+    const real g = log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
+    const real ir = fast_rcp(rho);
+    const real n[3] = {d0 * ir, d1 * ir, d2 * ir};
+    const real s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+    const real as = fabs(s);
+    const real cost = lam * g * as;
+    if (!DERIV) return cost;
+    const real sg = ex * fast_rcp(RL(1.0) + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
+    const real gp = -RL(32.0) * sg;
+    const real gpp = RL(1024.0) * sg * (RL(1.0) - sg);
+    const real sgn = (s > RL(0.0)) ? RL(1.0) : ((s < RL(0.0)) ? -RL(1.0) : RL(0.0));
+    const real t[3] = {v[0] - s * n[0], v[1] - s * n[1], v[2] - s * n[2]};
+    const real ls = lam * sgn;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        unsafeAtomicAdd(gq + i, ls * (gp * (-n[i]) * s + g * (-t[i] * ir)));       // state slots 0,1,2 = p
+        unsafeAtomicAdd(gq + 4 + i, ls * g * n[i]);                                // state slots 4,5,6 = v
+    }
+    const real gs[6] = {-t[0] * ir, -t[1] * ir, -t[2] * ir, n[0], n[1], n[2]};
+    const real wk = lam * g * fast_rcp(as > kAbsEps ? as : kAbsEps);
+    // lower triangle, row-major: (i,j), j <= i, index i(i+1)/2 + j
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            real h = wk * gs[i] * gs[j];
+            if (i < 3) {  // pp block
+                const real nn = n[i] * n[j];
+                const real Pn = (i == j ? RL(1.0) : RL(0.0)) - nn;
+                h += ls * (gpp * nn * s + gp * Pn * ir * s + gp * (n[i] * t[j] * ir + t[i] * ir * n[j]) +
+                           g * (-(t[i] * n[j] + n[i] * t[j]) * ir * ir - s * Pn * ir * ir));
+            } else if (j < 3) {  // vp block: H[v_i][p_j] = Hpv[j][i-3] (symmetric expression)
+                const int a = i - 3;
+                const real nn = n[a] * n[j];
+                const real Pn = (a == j ? RL(1.0) : RL(0.0)) - nn;
+                h += ls * (-gp * nn - g * Pn * ir);
+            }
+            unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
+        }
+    return cost;
+}
+
+// Evaluate the objective on (Xs, Us) held in LDS.  DERIV: also q, r, H6 (36 per stage, full
+// symmetric), rotQ.  Returns J (wave-uniform).  One wave; caller syncs before/after.
+template <bool DERIV>
+__device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, int Kpad, const real *Xs,
+                           const real *Us, long long *tclk = nullptr) {
+    const int lane = threadIdx.x;
+    const real *prm = sm + L.prm;
+    const real lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
+    real Jloc = RL(0.0);
+    // ---- collision terms: lane = (stage, obstacle point), 64 terms per round
+    if (DERIV) {  // the cells the terms add into
+        for (int e = lane; e < (N - 1) * 21; e += 64) sm[L.H6 + e] = RL(0.0);
+        for (int e = lane; e < (N - 1) * 6; e += 64) sm[L.q + (e / 6 + 1) * SD + pv_of(e % 6)] = RL(0.0);
+        __syncthreads();
+    }
+    const long long tc0 = AMK_CLK();
+    const int nterm = (N - 1) * K;
+    for (int t0 = 0; t0 < nterm; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < nterm) {
+            const int k = t / K;
+            const real *xk = Xs + (k + 1) * SD;
+            const real p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
+            const double *op = io.obs + (size_t)t * 3;  // [k][j][3]
+            const real o[3] = {(real)op[0], (real)op[1], (real)op[2]};
+            Jloc += collide_point<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
+        }
+    }
+    if (kTrace && tclk) tclk[0] += AMK_CLK() - tc0;
+    if (DERIV) __syncthreads();
+    const long long tc3 = AMK_CLK();
+    // ---- per-stage quadratic terms: lane = stage
+    if (lane < N) {
+        const int k = lane;
+        const real *uk = Us + k * UD;
+        const real *xk = Xs + (k + 1) * SD;
+        const real uref[4] = {RL(0.0), RL(0.0), kGz, RL(0.0)};
+#pragma unroll
+        for (int i = 0; i < UD; ++i) {
+            const real du = uk[i] - uref[i];
+            const real w = prm[PRM_W + 20 + i];
+            Jloc += du * w * du;  // :209-210
+            if (DERIV) sm[L.r + k * UD + i] = RL(2.0) * w * du;
+        }
+        if (k >= N - 1) {  // goal stage :168-170
+            const real *tg = sm + L.target;
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+                const real d = xk[i] - tg[i];
+                const real w = prm[PRM_W + i];
+                Jloc += d * w * d;
+                if (DERIV) sm[L.q + (k + 1) * SD + i] = RL(2.0) * w * d;
+            }
+        } else {  // path stage :171-208
+            const double *rf = io.ref + k * SD;
+            const real cy = sm[L.cy + k], sy = sm[L.sy + k];
+            real d[SD], y[SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i) { d[i] = xk[i] - (real)rf[i]; y[i] = d[i]; }
+            y[0] = cy * d[0] - sy * d[1];
+            y[1] = sy * d[0] + cy * d[1];
+            y[4] = cy * d[4] - sy * d[5];
+            y[5] = sy * d[4] + cy * d[5];
+            real wy[SD];
+#pragma unroll
+            for (int i = 0; i < SD; ++i) {
+                const real w = prm[PRM_W + 10 + i];
+                Jloc += y[i] * w * y[i];
+                wy[i] = RL(2.0) * w * y[i];
+            }
+            if (DERIV) {
+                real qq[SD];
+#pragma unroll
+                for (int i = 0; i < SD; ++i) qq[i] = wy[i];
+                qq[0] = cy * wy[0] + sy * wy[1];
+                qq[1] = -sy * wy[0] + cy * wy[1];
+                qq[4] = cy * wy[4] + sy * wy[5];
+                qq[5] = -sy * wy[4] + cy * wy[5];
+                real *qk = sm + L.q + (k + 1) * SD;
+#pragma unroll
+                for (int i = 0; i < SD; ++i) {
+                    const bool inpv = (i < 3) || (i >= 4 && i <= 6);
+                    qk[i] = qq[i] + (inpv ? qk[i] : RL(0.0));
+                }
+            }
+        }
+    }
+    if (kTrace && tclk) tclk[2] += AMK_CLK() - tc3;
+    return wave_sum(Jloc);
+}
+
+struct LanePlan {                // the two items + the role of this lane, in registers for one backward sweep
+    real coef[2][PLAN_TERMS + 1];
+    int idx[2][PLAN_TERMS];
+    int out[2], out_kstride[2], aux[2], aux_kstride[2];
+    LaneRole role;
+    real bconst, bdelta;
+};
+
+__device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_coef, const int *plan_meta) {
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e = lane + 64 * h;
+        const PlanItemMeta *m = reinterpret_cast<const PlanItemMeta *>(plan_meta) + e;
+#pragma unroll
+        for (int t = 0; t < PLAN_TERMS; ++t) lp.idx[h][t] = m->idx[t];
+#pragma unroll
+        for (int t = 0; t <= PLAN_TERMS; ++t) lp.coef[h][t] = plan_coef[e * (PLAN_TERMS + 1) + t];
+        lp.out[h] = m->out; lp.out_kstride[h] = m->out_kstride; lp.aux[h] = m->aux; lp.aux_kstride[h] = m->aux_kstride;
+    }
+    lp.role = reinterpret_cast<const LaneRole *>(plan_meta + PLAN_ITEMS * (PLAN_TERMS + 4))[lane];
+    lp.bconst = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane];
+    lp.bdelta = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane + 1];
+}
+
+// Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
+// control block is not positive definite.  Gains go to L.Kk ([k][a*KK_ROW + j], column 10 = feed-forward).
+//
+// A stage is two LDS rounds.  Both are straight-line code (every lane runs the same instructions on its own
+// host-built indices) so that the loads of a round are all in flight before the first dependent fp64 op: this
+// sweep is a chain of dependent fp64 operations (32 cycles each here) and LDS round trips, nothing else.
+__device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, const double *plan_coef,
+                                                 const int *plan_meta, int N, real delta) {
+    const int lane = threadIdx.x;
+    // the lane's plan is (re)loaded per sweep -- L2-resident words -- instead of being held for the whole
+    // solve: it is dead weight (~90 VGPRs) during the objective evaluation, which sets the register peak
+    LanePlan lp;
+    load_lane_plan(lp, plan_coef, plan_meta);
+    real *P = sm + L.P, *pv = sm + L.p, *lam = sm + L.lam;
+    // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
+    for (int e = lane; e < 100; e += 64) {
+        const int i = e / 10, j = e % 10;
+        P[e] = (i == j) ? RL(2.0) * sm[L.prm + PRM_W + i] + delta : RL(0.0);
+    }
+    if (lane < SD) {
+        pv[lane] = sm[L.q + N * SD + lane];
+        lam[lane] = pv[lane];
+    }
+    if (lane == 0) sm[L.red + 10] = RL(0.0);  // the zero cell of the plan
+    __syncthreads();
+    const LaneRole &R = lp.role;
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; --k) {
+        // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, q + A'lam,
+        // r_bar + B'p, r + B'lam)
+        {
+            real v[2][PLAN_TERMS], ax[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                for (int t = 0; t < PLAN_TERMS; ++t) v[h][t] = sm[lp.idx[h][t]];
+                ax[h] = sm[lp.aux[h] + k * lp.aux_kstride[h]];
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                // four partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
+                const real *c = lp.coef[h];
+                real a0 = c[0] * v[h][0], a1 = c[1] * v[h][1], a2 = c[2] * v[h][2], a3 = fma(c[PLAN_TERMS], delta, ax[h]);
+                a0 = fma(c[3], v[h][3], a0); a1 = fma(c[4], v[h][4], a1); a2 = fma(c[5], v[h][5], a2);
+                a0 = fma(c[6], v[h][6], a0); a1 = fma(c[7], v[h][7], a1); a2 = fma(c[8], v[h][8], a2);
+                sm[lp.out[h] + k * lp.out_kstride[h]] = (a0 + a1) + (a2 + a3);
+            }
+        }
+        __syncthreads();
+        // ---- rounds B+C: Hm = blkdiag(3x3, h33) because the yaw chain is decoupled (build_plan checks).  With
+        // adj = adjugate of the 3x3 block:  G(:,i)' Hm^-1 g = (G(0:3,i)' adj g(0:3)) / det + G(3,i) g(3) / h33.
+        // The products with adj run beside det -> 1/det (ONE reciprocal on the critical path; an LDL' has four
+        // sequential pivots).  Positive definite <=> leading principal minors > 0, the test an LDL' makes.
+        {
+            const real *h = sm + L.Hm;  // lower: h00 h10 h11 h20 h21 h22 h30 h31 h32 h33
+            const real h00 = h[0], h10 = h[1], h11 = h[2], h20 = h[3], h21 = h[4], h22 = h[5], h33 = h[9];
+            real gi[4], gj[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                gi[a] = sm[R.gi + a * R.gi_stride];
+                gj[a] = sm[R.gj + a * R.gj_stride];
+            }
+            const real b0 = sm[R.b_idx[0] + k * R.b_ks[0]], b1 = sm[R.b_idx[1] + k * R.b_ks[1]];
+            const real b2 = sm[R.b_idx[2] + k * R.b_ks[2]];
+            const real lamv = sm[R.lam_src];
+            const real c00 = h11 * h22 - h21 * h21, c10 = h21 * h20 - h10 * h22, c20 = h10 * h21 - h11 * h20;
+            const real c11 = h00 * h22 - h20 * h20, c21 = h10 * h20 - h00 * h21, c22 = h00 * h11 - h10 * h10;
+            const real det = (h00 * c00 + h10 * c10) + h20 * c20;
+            if (!(h00 > RL(0.0) && c22 > RL(0.0) && det > RL(0.0) && h33 > RL(0.0))) return false;
+            const real rd = fast_rcp(det), r33 = fast_rcp(h33);
+            const real u0 = (c00 * gj[0] + c10 * gj[1]) + c20 * gj[2];
+            const real u1 = (c10 * gj[0] + c11 * gj[1]) + c21 * gj[2];
+            const real u2 = (c20 * gj[0] + c21 * gj[1]) + c22 * gj[2];
+            const real u3 = gj[3] * r33;
+            const real t = (gi[0] * u0 + gi[1] * u1) + gi[2] * u2;
+            const real base = (fma(lp.bdelta, delta, lp.bconst) + b0) + (b1 + b2);
+            const real val = fma(-t, rd, fma(-gi[3], u3, base));
+            if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward)
+                real *kk = sm + L.Kk + k * KK_STAGE + R.gain_col;
+                kk[0] = -u0 * rd; kk[KK_ROW] = -u1 * rd; kk[2 * KK_ROW] = -u2 * rd; kk[3 * KK_ROW] = -u3;
+            }
+            if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
+                sm[R.out1] = val;
+                sm[R.out2] = val;
+                sm[R.lam_dst] = lamv;
+            }
+        }
+        __syncthreads();
+    }
+    return true;
+}
+
+// forward roll of the Newton step: dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k.
+// Lane i < 10 owns dX[i], lane a < 4 owns dU[a]; a stage is two LDS broadcasts (dX_k to every lane, then dU_k).
+// The v_readlane version of the same exchange cost 56 VALU issue slots per stage -- more than its arithmetic.
+__device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N) {
+    const int lane = threadIdx.x;
+    const real *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
+    real arow[SD], brow[UD];  // row `lane` of A and B (lanes >= 10 idle)
+    const int row = lane < SD ? lane : 0;
+#pragma unroll
+    for (int j = 0; j < SD; ++j) arow[j] = A[row * SD + j];
+#pragma unroll
+    for (int j = 0; j < UD; ++j) brow[j] = B[row * UD + j];
+    const int a = lane < UD ? lane : 0;
+    if (lane < SD) sm[L.dX + lane] = RL(0.0);
+    __syncthreads();
+#pragma unroll 1
+    for (int k = 0; k < N; ++k) {
+        const real *kk = sm + L.Kk + k * KK_STAGE + a * KK_ROW;
+        const real *xk = sm + L.dX + k * SD;
+        real krow[SD + 1], xs[SD];
+#pragma unroll
+        for (int j = 0; j <= SD; ++j) krow[j] = kk[j];
+#pragma unroll
+        for (int j = 0; j < SD; ++j) xs[j] = xk[j];
+        // partial sums: four short dependent chains instead of one of ten
+        real d0 = fma(krow[0], xs[0], krow[SD]), d1 = krow[1] * xs[1], d2 = krow[2] * xs[2], d3 = krow[3] * xs[3];
+        d0 = fma(krow[4], xs[4], d0); d1 = fma(krow[5], xs[5], d1); d2 = fma(krow[6], xs[6], d2);
+        d3 = fma(krow[7], xs[7], d3); d0 = fma(krow[8], xs[8], d0); d1 = fma(krow[9], xs[9], d1);
+        const real du = (d0 + d1) + (d2 + d3);
+        if (lane < UD) sm[L.dU + k * UD + lane] = du;
+        real a0 = arow[0] * xs[0], a1 = arow[1] * xs[1], a2 = arow[2] * xs[2], a3 = arow[3] * xs[3];
+        a0 = fma(arow[4], xs[4], a0); a1 = fma(arow[5], xs[5], a1); a2 = fma(arow[6], xs[6], a2);
+        a3 = fma(arow[7], xs[7], a3); a0 = fma(arow[8], xs[8], a0); a1 = fma(arow[9], xs[9], a1);
+        __syncthreads();
+        const real *uk = sm + L.dU + k * UD;
+        a2 = fma(brow[0], uk[0], a2); a3 = fma(brow[1], uk[1], a3);
+        a0 = fma(brow[2], uk[2], a0); a1 = fma(brow[3], uk[3], a1);
+        if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+    }
+}
+
+// The whole solve for one scene.  w0/w_out: decision vector [X_0,U_0,...,U_{N-1},X_N] in global
+// memory (warm start in, solution out; may alias).  info[4] as in the C ABI.
+__device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
+                            const double *x_init, const double *target, const SceneIO &io, const double *w0,
+                            double *w_out, int *info, const double *plan_coef, const int *plan_meta,
+                            double *trace = nullptr) {
+    const int lane = threadIdx.x;
+    const real o_tol = (real)opt.tol, o_mu_init = (real)opt.mu_init, o_bound_push = (real)opt.bound_push, o_bound_frac = (real)opt.bound_frac, o_kappa_mu = (real)opt.kappa_mu, o_tau_min = (real)opt.tau_min, o_eta_phi = (real)opt.eta_phi, o_s_max = (real)opt.s_max, o_kappa_sigma = (real)opt.kappa_sigma;
+    int Kpad = 1;
+    while (Kpad < K) Kpad <<= 1;
+    for (int e = lane; e < PRM_LEN; e += 64) sm[L.prm + e] = (real)prm_g[e];
+    if (lane < SD) {
+        sm[L.xinit + lane] = (real)x_init[lane];
+        sm[L.target + lane] = (real)target[lane];
+    }
+    if (lane < N - 1) {  // rot of ref yaw, :174-185
+        const real yaw = (real)io.ref[lane * SD + 3];
+        sm[L.cy + lane] = cos(yaw);
+        sm[L.sy + lane] = sin(-yaw);
+    }
+    __syncthreads();
+    const real *prm = sm + L.prm;
+    for (int e = lane; e < 56 + 10 + 40; e += 64) sm[L.M + e] = RL(0.0);  // structurally-zero outputs stay zero
+    if (lane < N - 1) {  // constant part of Q on the rotated (px,py) and (vx,vy) blocks
+        const real cy = sm[L.cy + lane], sy = sm[L.sy + lane];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const real w0q = RL(2.0) * prm[PRM_W + 10 + 4 * b], w1q = RL(2.0) * prm[PRM_W + 11 + 4 * b];
+            sm[L.rotQ + lane * 6 + b * 3 + 0] = cy * cy * w0q + sy * sy * w1q;
+            sm[L.rotQ + lane * 6 + b * 3 + 1] = -cy * sy * w0q + sy * cy * w1q;
+            sm[L.rotQ + lane * 6 + b * 3 + 2] = sy * sy * w0q + cy * cy * w1q;
+        }
+    }
+    real mu = o_mu_init;
+    // warm start pushed into the interior; duals on the central path
+    for (int e = lane; e < N * UD; e += 64) {
+        const int k = e / UD, i = e % UD;
+        const real lb = prm[PRM_LB + i], ub = prm[PRM_UB + i];
+        const real pl = fmin(o_bound_push * fmax(RL(1.0), fabs(lb)), o_bound_frac * (ub - lb));
+        const real pu = fmin(o_bound_push * fmax(RL(1.0), fabs(ub)), o_bound_frac * (ub - lb));
+        real u = (real)w0[14 * k + 10 + i];
+        u = fmin(fmax(u, lb + pl), ub - pu);
+        sm[L.U + e] = u;
+        sm[L.zl + e] = mu / (u - lb);
+        sm[L.zu + e] = mu / (ub - u);
+    }
+    if (lane < SD) sm[L.X + lane] = sm[L.xinit + lane];
+    __syncthreads();
+    {  // rollout X_{k+1} = A X_k + B U_k + c
+        const real *A = prm + PRM_A, *B = prm + PRM_B, *c = prm + PRM_C;
+        for (int k = 0; k < N; ++k) {
+            if (lane < SD) {
+                real a = RL(0.0);
+#pragma unroll
+                for (int j = 0; j < SD; ++j) a += A[lane * SD + j] * sm[L.X + k * SD + j];
+#pragma unroll
+                for (int j = 0; j < UD; ++j) a += B[lane * UD + j] * sm[L.U + k * UD + j];
+                sm[L.X + (k + 1) * SD + lane] = a + c[lane];
+            }
+            __syncthreads();
+        }
+    }
+    const real mu_min = o_tol / RL(10.0);
+    real delta_last = RL(0.0), a_last = RL(0.0);
+    int status = 1, n_reg = 0, ls_fail = 0, it = 0;
+    const int nvar = UD * N;
+#pragma unroll 1
+    for (it = 0; it < opt.max_iter; ++it) {
+        const long long t0 = AMK_CLK();
+        long long tclk[3] = {0, 0, 0};
+        const real J = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U, kTrace ? tclk : nullptr);
+        __syncthreads();
+        const long long t1 = AMK_CLK();
+        if (it > 0 && a_last >= RL(0.5)) mu = fmax(mu_min, o_kappa_mu * mu);
+        const real tau = fmax(o_tau_min, RL(1.0) - mu);
+        for (int e = lane; e < nvar; e += 64) {
+            const int i = e % UD;
+            const real u = sm[L.U + e];
+            const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
+            const real isl = fast_rcp(sl), isu = fast_rcp(su);
+            sm[L.rb + e] = sm[L.r + e] - mu * isl + mu * isu;
+            sm[L.Rb + e] = RL(2.0) * prm[PRM_W + 20 + i] + sm[L.zl + e] * isl + sm[L.zu + e] * isu;
+        }
+        __syncthreads();
+        real delta = RL(0.0);
+        int reg_now = 0;
+        bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
+        while (!ok) {
+            __syncthreads();
+            if (delta == RL(0.0)) delta = (delta_last == RL(0.0)) ? RL(1e-4) : fmax(RL(1e-20), delta_last / RL(3.0));
+            else delta *= (delta_last == RL(0.0)) ? RL(100.0) : RL(8.0);
+            ++reg_now;
+            if (delta > (AMK_REAL_F32 ? RL(1e30) : RL(1e40))) break;
+            ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
+        }
+        if (!ok) { status = 2; break; }
+        // KKT error E_0 at the current iterate (gU from the adjoint sweep inside the backward pass)
+        {
+            real zs = RL(0.0), ed = RL(0.0), ec = RL(0.0);
+            for (int e = lane; e < nvar; e += 64) {
+                const int i = e % UD;
+                const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e];
+                const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
+                zs += zl + zu;
+                ed = fmax(ed, fabs(sm[L.gU + e] - zl + zu));
+                ec = fmax(ec, fmax(fabs(sl * zl), fabs(su * zu)));
+            }
+            zs = wave_sum(zs); ed = wave_max(ed); ec = wave_max(ec);
+            const real s_d = fmax(o_s_max, zs / (RL(2.0) * nvar)) / o_s_max;
+            if (kTrace && trace && lane == 0) {
+                trace[16 * it + 0] = J; trace[16 * it + 1] = fmax(ed, ec) / s_d; trace[16 * it + 2] = mu;
+                trace[16 * it + 3] = delta;
+            }
+            if (fmax(ed, ec) / s_d <= o_tol) { status = 0; break; }
+        }
+        n_reg += reg_now;
+        if (delta > RL(0.0)) delta_last = delta;
+        const long long t2 = AMK_CLK();
+        riccati_forward(sm, L, N);
+        const long long t3 = AMK_CLK();
+        // dual steps, fraction to the boundary, directional derivative, barrier value
+        real a_pr = RL(1.0), a_du = RL(1.0), dphi = RL(0.0), phi0 = RL(0.0);
+        for (int e = lane; e < nvar; e += 64) {
+            const int i = e % UD;
+            const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e], du = sm[L.dU + e];
+            const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
+            const real isl = fast_rcp(sl), isu = fast_rcp(su);
+            const real dzl = mu * isl - zl - (zl * isl) * du;
+            const real dzu = mu * isu - zu + (zu * isu) * du;
+            sm[L.dzl + e] = dzl;
+            sm[L.dzu + e] = dzu;
+            // fraction to the boundary: one reciprocal per ratio, only the binding side of each bound
+            const real idu = fast_rcp(du);
+            if (du < RL(0.0)) a_pr = fmin(a_pr, -tau * sl * idu);
+            if (du > RL(0.0)) a_pr = fmin(a_pr, tau * su * idu);
+            if (dzl < RL(0.0)) a_du = fmin(a_du, -tau * zl * fast_rcp(dzl));
+            if (dzu < RL(0.0)) a_du = fmin(a_du, -tau * zu * fast_rcp(dzu));
+            dphi += (sm[L.gU + e] - mu * isl + mu * isu) * du;
+            phi0 -= mu * log(sl * su);  // both slacks are positive and bounded by the box: no overflow
+        }
+        a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi); phi0 = J + wave_sum(phi0);
+        // backtracking Armijo line search on the barrier function
+        const long long t4 = AMK_CLK();
+        real a = a_pr;
+        bool accepted = false;
+        for (int ls = 0; ls < opt.max_ls; ++ls) {
+            __syncthreads();
+            for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
+            for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
+            __syncthreads();
+            real phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
+            real lg = RL(0.0);
+            for (int e = lane; e < nvar; e += 64) {
+                const int i = e % UD;
+                const real u = sm[L.Ut + e];
+                lg -= mu * log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
+            }
+            phi += wave_sum(lg);
+            if (phi <= phi0 + o_eta_phi * a * dphi) { accepted = true; break; }
+            if (ls + 1 < opt.max_ls) a *= RL(0.5);
+        }
+        if (!accepted) ++ls_fail;
+        a_last = accepted ? a : RL(0.0);
+        if (kTrace && trace && lane == 0) {
+            trace[16 * it + 4] = a; trace[16 * it + 5] = a_pr; trace[16 * it + 6] = a_du; trace[16 * it + 7] = dphi;
+            trace[16 * it + 8] = (double)(t1 - t0); trace[16 * it + 9] = (double)(t2 - t1);
+            trace[16 * it + 10] = (double)(t3 - t2); trace[16 * it + 11] = (double)(t4 - t3);
+            trace[16 * it + 12] = (double)(AMK_CLK() - t4); trace[16 * it + 13] = (double)tclk[0]; trace[16 * it + 14] = (double)tclk[1]; trace[16 * it + 15] = (double)tclk[2];
+        }
+        __syncthreads();
+        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] = sm[L.Xt + e];
+        for (int e = lane; e < nvar; e += 64) {
+            const int i = e % UD;
+            const real u = sm[L.Ut + e];
+            sm[L.U + e] = u;
+            const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
+            real zl = sm[L.zl + e] + a_du * sm[L.dzl + e], zu = sm[L.zu + e] + a_du * sm[L.dzu + e];
+            zl = fmax(fmin(zl, o_kappa_sigma * mu / sl), mu / (o_kappa_sigma * sl));
+            zu = fmax(fmin(zu, o_kappa_sigma * mu / su), mu / (o_kappa_sigma * su));
+            sm[L.zl + e] = zl;
+            sm[L.zu + e] = zu;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int e = lane; e < (N + 1) * SD; e += 64) w_out[14 * (e / SD) + (e % SD)] = sm[L.X + e];
+    for (int e = lane; e < nvar; e += 64) w_out[14 * (e / UD) + 10 + (e % UD)] = sm[L.U + e];
+    if (lane == 0) {  // kept for the control-step bookkeeping of the calling kernel
+        sm[L.red + 0] = (real)status;
+        sm[L.red + 1] = (real)it;
+    }
+    if (info && lane == 0) {
+        info[0] = status;
+        info[1] = it;
+        info[2] = n_reg;
+        info[3] = ls_fail;
+    }
+}
+
+__device__ __forceinline__ int sm_status(const real *sm, const LdsMap &L) { return (int)sm[L.red + 0]; }
+__device__ __forceinline__ int sm_iters(const real *sm, const LdsMap &L) { return (int)sm[L.red + 1]; }
+
+
+#undef RL
+}  // namespace AMK_RNS

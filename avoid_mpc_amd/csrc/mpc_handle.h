@@ -8,7 +8,8 @@ struct amk_mpc {
     int N = 0, K = 0, S = 0, nx = 0, nref = 0;
     double h_prm[amk::PRM_LEN];
     amk::SolveOpts opt;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;     // fp64 scratchpad; the fp32 kernels take half
+    int precision = 64;       // arithmetic of the solve: 64 (default) or 32 (amk_mpc_set_precision)
     amk::DevBuf<double> prm;  // [PRM_LEN]
     amk::DevBuf<double> w0;   // [S][nx]  mNlpW0
     amk::DevBuf<double> plan_coef;  // item coefficients + lane-role constants of the Riccati plan (mpc_device.h)

@@ -217,17 +217,19 @@ extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
 #ifndef AMK_SOLVE_LDS_MIN
 #define AMK_SOLVE_LDS_MIN 0
 #endif
-// grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total doubles
-template <int NT>  // NT > 0: horizon baked in (LDS offsets become immediates, as the reference bakes N into its plugin)
-__global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
-                                                       SolveOpts opt, const double *__restrict__ ref_states,
-                                                       double *__restrict__ w0, double *__restrict__ u_out,
-                                                       double *__restrict__ x0array, int *__restrict__ info,
-                                                       double *trace, const int *__restrict__ done,
-                                                       double *__restrict__ ref_path, int *__restrict__ step_flags,
-                                                       const double *__restrict__ plan_coef,
-                                                       const int *__restrict__ plan_meta) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
+// grid = S blocks of one wavefront; dynamic LDS = LdsMap(N).total reals.  R = double: the product default;
+// R = float: the fp32 variant of BASELINE config C5 (amk_mpc_set_precision), same algorithm, same interfaces.
+template <class R, int NT>  // NT > 0: horizon baked in (LDS offsets become immediates, as the reference bakes N into its plugin)
+__device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int nx, const double *__restrict__ prm,
+                                                  const SolveOpts &opt, const double *__restrict__ ref_states,
+                                                  double *__restrict__ w0, double *__restrict__ u_out,
+                                                  double *__restrict__ x0array, int *__restrict__ info, double *trace,
+                                                  const int *__restrict__ done, double *__restrict__ ref_path,
+                                                  int *__restrict__ step_flags, const double *__restrict__ plan_coef,
+                                                  const int *__restrict__ plan_meta) {
+    using namespace amk32;  // solve_scene / sm_status / sm_iters overload on the scratchpad type
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
+    R *sm = reinterpret_cast<R *>(sm_raw);
     const int s = blockIdx.x;
     if (done && done[s]) return;  // control step: this scene left the re-plan loop already
     const int N = NT > 0 ? NT : Nrt;
@@ -257,19 +259,46 @@ __global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(int Nrt,
     }
 }
 
+#define AMK_SOLVE_ARGS                                                                                                   \
+    int Nrt, int K, int nref, int nx, const double *__restrict__ prm, SolveOpts opt,                                     \
+        const double *__restrict__ ref_states, double *__restrict__ w0, double *__restrict__ u_out,                      \
+        double *__restrict__ x0array, int *__restrict__ info, double *trace, const int *__restrict__ done,               \
+        double *__restrict__ ref_path, int *__restrict__ step_flags, const double *__restrict__ plan_coef,               \
+        const int *__restrict__ plan_meta
+#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta
+
+template <int NT>
+__global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(AMK_SOLVE_ARGS) {
+    solve_kernel_body<double, NT>(AMK_SOLVE_PASS);
+}
+template <int NT>
+__global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel_f32(AMK_SOLVE_ARGS) {
+    solve_kernel_body<float, NT>(AMK_SOLVE_PASS);
+}
+
 namespace amk {
 int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
                  double *d_ref_path, int *d_step_flags, hipStream_t stream) {
     TimedLaunch tl(KC_SOLVE, stream);
-#define AMK_LAUNCH_SOLVE(NT)                                                                                         \
-    hipLaunchKernelGGL(mpc_solve_kernel<NT>, dim3(m->S), dim3(64), m->lds_bytes, stream, m->N, m->K, m->nref, m->nx, \
-                       m->prm.p, m->opt, d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, \
-                       d_step_flags, m->plan_coef.p, m->plan_meta.p)
-    switch (m->N) {  // the BASELINE horizons get their own instantiation; anything else runs the generic one
-        case 10: AMK_LAUNCH_SOLVE(10); break;
-        case 20: AMK_LAUNCH_SOLVE(20); break;
-        case 30: AMK_LAUNCH_SOLVE(30); break;
-        default: AMK_LAUNCH_SOLVE(0); break;
+#define AMK_LAUNCH_SOLVE(KERNEL, NT, LDS)                                                                            \
+    hipLaunchKernelGGL(KERNEL<NT>, dim3(m->S), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
+                       d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, d_step_flags,         \
+                       m->plan_coef.p, m->plan_meta.p)
+    if (m->precision == 32) {  // fp32 arithmetic, half the scratchpad
+        const size_t lds = m->lds_bytes / 2;
+        switch (m->N) {
+            case 10: AMK_LAUNCH_SOLVE(mpc_solve_kernel_f32, 10, lds); break;
+            case 20: AMK_LAUNCH_SOLVE(mpc_solve_kernel_f32, 20, lds); break;
+            case 30: AMK_LAUNCH_SOLVE(mpc_solve_kernel_f32, 30, lds); break;
+            default: AMK_LAUNCH_SOLVE(mpc_solve_kernel_f32, 0, lds); break;
+        }
+    } else {
+        switch (m->N) {  // the BASELINE horizons get their own instantiation; anything else runs the generic one
+            case 10: AMK_LAUNCH_SOLVE(mpc_solve_kernel, 10, m->lds_bytes); break;
+            case 20: AMK_LAUNCH_SOLVE(mpc_solve_kernel, 20, m->lds_bytes); break;
+            case 30: AMK_LAUNCH_SOLVE(mpc_solve_kernel, 30, m->lds_bytes); break;
+            default: AMK_LAUNCH_SOLVE(mpc_solve_kernel, 0, m->lds_bytes); break;
+        }
     }
 #undef AMK_LAUNCH_SOLVE
     AMK_HIP(hipGetLastError());
@@ -384,6 +413,13 @@ int amk_mpc_set_solver_options(amk_mpc *m, double tol, int max_iter) {
     if (!m || !(tol > 0) || max_iter < 0) return AMK_ERR_INVALID_ARG;
     m->opt.tol = tol;
     m->opt.max_iter = max_iter;
+    return AMK_OK;
+}
+
+int amk_mpc_set_precision(amk_mpc *mpc, int bits) {
+    if (!mpc) return AMK_ERR_INVALID_ARG;
+    if (bits != 32 && bits != 64) return AMK_ERR_UNSUPPORTED;
+    mpc->precision = bits;
     return AMK_OK;
 }
 

@@ -144,6 +144,10 @@ class MpcBatch:
     def set_solver_options(self, tol=1e-4, max_iter=10):
         capi.check(self.lib.amk_mpc_set_solver_options(self.h, float(tol), int(max_iter)), "set_solver_options")
 
+    def set_precision(self, bits):
+        """64 (default) or 32: arithmetic of the solve (BASELINE config C5's fp32 tolerance check)."""
+        capi.check(self.lib.amk_mpc_set_precision(self.h, int(bits)), "set_precision")
+
     def configure(self, prm):
         """SetupMPC (AvoidanceStateMachine.cpp:55-70) from a synth.MpcParams."""
         self.SetupWeights(prm.weights); self.SetupTau(prm.tau); self.SetupGains(prm.gain)

@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--streams", type=int, default=16,
                     help="independent steps in flight (each on its own HIP stream with its own handles)")
+    ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
+                    help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with every kernel class timed")
     args = ap.parse_args()
@@ -165,7 +167,7 @@ def main():
         def __init__(self):
             self.stream = torch.cuda.Stream(device=dev)
             self.kd_o, self.kd_e = KdBatch(S, n), KdBatch(S, ne)
-            self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm)
+            self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm); self.mpc.set_precision(args.precision)
             self.ref = ref0_d.clone()
             self.out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
                             x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
@@ -248,7 +250,7 @@ def main():
             "metric": "MPC steps/sec (50k-pt cloud, N=20, 8 obstacle constraints)",
             "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1] batched as configs[2]: {S} scenes/GPU x ({n}-pt obstacle "
                                    f"cloud + {ne}-pt edge cloud, N={N}, K={prm.K}), fresh frame + zero warm start "
                                    f"every step", "scenes_per_gpu": S, "points": n, "horizon": N, "K": prm.K,

@@ -127,6 +127,11 @@ int amk_mpc_set_drone_accel_limits(amk_mpc *mpc, double aMinZ, double aMaxZ, dou
                                    double aMaxYawDot);              /* .cpp:70-92                */
 /* ipopt.tol / ipopt.max_iter of HighLvlMpc.cpp:19-20                                            */
 int amk_mpc_set_solver_options(amk_mpc *mpc, double tol, int max_iter);
+/* Arithmetic of the NLP evaluation and the interior-point method: 64 (default; the reference's CasADi/IPOPT
+ * path is fp64 throughout) or 32 (BASELINE.json configs[4], "fp32 tolerance check vs CPU trajectory").  The
+ * interface stays double and the KD queries stay fp64 (neighbour indices remain bit-exact); only the solve
+ * narrows.  Anything else: AMK_ERR_UNSUPPORTED.                                                              */
+int amk_mpc_set_precision(amk_mpc *mpc, int bits);
 
 /* Solve(vecRefStates, u, x0Array, faster) (HighLvlMpc.cpp:93-137) for every scene.
  *   d_ref_states [S][20+10N+3KN]  = [x_init | ref_k | obstacles | target]  (GetRefStates layout,

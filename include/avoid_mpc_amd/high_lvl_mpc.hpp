@@ -63,6 +63,12 @@ public:
     }
     // beyond the reference: the status the reference never looks at (.cpp:116-122)
     const int *LastSolveInfo() const { return mInfo; }
+    // beyond the reference: arithmetic of the solve, 64 (default) or 32 (amk_mpc_set_precision)
+    void SetPrecision(int bits) {
+        mPrecision = bits;
+        if (mpc_ && amk_mpc_set_precision(mpc_, bits) != AMK_OK)
+            throw std::runtime_error("ObstacleAvoidanceMPC::SetPrecision: 32 or 64");
+    }
     amk_mpc *handle() { return mpc_; }
 
 private:
@@ -83,9 +89,10 @@ private:
         amk_mpc_setup_gains(mpc_, mGains.data());
         amk_mpc_set_drone_radius(mpc_, mDroneRadius);
         if (mHaveLimits) amk_mpc_set_drone_accel_limits(mpc_, mLimits[0], mLimits[1], mLimits[2], mLimits[3]);
+        amk_mpc_set_precision(mpc_, mPrecision);
     }
     double mT = 0, mDt = 0;
-    int mN = 0, mK = -1;
+    int mN = 0, mK = -1, mPrecision = 64;
     std::string mSoPath;
     double mDroneRadius = 0;
     std::vector<double> mTau, mGains, mWeights, mLimits;
