@@ -26,6 +26,7 @@ SYMBOLS = [
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_step_batch", "amk_step_batch_host",
+    "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
 ]
 
 
@@ -37,6 +38,15 @@ class StepParams(C.Structure):
     _fields_ = [("speed", C.c_double), ("safety_distance", C.c_double),
                 ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
 
+
+class DepthParams(C.Structure):
+    """amk_depth_params (FrameKDMap's perception parameters, mpc_parameters.yaml:59-66)."""
+    _fields_ = [("pixel2meter", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
+                ("resize_scale", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("Tbc", C.c_double * 16)]
+
+
+AMK_DEPTH_U16, AMK_DEPTH_F32 = 0, 1
 
 _lib = None
 
@@ -93,6 +103,9 @@ def load():
         "amk_mpc_solve_host": (i, [vp, vp, vp, vp, vp, i]),
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
+        "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
+        "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
+        "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
     }
     sig["amk__kd_set_mode"] = (i, [vp, i])  # internal: 0 bucketed index, 1 streaming scan
     for name, (res, args) in sig.items():

@@ -195,3 +195,33 @@ def step_batch(kd_obstacle, kd_edge, mpc, prm, state_quad, pos_x, ref_path, stre
                                           capi.dptr(out["x0array"]), capi.dptr(out["flags"]),
                                           capi.stream_ptr(stream)), "amk_step_batch")
     return out
+
+
+def depth_params(pixel2meter=1.0, depth_min=0.1, depth_max=100.0, resize_scale=10.0, fx=320.0, fy=320.0, cx=320.0,
+                 cy=240.0, Tbc=None):
+    """amk_depth_params with the defaults of AM/config/mpc_parameters.yaml:59-66."""
+    p = capi.DepthParams(float(pixel2meter), float(depth_min), float(depth_max), float(resize_scale), float(fx),
+                         float(fy), float(cx), float(cy))
+    T = np.eye(4) if Tbc is None else np.asarray(Tbc, np.float64).reshape(4, 4)
+    for i in range(16):
+        p.Tbc[i] = float(T.flat[i])
+    return p
+
+
+def depth_to_cloud(depth, params, Twb, point_stride=3, stream=None):
+    """FrameKDMap::ProcessDepth for a batch: depth [S, rows, cols] uint16 / float32 device tensor, Twb [S, 4, 4]
+    float64 -> (cloud float32 [S, W*H, point_stride], counts int32 [S]); the cloud feeds KdBatch.build(cloud, counts)."""
+    assert depth.dim() == 3 and depth.dtype in (torch.uint16, torch.int16, torch.float32) and depth.is_contiguous()
+    S, rows, cols = (int(v) for v in depth.shape)
+    assert Twb.dtype == torch.float64 and tuple(Twb.shape) == (S, 4, 4) and Twb.is_contiguous()
+    lib = capi.load()
+    w, h = C.c_int(), C.c_int()
+    capi.check(lib.amk_depth_out_size(rows, cols, params.resize_scale, C.byref(w), C.byref(h)), "amk_depth_out_size")
+    cap = w.value * h.value
+    cloud = torch.zeros((S, cap, point_stride), dtype=torch.float32, device=depth.device)
+    counts = torch.empty(S, dtype=torch.int32, device=depth.device)
+    kind = capi.AMK_DEPTH_F32 if depth.dtype == torch.float32 else capi.AMK_DEPTH_U16
+    capi.check(lib.amk_depth_to_cloud(capi.dptr(depth), kind, rows, cols, rows * cols, S, C.byref(params),
+                                      capi.dptr(Twb), capi.dptr(cloud), int(point_stride), cap * point_stride,
+                                      capi.dptr(counts), capi.stream_ptr(stream)), "amk_depth_to_cloud")
+    return cloud, counts

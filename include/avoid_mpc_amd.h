@@ -189,6 +189,45 @@ int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_
                         const double *h_state_quad, const double *h_pos_x, double *h_ref_path,
                         double *h_u, double *h_x0array, int *h_flags);
 
+/* ------------------------------------------------------------------------------------------ */
+/* Depth image -> obstacle cloud: FrameKDMap::ProcessDepth            FrameKDMap.cpp:75-138   */
+/* (the step immediately before the tree build)                   */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct amk_depth_params {
+    double pixel2meter;   /* mParamPixel2Meter   mpc_parameters.yaml:64                            */
+    double depth_min;     /* mParamDepthMin      :66                                               */
+    double depth_max;     /* mParamDepthMax      :65                                               */
+    double resize_scale;  /* mParamDepthScale    :63  (output is cols/scale x rows/scale, truncated) */
+    double fx, fy, cx, cy; /* FULL-resolution intrinsics (:59-62); divided by resize_scale inside,
+                             as the FrameKDMap constructor does (FrameKDMap.cpp:21-24)             */
+    double Tbc[16];       /* body <- camera, row-major 4x4 (mParamTbc)                             */
+} amk_depth_params;
+
+#define AMK_DEPTH_U16 0   /* CV_16UC1 */
+#define AMK_DEPTH_F32 1   /* CV_32FC1 */
+
+/* Width / height of the down-scaled image = capacity of the output cloud per scene (FrameKDMap.cpp:106-107). */
+int amk_depth_out_size(int rows, int cols, double resize_scale, int *out_w, int *out_h);
+
+/* For every scene: inverse depth of the raw pixels with the range gate (GetInvDepthImg, :76-89), bilinear
+ * down-scale (cv::resize with dsize given: its 4th positional argument cv::INTER_MAX lands in `fx`, so the
+ * interpolation is the default INTER_LINEAR, :109), back-projection of every pixel with inverse depth >= 1e-2
+ * and min < depth < max through the scaled intrinsics (:110-118,131-138), transform by Twb * Tbc (:119-120),
+ * points appended in row-major pixel order as float32 (:122).
+ *   d_depth   [S][rows][cols] uint16 or float32, scene_stride in ELEMENTS
+ *   d_Twb     [S][16] world <- body, row-major
+ *   d_cloud   [S][W*H][point_stride] float32 out (point_stride 3 or 4: feeds amk_kd_build directly),
+ *             cloud_scene_stride in floats;  d_counts [S] out: points written per scene.
+ * Arithmetic contract: DESIGN.md section 10 (float bilinear taps in OpenCV's order without FMA, double
+ * back-projection and transform without FMA); bit-exact against oracle/depth_oracle.c.  Parity with OpenCV's
+ * own resize and Eigen's -march=native products is unpinned (neither is in the image).                       */
+int amk_depth_to_cloud(const void *d_depth, int depth_type, int rows, int cols, long long scene_stride,
+                       int n_scenes, const amk_depth_params *params, const double *d_Twb, float *d_cloud,
+                       int point_stride, long long cloud_scene_stride, int *d_counts, void *stream);
+int amk_depth_to_cloud_host(const void *h_depth, int depth_type, int rows, int cols, long long scene_stride,
+                            int n_scenes, const amk_depth_params *params, const double *h_Twb, float *h_cloud,
+                            int point_stride, long long cloud_scene_stride, int *h_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,10 +3,10 @@
 //
 // In scope: per-frame dual trees, the query list [cur, keyframes[0..size-2]]
 // (FrameKDMap.cpp:64-74), the fast path / multi-frame merge of QueryNearest (:322-376) and
-// GetNearestDistance (:400-427).  Out of scope here: depth image -> clouds (ProcessDepth /
-// BuildEdgeCloud, §8 f2/f3) -- AddVertex takes the two clouds directly -- and the keyframe
-// maintenance thread (§8 f1).  The reference fans frames out over std::threads; every per-frame search
-// here is one device call, so the loop is sequential on the host.
+// GetNearestDistance (:400-427), the keyframe sweep (§8 f1, KeyframeUpdate) and the obstacle half of
+// ProcessDepth (§8 f2: depth image -> world-frame cloud, FrameKDMap.cpp:90-130).  Not here: BuildEdgeCloud
+// (§8 f3, OpenCV erode + Canny) -- AddVertex takes the edge cloud from the caller.  The reference fans frames out
+// over std::threads; every per-frame search here is one device call, so the loop is sequential on the host.
 #pragma once
 #include <algorithm>
 #include <cfloat>
@@ -54,6 +54,26 @@ public:
     // PtIsInFrame (FrameKDMap.cpp:215-231) needs the camera model; the default accepts every point
     // (both query paths return the same neighbours for a single-frame map).
     std::function<bool(const Vector3d &)> ptIsInCurFrame = [](const Vector3d &) { return true; };
+
+    // ProcessDepth, obstacle cloud only (FrameKDMap.cpp:90-130): raw depth buffer (AMK_DEPTH_U16 / AMK_DEPTH_F32,
+    // rows x cols, tightly packed) + Twb (row-major 4x4) -> points in the reference's row-major pixel order.
+    // `Cloud` is anything with a `points` vector of {x, y, z} floats (pcl::PointCloud<pcl::PointXYZ> qualifies).
+    amk_depth_params depthParams{};  // perception parameters (ParameterManager.cpp:44-57); fx..cy full-resolution
+    template <class Cloud>
+    void ProcessDepth(const void *depth, int depthType, int rows, int cols, const double *Twb, Cloud &cloud) {
+        int w = 0, h = 0;
+        amk_throw(amk_depth_out_size(rows, cols, depthParams.resize_scale, &w, &h), "amk_depth_out_size");
+        std::vector<float> xyz((size_t)w * h * 3);
+        int n = 0;
+        amk_throw(amk_depth_to_cloud_host(depth, depthType, rows, cols, (long long)rows * cols, 1, &depthParams, Twb,
+                                          xyz.data(), 3, (long long)w * h * 3, &n), "amk_depth_to_cloud_host");
+        cloud.points.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            cloud.points[i].x = xyz[3 * i];
+            cloud.points[i].y = xyz[3 * i + 1];
+            cloud.points[i].z = xyz[3 * i + 2];
+        }
+    }
 
     // AddVertex after ProcessDepth (FrameKDMap.cpp:39-51): two fresh trees, then swap under the lock.
     template <class CloudPtr>

@@ -254,3 +254,34 @@ def step_oracle(kd_obs, kd_edge, mpc, prm, state_quad, pos_x, ref_path, want_log
                   prm.safety_distance, prm.max_iter, sq.reshape(-1), float(pos_x), ref_path.reshape(-1), u,
                   x0.reshape(-1), flags, log.ctypes.data_as(C.c_void_p) if want_log else None)
     return dict(u=u, x0array=x0, flags=flags, ref_log=log)
+
+
+# ---- depth image -> cloud (oracle/depth_oracle.c) ------------------------------------------------
+class DepthoParams(C.Structure):
+    _fields_ = [("pixel2meter", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
+                ("resize_scale", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("Tbc", C.c_double * 16)]
+
+
+def depth_oracle(depth, prm, Twb, stride=3):
+    """One scene.  depth [rows, cols] uint16 / float32; prm: dict of the amk_depth_params fields (Tbc 4x4);
+    -> (cloud float32 [count, stride], inverse-depth image float32 [H, W])."""
+    lib = load_oracle()
+    lib.deptho_process.restype = C.c_int
+    lib.deptho_process.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DepthoParams), _f64p,
+                                   C.c_void_p, C.c_int, C.c_void_p]
+    depth = np.ascontiguousarray(depth)
+    assert depth.dtype in (np.uint16, np.float32) and depth.ndim == 2
+    rows, cols = depth.shape
+    p = DepthoParams(prm["pixel2meter"], prm["depth_min"], prm["depth_max"], prm["resize_scale"], prm["fx"],
+                     prm["fy"], prm["cx"], prm["cy"])
+    T = np.asarray(prm.get("Tbc", np.eye(4)), np.float64).reshape(4, 4)
+    for i in range(16):
+        p.Tbc[i] = float(T.flat[i])
+    W, H = int(cols / prm["resize_scale"]), int(rows / prm["resize_scale"])
+    cloud = np.zeros((W * H, stride), np.float32)
+    inv = np.zeros((H, W), np.float32)
+    n = lib.deptho_process(depth.ctypes.data_as(C.c_void_p), 0 if depth.dtype == np.uint16 else 1, rows, cols,
+                           C.byref(p), np.ascontiguousarray(Twb, np.float64).reshape(-1),
+                           cloud.ctypes.data_as(C.c_void_p), stride, inv.ctypes.data_as(C.c_void_p))
+    return cloud[:n], inv

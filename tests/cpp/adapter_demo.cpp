@@ -131,6 +131,30 @@ int main(int argc, char **argv) {
             wr(o, &c, 1); wr(o, d2.data(), c); wr(o, &nd, 1);
         }
     }
+    // 6. ProcessDepth (FrameKDMap.cpp:90-130): a synthetic 16UC1 depth frame (millimetres) made here from a closed
+    //    formula the test repeats; yaml intrinsics at 120 x 160, resize_scale 4, a yawed body pose
+    {
+        const int rows = 120, cols = 160;
+        std::vector<unsigned short> img((size_t)rows * cols);
+        for (int r = 0; r < rows; ++r)
+            for (int c = 0; c < cols; ++c) {
+                unsigned v = 1500u + (unsigned)((r * 37 + c * 91) % 4000);
+                if ((r * 7 + c * 13) % 11 == 0) v = 0;  // holes
+                img[(size_t)r * cols + c] = (unsigned short)v;
+            }
+        FrameKDMap dmap;
+        dmap.depthParams.pixel2meter = 1e-3; dmap.depthParams.depth_min = 0.1; dmap.depthParams.depth_max = 100.0;
+        dmap.depthParams.resize_scale = 4.0;
+        dmap.depthParams.fx = 80.0; dmap.depthParams.fy = 80.0; dmap.depthParams.cx = 80.0; dmap.depthParams.cy = 60.0;
+        const double Tbc[16] = {0, 0, 1, 0.1, -1, 0, 0, 0.0, 0, -1, 0, 0.05, 0, 0, 0, 1};
+        for (int i = 0; i < 16; ++i) dmap.depthParams.Tbc[i] = Tbc[i];
+        const double Twb[16] = {0.8, -0.6, 0, 2.0, 0.6, 0.8, 0, -1.0, 0, 0, 1, 1.5, 0, 0, 0, 1};
+        Cloud dc;
+        dmap.ProcessDepth(img.data(), AMK_DEPTH_U16, rows, cols, Twb, dc);
+        int cnt = (int)dc.points.size();
+        wr(o, &cnt, 1);
+        for (auto &p : dc.points) { float v[3] = {p.x, p.y, p.z}; wr(o, v, 3); }
+    }
     fclose(o);
     return 0;
 }

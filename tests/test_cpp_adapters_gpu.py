@@ -99,4 +99,15 @@ def test_adapters_match_oracle(tmp_path):
         assert np.array_equal(d2, alld)
         nn = min([t.search(q, 1)[1][0] for t in query_frames if t.size() > 1] or [np.finfo(np.float64).max])
         assert nd == np.sqrt(nn)
+    # 6. ProcessDepth through the adapter == the depth oracle on the same synthetic frame
+    r, c = np.meshgrid(np.arange(120), np.arange(160), indexing="ij")
+    img = (1500 + (r * 37 + c * 91) % 4000).astype(np.uint16)
+    img[(r * 7 + c * 13) % 11 == 0] = 0
+    dprm = dict(pixel2meter=1e-3, depth_min=0.1, depth_max=100.0, resize_scale=4.0, fx=80.0, fy=80.0, cx=80.0, cy=60.0,
+                Tbc=np.array([[0, 0, 1, 0.1], [-1, 0, 0, 0.0], [0, -1, 0, 0.05], [0, 0, 0, 1.0]]))
+    Twb = np.array([[0.8, -0.6, 0, 2.0], [0.6, 0.8, 0, -1.0], [0, 0, 1, 1.5], [0, 0, 0, 1.0]])
+    ref, _ = _oracle.depth_oracle(img, dprm, Twb)
+    cnt = int(take(np.int32, 1)[0])
+    pts = take(np.float32, 3 * cnt).reshape(-1, 3)
+    assert cnt == len(ref) > 500 and np.array_equal(pts, ref)
     assert off == len(buf)
