@@ -16,7 +16,15 @@
 namespace amk {
 
 constexpr int kGridMaxCells = 8192;
-constexpr int kGridBuildThreads = 1024;
+// 512, not 1024: a 1024-thread workgroup needs four wave slots on every SIMD of one CU at the same moment, and the
+// dispatcher holds everything behind it until a CU qualifies -- measured: 1024-thread builds do not overlap with
+// the solves (or the searches) of other streams AT ALL (time = sum), 512/256-thread builds overlap almost fully
+// (solves + builds on separate streams: 32 ms vs 27 ms for the solves alone, 48 ms as a sum).  Alone on the chip
+// the 1024-thread version is ~25 % faster (16 instead of 8 waves per CU hide the load latency better).
+#ifndef AMK_BUILD_THREADS
+#define AMK_BUILD_THREADS 512
+#endif
+constexpr int kGridBuildThreads = AMK_BUILD_THREADS;
 constexpr int kGridUnroll = 4;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz
 
