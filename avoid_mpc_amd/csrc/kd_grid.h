@@ -43,12 +43,12 @@ __device__ __forceinline__ int cell_of(double p, double bbmin, double inv_h, int
     return (int)c;
 }
 
-static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel(
-    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
-    const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP,
-    int *__restrict__ cell_start, double *__restrict__ gparams) {
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int n = sizes[s];
+// the index of scene s from its compacted SoA planes; called by every thread of a kGridBuildThreads block
+__device__ __forceinline__ void grid_build_scene(int s, const float *__restrict__ X, const float *__restrict__ Y,
+                                                 const float *__restrict__ Z, int cap, int n,
+                                                 const float *__restrict__ bbox, float4 *__restrict__ GP,
+                                                 int *__restrict__ cell_start, double *__restrict__ gparams) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
     float4 *gpt4 = GP + (size_t)s * cap;  // bucket-contiguous points: (x, y, z, cloud index as int bits)
     int *cs = cell_start + (size_t)s * (kGridMaxCells + 2);
@@ -165,6 +165,13 @@ static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel
             }
         }
     }
+}
+
+static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
+    const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP,
+    int *__restrict__ cell_start, double *__restrict__ gparams) {
+    grid_build_scene(blockIdx.x, X, Y, Z, cap, sizes[blockIdx.x], bbox, GP, cell_start, gparams);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -78,12 +78,12 @@ using amk::kWave;
 #endif
 constexpr int kCompactThreads = AMK_BUILD_THREADS;
 
-__global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
-    const float *__restrict__ xyz, int point_stride, long long scene_stride,
-    const int *__restrict__ counts, int max_points, float *__restrict__ X, float *__restrict__ Y,
-    float *__restrict__ Z, int cap, int *__restrict__ size_out, float *__restrict__ pmax_out,
-    float *__restrict__ bbox_out) {
-    const int s = blockIdx.x;
+// returns (to every thread) the number of points kept
+__device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xyz, int point_stride, long long scene_stride,
+                                             const int *__restrict__ counts, int max_points, float *__restrict__ X,
+                                             float *__restrict__ Y, float *__restrict__ Z, int cap,
+                                             int *__restrict__ size_out, float *__restrict__ pmax_out,
+                                             float *__restrict__ bbox_out) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6;
     const float *src = xyz + (long long)s * scene_stride;
@@ -182,6 +182,23 @@ __global__ __launch_bounds__(kCompactThreads) void kd_compact_kernel(
         for (int j = 1; j < NW; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
         bbox_out[6 * s + tid] = v;
     }
+    return base;
+}
+
+// InitializeNew for scene s = blockIdx.x: compaction, then the bucketed index from the planes this block has just
+// written (one launch instead of two: under 16 steps in flight every launch of a stream queues behind the others)
+static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
+__global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(
+    const float *__restrict__ xyz, int point_stride, long long scene_stride, const int *__restrict__ counts,
+    int max_points, float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Z, int cap,
+    int *__restrict__ size_out, float *__restrict__ pmax_out, float *__restrict__ bbox_out, float4 *__restrict__ GP,
+    int *__restrict__ cell_start, double *__restrict__ gparams) {
+    const int s = blockIdx.x;
+    const int n = compact_scene(s, xyz, point_stride, scene_stride, counts, max_points, X, Y, Z, cap, size_out, pmax_out,
+                                bbox_out);
+    __threadfence_block();
+    __syncthreads();  // the planes and the bounding box are this block's own stores
+    amk::grid_build_scene(s, X, Y, Z, cap, n, bbox_out, GP, cell_start, gparams);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,16 +549,11 @@ int amk_kd_destroy(amk_kd *kd) {
 int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
                  const int *d_counts, void *stream) {
     if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
-    { amk::TimedLaunch tl(amk::KC_COMPACT, (hipStream_t)stream);
-    hipLaunchKernelGGL(kd_compact_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
-                       point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
-                       kd->size.p, kd->pmax.p, kd->bbox.p); }
-    AMK_HIP(hipGetLastError());
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
-        hipLaunchKernelGGL(amk::kd_grid_build_kernel, dim3(kd->n_scenes), dim3(amk::kGridBuildThreads), 0,
-                           (hipStream_t)stream, kd->x.p, kd->y.p, kd->z.p, kd->cap, kd->size.p, kd->bbox.p, kd->gpt.p,
-                           kd->cell_start.p, kd->gparams.p);
+        hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
+                           point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
+                           kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p);
     }
     AMK_HIP(hipGetLastError());
     return AMK_OK;
