@@ -101,8 +101,8 @@ def cpu_baseline(n, T, K, budget_s=6.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=2048)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--scenes", type=int, default=256, help="scenes per GPU per step (BASELINE configs[2])")
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--T", type=float, default=0.66)
