@@ -306,6 +306,19 @@ int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_
 }
 }  // namespace amk
 
+// internal (diagnostics): host copy of the Riccati plan's LDS indices, [PLAN_ITEMS][PLAN_TERMS + 4] ints + lane roles
+extern "C" int amk__plan_dump(amk_mpc *m, int *h_meta, int n_ints) {
+    std::vector<double> coef;
+    std::vector<int> meta;
+    int st = build_plan(m, coef, meta);
+    if (st != AMK_OK) return st;
+    const LdsMap L(m->N);
+    const int hdr[8] = {L.P, L.p, L.lam, L.M, L.Hm, L.G, L.q, L.total};
+    for (int i = 0; i < 8 && i < n_ints; ++i) h_meta[i] = hdr[i];
+    for (int i = 0; i + 8 < n_ints && i < (int)meta.size(); ++i) h_meta[8 + i] = meta[i];
+    return (int)meta.size() + 8;
+}
+
 // internal: resident solve blocks per CU as the runtime computes it (diagnostics)
 extern "C" int amk__solve_occupancy(amk_mpc *m) {
     int nb = -1;
