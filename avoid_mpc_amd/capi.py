@@ -27,6 +27,7 @@ SYMBOLS = [
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_step_batch", "amk_step_batch_host",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
+    "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
 
 
@@ -106,6 +107,8 @@ def load():
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
         "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
         "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
+        "amk_depth_to_edge_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
+        "amk_depth_to_edge_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
     }
     sig["amk__kd_set_mode"] = (i, [vp, i])  # internal: 0 bucketed index, 1 streaming scan
     for name, (res, args) in sig.items():

@@ -208,8 +208,8 @@ def depth_params(pixel2meter=1.0, depth_min=0.1, depth_max=100.0, resize_scale=1
     return p
 
 
-def depth_to_cloud(depth, params, Twb, point_stride=3, stream=None):
-    """FrameKDMap::ProcessDepth for a batch: depth [S, rows, cols] uint16 / float32 device tensor, Twb [S, 4, 4]
+def depth_to_cloud(depth, params, Twb, point_stride=3, stream=None, edge=False):
+    """FrameKDMap::ProcessDepth (edge=True: FrameKDMap::BuildEdgeCloud, Twb then = mCurFrame.Twc) for a batch: depth [S, rows, cols] uint16 / float32 device tensor, Twb [S, 4, 4]
     float64 -> (cloud float32 [S, W*H, point_stride], counts int32 [S]); the cloud feeds KdBatch.build(cloud, counts)."""
     assert depth.dim() == 3 and depth.dtype in (torch.uint16, torch.int16, torch.float32) and depth.is_contiguous()
     S, rows, cols = (int(v) for v in depth.shape)
@@ -221,7 +221,8 @@ def depth_to_cloud(depth, params, Twb, point_stride=3, stream=None):
     cloud = torch.zeros((S, cap, point_stride), dtype=torch.float32, device=depth.device)
     counts = torch.empty(S, dtype=torch.int32, device=depth.device)
     kind = capi.AMK_DEPTH_F32 if depth.dtype == torch.float32 else capi.AMK_DEPTH_U16
-    capi.check(lib.amk_depth_to_cloud(capi.dptr(depth), kind, rows, cols, rows * cols, S, C.byref(params),
-                                      capi.dptr(Twb), capi.dptr(cloud), int(point_stride), cap * point_stride,
-                                      capi.dptr(counts), capi.stream_ptr(stream)), "amk_depth_to_cloud")
+    fn = lib.amk_depth_to_edge_cloud if edge else lib.amk_depth_to_cloud
+    capi.check(fn(capi.dptr(depth), kind, rows, cols, rows * cols, S, C.byref(params), capi.dptr(Twb), capi.dptr(cloud),
+                  int(point_stride), cap * point_stride, capi.dptr(counts), capi.stream_ptr(stream)),
+               "amk_depth_to_edge_cloud" if edge else "amk_depth_to_cloud")
     return cloud, counts

@@ -228,6 +228,26 @@ int amk_depth_to_cloud_host(const void *h_depth, int depth_type, int rows, int c
                             int n_scenes, const amk_depth_params *params, const double *h_Twb, float *h_cloud,
                             int point_stride, long long cloud_scene_stride, int *h_counts);
 
+/* Depth image -> edge cloud: FrameKDMap::BuildEdgeCloud (FrameKDMap.cpp:176-214), the
+ * input of the Edge-KD-tree.  On the down-scaled inverse-depth image of amk_depth_to_cloud: 8-bit quantisation
+ * uchar(depth / (max - min) * 200), 255 where invalid (:180-193); cv::erode with a 3x3 kernel (:194);
+ * cv::Canny(img, 0.1, 0.3) (:196: aperture 3, L1 norm, thresholds floor to 0, so every pixel that survives the
+ * non-maximum suppression with a non-zero Sobel magnitude is an edge); the edge pixels are back-projected at their
+ * QUANTISED, ERODED depth (:199-200) and transformed by d_Twc * Tbc, appended in row-major order.
+ *   d_Twc [S][16]  the matrix the reference multiplies with Tbc at :209: mCurFrame.Twc, i.e. the PREVIOUS frame's
+ *                  Twb * Tbc (it is updated only after ProcessDepth, :50).  Pass Twb of the current frame instead to
+ *                  get what the authors presumably meant.
+ * The edge cloud of a scene is empty when its obstacle cloud is (:126-128).  Down-scaled images of more than
+ * AMK_EDGE_MAX_PIXELS pixels: AMK_ERR_UNSUPPORTED.  Bit-exact against oracle/depth_oracle.c; parity with OpenCV's
+ * own erode / Canny is unpinned.                                                          */
+#define AMK_EDGE_MAX_PIXELS 16000
+int amk_depth_to_edge_cloud(const void *d_depth, int depth_type, int rows, int cols, long long scene_stride,
+                            int n_scenes, const amk_depth_params *params, const double *d_Twc, float *d_cloud,
+                            int point_stride, long long cloud_scene_stride, int *d_counts, void *stream);
+int amk_depth_to_edge_cloud_host(const void *h_depth, int depth_type, int rows, int cols, long long scene_stride,
+                                 int n_scenes, const amk_depth_params *params, const double *h_Twc, float *h_cloud,
+                                 int point_stride, long long cloud_scene_stride, int *h_counts);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,10 +3,10 @@
 //
 // In scope: per-frame dual trees, the query list [cur, keyframes[0..size-2]]
 // (FrameKDMap.cpp:64-74), the fast path / multi-frame merge of QueryNearest (:322-376) and
-// GetNearestDistance (:400-427), the keyframe sweep (§8 f1, KeyframeUpdate) and the obstacle half of
-// ProcessDepth (§8 f2: depth image -> world-frame cloud, FrameKDMap.cpp:90-130).  Not here: BuildEdgeCloud
-// (§8 f3, OpenCV erode + Canny) -- AddVertex takes the edge cloud from the caller.  The reference fans frames out
-// over std::threads; every per-frame search here is one device call, so the loop is sequential on the host.
+// GetNearestDistance (:400-427), the keyframe sweep (§8 f1, KeyframeUpdate), ProcessDepth (§8 f2: depth image ->
+// world-frame cloud, FrameKDMap.cpp:90-130) and BuildEdgeCloud (§8 f3: quantise, erode, Canny, back-project,
+// :176-214), i.e. the reference's AddVertex(Twb, depth image) end to end.  The reference fans frames out over
+// std::threads; every per-frame search here is one device call, so the loop is sequential on the host.
 #pragma once
 #include <algorithm>
 #include <cfloat>
@@ -54,6 +54,8 @@ public:
     // PtIsInFrame (FrameKDMap.cpp:215-231) needs the camera model; the default accepts every point
     // (both query paths return the same neighbours for a single-frame map).
     std::function<bool(const Vector3d &)> ptIsInCurFrame = [](const Vector3d &) { return true; };
+    // mCurFrame.Twc (row-major).  The reference leaves it uninitialised until the first AddVertex; identity here.
+    double mTwc[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
     // ProcessDepth, obstacle cloud only (FrameKDMap.cpp:90-130): raw depth buffer (AMK_DEPTH_U16 / AMK_DEPTH_F32,
     // rows x cols, tightly packed) + Twb (row-major 4x4) -> points in the reference's row-major pixel order.
@@ -74,6 +76,43 @@ public:
             cloud.points[i].z = xyz[3 * i + 2];
         }
     }
+
+    // BuildEdgeCloud (FrameKDMap.cpp:176-214).  Twc is what the reference multiplies with Tbc at :209: mCurFrame.Twc,
+    // the PREVIOUS frame's Twb * Tbc.
+    template <class Cloud>
+    void BuildEdgeCloud(const void *depth, int depthType, int rows, int cols, const double *Twc, Cloud &edgeCloud) {
+        int w = 0, h = 0;
+        amk_throw(amk_depth_out_size(rows, cols, depthParams.resize_scale, &w, &h), "amk_depth_out_size");
+        std::vector<float> xyz((size_t)w * h * 3);
+        int n = 0;
+        amk_throw(amk_depth_to_edge_cloud_host(depth, depthType, rows, cols, (long long)rows * cols, 1, &depthParams, Twc,
+                                               xyz.data(), 3, (long long)w * h * 3, &n), "amk_depth_to_edge_cloud_host");
+        edgeCloud.points.resize((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            edgeCloud.points[i].x = xyz[3 * i];
+            edgeCloud.points[i].y = xyz[3 * i + 1];
+            edgeCloud.points[i].z = xyz[3 * i + 2];
+        }
+    }
+
+    // AddVertex(mat4Twb, depth) of the reference (FrameKDMap.cpp:34-51), the depth image as a raw buffer:
+    // ProcessDepth + BuildEdgeCloud (with the stale pose, as the reference), two fresh trees, swap, Twc = Twb * Tbc.
+    struct XYZ { float x, y, z; };
+    struct XYZCloud { std::vector<XYZ> points; };
+    void AddVertex(const double *Twb, const void *depth, int depthType, int rows, int cols) {
+        auto cloud = std::make_shared<XYZCloud>(), edgeCloud = std::make_shared<XYZCloud>();
+        ProcessDepth(depth, depthType, rows, cols, Twb, *cloud);
+        if (cloud->points.empty()) return;                                         // :39-41
+        BuildEdgeCloud(depth, depthType, rows, cols, mTwc, *edgeCloud);            // ProcessDepth's tail, :130
+        AddVertex(cloud, edgeCloud);
+        for (int i = 0; i < 4; ++i)                                                // mCurFrame.Twc = mat4Twb * mParamTbc, :50
+            for (int j = 0; j < 4; ++j) {
+                double acc = 0;
+                for (int k = 0; k < 4; ++k) acc += Twb[4 * i + k] * depthParams.Tbc[4 * k + j];
+                mTwc[4 * i + j] = acc;
+            }
+    }
+    const double *CurTwc() const { return mTwc; }
 
     // AddVertex after ProcessDepth (FrameKDMap.cpp:39-51): two fresh trees, then swap under the lock.
     template <class CloudPtr>

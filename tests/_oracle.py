@@ -285,3 +285,28 @@ def depth_oracle(depth, prm, Twb, stride=3):
                            C.byref(p), np.ascontiguousarray(Twb, np.float64).reshape(-1),
                            cloud.ctypes.data_as(C.c_void_p), stride, inv.ctypes.data_as(C.c_void_p))
     return cloud[:n], inv
+
+
+def depth_edge_oracle(depth, prm, Twc, stride=3):
+    """BuildEdgeCloud for one scene -> (cloud float32 [count, stride], quant, eroded, edges uint8 [H, W])."""
+    lib = load_oracle()
+    lib.deptho_edge.restype = C.c_int
+    lib.deptho_edge.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(DepthoParams), _f64p, C.c_void_p, C.c_int,
+                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    depth = np.ascontiguousarray(depth)
+    assert depth.dtype in (np.uint16, np.float32) and depth.ndim == 2
+    rows, cols = depth.shape
+    p = DepthoParams(prm["pixel2meter"], prm["depth_min"], prm["depth_max"], prm["resize_scale"], prm["fx"],
+                     prm["fy"], prm["cx"], prm["cy"])
+    T = np.asarray(prm.get("Tbc", np.eye(4)), np.float64).reshape(4, 4)
+    for i in range(16):
+        p.Tbc[i] = float(T.flat[i])
+    W, H = int(cols / prm["resize_scale"]), int(rows / prm["resize_scale"])
+    cloud = np.zeros((W * H, stride), np.float32)
+    quant = np.zeros((H, W), np.uint8); eroded = np.zeros((H, W), np.uint8); edges = np.zeros((H, W), np.uint8)
+    winv = np.zeros(H * W, np.float32); wmag = np.zeros(H * W, np.int16)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = lib.deptho_edge(vp(depth), 0 if depth.dtype == np.uint16 else 1, rows, cols, C.byref(p),
+                        np.ascontiguousarray(Twc, np.float64).reshape(-1), vp(cloud), stride, vp(quant), vp(eroded),
+                        vp(edges), vp(winv), vp(wmag))
+    return cloud[:n], quant, eroded, edges

@@ -154,6 +154,17 @@ int main(int argc, char **argv) {
         int cnt = (int)dc.points.size();
         wr(o, &cnt, 1);
         for (auto &p : dc.points) { float v[3] = {p.x, p.y, p.z}; wr(o, v, 3); }
+        // 7. the reference's AddVertex(Twb, depth) twice (FrameKDMap.cpp:34-51): the second frame's edge cloud is
+        //    back-projected with the FIRST frame's Twb * Tbc (:209); then the Edge-KD-tree query of PlanWapionts
+        const double Twb2[16] = {1, 0, 0, 2.5, 0, 1, 0, -1.0, 0, 0, 1, 1.5, 0, 0, 0, 1};
+        dmap.AddVertex(Twb, img.data(), AMK_DEPTH_U16, rows, cols);
+        dmap.AddVertex(Twb2, img.data(), AMK_DEPTH_U16, rows, cols);
+        int ecnt = (int)dmap.CurFrame().edgeCloud->GetPointCloud().pts.size();
+        wr(o, &ecnt, 1);
+        std::vector<Vector3d> epts; std::vector<double> ed2;
+        dmap.QueryNearest(Vector3d(3.0, -1.0, 1.5), 1, epts, ed2, true);
+        int ec = (int)ed2.size();
+        wr(o, &ec, 1); wr(o, ed2.data(), ec);
     }
     fclose(o);
     return 0;

@@ -110,4 +110,11 @@ def test_adapters_match_oracle(tmp_path):
     cnt = int(take(np.int32, 1)[0])
     pts = take(np.float32, 3 * cnt).reshape(-1, 3)
     assert cnt == len(ref) > 500 and np.array_equal(pts, ref)
+    # 7. AddVertex(Twb, depth) twice: edge cloud of frame 2 uses frame 1's Twb * Tbc
+    eref = _oracle.depth_edge_oracle(img, dprm, Twb @ dprm["Tbc"])[0]
+    ecnt = int(take(np.int32, 1)[0])
+    assert ecnt == len(eref) > 20
+    ec = int(take(np.int32, 1)[0]); ed2 = take(np.float64, ec)
+    et = _oracle.kd_oracle(eref)
+    assert ec == 1 and ed2[0] == et.search(np.array([3.0, -1.0, 1.5]), 1)[1][0]
     assert off == len(buf)
