@@ -75,13 +75,15 @@ struct LdsMap {
         X = take((N + 1) * SD); U = take(N * UD); zl = take(N * UD); zu = take(N * UD);
         dX = take((N + 1) * SD); dU = take(N * UD);
         q = take((N + 1) * SD); r = take(N * UD); rb = take(N * UD); Rb = take(N * UD); gU = take(N * UD);
-        // buffers with disjoint lifetimes share storage: the derivative blocks q, r, r_bar, R_bar are dead once
-        // the backward sweep has run; the dual steps and the line-search trial point are born after it
-        Xt = q; Ut = rb; dzl = Rb; dzu = r;
+        // (the dual steps and the line-search trial point alias the gains, below)
         H6 = take(N * 21); rotQ = take(N * 6);
         P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
         Atp = take(SD); Atl = take(SD); qu = take(UD); Y = 0; Z = 0; D = 0;
         Kk = take(N * KK_STAGE); red = take(16);
+        // buffers with disjoint lifetimes share storage: the gains are dead once the forward roll has run; the dual
+        // steps and the line-search trial point are born after it.  (Not on q / r: the first trial point is evaluated
+        // WITH derivatives, into q, r, H6, so that an accepted full step needs no second evaluation.)
+        Xt = Kk; Ut = Xt + (N + 1) * SD; dzl = Ut + N * UD; dzu = dzl + N * UD;
         total = o;
     }
 };

@@ -448,11 +448,16 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     real delta_last = RL(0.0), a_last = RL(0.0);
     int status = 1, n_reg = 0, ls_fail = 0, it = 0;
     const int nvar = UD * N;
+    // The first line-search trial is evaluated with derivatives: when it is accepted (the common case) the next
+    // iteration finds q, r, H6 and J of its iterate already in LDS.  Same values as a fresh evaluation.
+    bool have_derivs = false;
+    real J_carried = RL(0.0);
 #pragma unroll 1
     for (it = 0; it < opt.max_iter; ++it) {
         const long long t0 = AMK_CLK();
         long long tclk[3] = {0, 0, 0};
-        const real J = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U, kTrace ? tclk : nullptr);
+        const real J = have_derivs ? J_carried
+                                   : evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U, kTrace ? tclk : nullptr);
         __syncthreads();
         const long long t1 = AMK_CLK();
         if (it > 0 && a_last >= RL(0.5)) mu = fmax(mu_min, o_kappa_mu * mu);
@@ -527,12 +532,22 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         const long long t4 = AMK_CLK();
         real a = a_pr;
         bool accepted = false;
+        const bool speculate = it + 1 < opt.max_iter;  // the last iteration has no successor to hand derivatives to
+        have_derivs = false;
         for (int ls = 0; ls < opt.max_ls; ++ls) {
             __syncthreads();
             for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
             for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
             __syncthreads();
-            real phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
+            real phi;
+            if (ls == 0 && speculate) {
+                phi = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
+                J_carried = phi;
+                have_derivs = true;
+            } else {
+                phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
+                have_derivs = false;  // the iterate moves on to a point that has no derivatives yet
+            }
             real lg = RL(0.0);
             for (int e = lane; e < nvar; e += 64) {
                 const int i = e % UD;
