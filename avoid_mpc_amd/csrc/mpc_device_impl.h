@@ -148,14 +148,17 @@ __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneI
         __syncthreads();
     }
     const long long tc0 = AMK_CLK();
-    const int nterm = (N - 1) * K;
-    for (int t0 = 0; t0 < nterm; t0 += 64) {
-        const int t = t0 + lane;
-        if (t < nterm) {
-            const int k = t / K;
+    // lane = (obstacle slot, stage), stage fastest: a round covers `per` obstacle points of EVERY stage, so a stage's
+    // LDS cells see `per` (3 at N = 20) colliding ds_add_f64 per instruction instead of K (8) with the obstacle
+    // index fastest -- the atomics are a fifth of the kernel's LDS time
+    const int ns = N - 1, per = 64 / ns;
+    const int jl = lane / ns, k = lane - jl * ns;
+    for (int j0 = 0; j0 < K; j0 += per) {
+        const int j = j0 + jl;
+        if (jl < per && j < K) {
             const real *xk = Xs + (k + 1) * SD;
             const real p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
-            const double *op = io.obs + (size_t)t * 3;  // [k][j][3]
+            const double *op = io.obs + ((size_t)k * K + j) * 3;  // [k][j][3]
             const real o[3] = {(real)op[0], (real)op[1], (real)op[2]};
             Jloc += collide_point<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
         }
