@@ -20,7 +20,7 @@ namespace amk {
 thread_local int g_last_hip_error = 0;
 
 struct Timing {
-    int mode = 0;  // 0 off, 1 KC_SOLVE only, 2 every kernel class
+    int mode = 0;  // 0 off, 1 KC_SOLVE and KC_GRID (the dominant kernel and the HBM-heavy one), 2 every kernel class
     struct Rec { int kclass; hipEvent_t a, b; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
@@ -35,7 +35,7 @@ Timing &timing() { static Timing t; return t; }
 
 TimedLaunch::TimedLaunch(int kclass, hipStream_t s) : slot(-1), stream(s) {
     Timing &t = timing();
-    if (t.mode == 0 || (t.mode == 1 && kclass != KC_SOLVE)) return;
+    if (t.mode == 0 || (t.mode == 1 && kclass != KC_SOLVE && kclass != KC_GRID)) return;
     Timing::Rec r{kclass, t.get(), t.get()};
     (void)hipEventRecord(r.a, stream);
     slot = (int)t.recs.size();

@@ -236,6 +236,9 @@ def main():
         alg_launch = solve_alg_bytes(N, prm.K) * S
         achieved = alg_launch / (solve_ms * 1e-3) / 1e9
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
+        build_ms = ms[7] / max(cnt[7], 1)
+        build_alg = 64 * S * (n + ne) // 2       # mean of the obstacle and the edge launch
+        build_traffic = None
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath):   # PMC passes cannot run inside this process: reuse the committed rocprofv3 result
@@ -243,6 +246,9 @@ def main():
             m = tj.get("_meta", {})
             if (m.get("scenes_per_gpu"), m.get("points"), m.get("horizon"), m.get("K")) == (S, n, N, prm.K):
                 kk = tj["kernels"].get(f"mpc_solve_kernel<{N}>")
+                kb = tj["kernels"].get("kd_build_kernel")
+                if kb:
+                    build_traffic = round(kb["hbm_bytes_per_launch_x2"])
                 if kk:
                     traffic = round(kk["hbm_bytes_per_launch_x2"])
                     traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
@@ -264,7 +270,17 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(solve_ms, 4), "launches": cnt[5],
                          "alg_bytes_per_launch": alg_launch,
-                         "note": "dominant kernel by time; it is fp64-VALU/latency bound, not HBM bound"},
+                         "note": "dominant kernel by time; it is bound by LDS bandwidth and dependent-op latency "
+                                 "(DESIGN.md section 5), not by HBM; avg_launch_ms is submit-to-complete on the launch "
+                                 "stream with 15 other steps in flight"},
+            "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (obstacle + edge launch averaged)",
+                                  "alg_bytes_per_launch": build_alg, "avg_launch_ms": round(build_ms, 4),
+                                  "launches": cnt[7], "achieved": round(build_alg / (build_ms * 1e-3) / 1e9, 1),
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(build_alg / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                  "traffic": build_traffic,
+                                  "note": "the HBM-heavy kernel: 64 B per point (12 read + 12 written as SoA planes, "
+                                          "12 re-read twice, 16 written as bucket records)"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},
