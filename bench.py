@@ -253,7 +253,7 @@ def main():
                     traffic = round(kk["hbm_bytes_per_launch_x2"])
                     traffic_src = "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
         line = {
-            "metric": "MPC steps/sec (50k-pt cloud, N=20, 8 obstacle constraints)",
+            "metric": f"MPC steps/sec ({n // 1000}k-pt cloud, N={N}, {prm.K} obstacle constraints)",
             "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
