@@ -115,6 +115,7 @@ __device__ __forceinline__ int pv_inv(int s) { return s < 3 ? s : (s >= 4 && s <
 // (mpc_solve.hip: build_plan) from the non-zeros of A (19) and B (10).  128 items = 2 per lane.
 constexpr int PLAN_ITEMS = 128;
 constexpr int PLAN_TERMS = 9;
+constexpr int PLAN_TERMS_LIGHT = 3;   // the host sorts the items by term count: the second item of every lane has <= 3 terms
 struct PlanItemMeta {            // one per item, ints
     int idx[PLAN_TERMS];         // LDS offsets (doubles) of the source cells (unused terms: the zero cell)
     int out;                     // LDS offset of the result (+ k * out_kstride)

@@ -241,9 +241,11 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
         const int e = lane + 64 * h;
         const PlanItemMeta *m = reinterpret_cast<const PlanItemMeta *>(plan_meta) + e;
 #pragma unroll
-        for (int t = 0; t < PLAN_TERMS; ++t) lp.idx[h][t] = m->idx[t];
+        for (int t = 0; t < PLAN_TERMS; ++t)
+            if (h == 0 || t < PLAN_TERMS_LIGHT) lp.idx[h][t] = m->idx[t];
 #pragma unroll
-        for (int t = 0; t <= PLAN_TERMS; ++t) lp.coef[h][t] = plan_coef[e * (PLAN_TERMS + 1) + t];
+        for (int t = 0; t <= PLAN_TERMS; ++t)
+            if (h == 0 || t < PLAN_TERMS_LIGHT || t == PLAN_TERMS) lp.coef[h][t] = plan_coef[e * (PLAN_TERMS + 1) + t];
         lp.out[h] = m->out; lp.out_kstride[h] = m->out_kstride; lp.aux[h] = m->aux; lp.aux_kstride[h] = m->aux_kstride;
     }
     lp.role = reinterpret_cast<const LaneRole *>(plan_meta + PLAN_ITEMS * (PLAN_TERMS + 4))[lane];
@@ -282,21 +284,26 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
         // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, q + A'lam,
         // r_bar + B'p, r + B'lam)
         {
-            real v[2][PLAN_TERMS], ax[2];
+            // item 0: up to 9 terms; item 1: up to 3 (the items are sorted by term count on the host: 460 terms in
+            // 109 items, so the light half of the slots needs a third of the loads and FMAs)
+            real v[PLAN_TERMS], u[PLAN_TERMS_LIGHT], ax[2];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
+            for (int t = 0; t < PLAN_TERMS; ++t) v[t] = sm[lp.idx[0][t]];
 #pragma unroll
-                for (int t = 0; t < PLAN_TERMS; ++t) v[h][t] = sm[lp.idx[h][t]];
-                ax[h] = sm[lp.aux[h] + k * lp.aux_kstride[h]];
+            for (int t = 0; t < PLAN_TERMS_LIGHT; ++t) u[t] = sm[lp.idx[1][t]];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) ax[h] = sm[lp.aux[h] + k * lp.aux_kstride[h]];
+            {   // four partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
+                const real *c = lp.coef[0];
+                real a0 = c[0] * v[0], a1 = c[1] * v[1], a2 = c[2] * v[2], a3 = fma(c[PLAN_TERMS], delta, ax[0]);
+                a0 = fma(c[3], v[3], a0); a1 = fma(c[4], v[4], a1); a2 = fma(c[5], v[5], a2);
+                a0 = fma(c[6], v[6], a0); a1 = fma(c[7], v[7], a1); a2 = fma(c[8], v[8], a2);
+                sm[lp.out[0] + k * lp.out_kstride[0]] = (a0 + a1) + (a2 + a3);
             }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                // four partial sums: a dependent fp64 FMA is 32 cycles on this chip, an independent one 4
-                const real *c = lp.coef[h];
-                real a0 = c[0] * v[h][0], a1 = c[1] * v[h][1], a2 = c[2] * v[h][2], a3 = fma(c[PLAN_TERMS], delta, ax[h]);
-                a0 = fma(c[3], v[h][3], a0); a1 = fma(c[4], v[h][4], a1); a2 = fma(c[5], v[h][5], a2);
-                a0 = fma(c[6], v[h][6], a0); a1 = fma(c[7], v[h][7], a1); a2 = fma(c[8], v[h][8], a2);
-                sm[lp.out[h] + k * lp.out_kstride[h]] = (a0 + a1) + (a2 + a3);
+            {
+                const real *c = lp.coef[1];
+                const real a0 = c[0] * u[0], a1 = c[1] * u[1], a2 = c[2] * u[2], a3 = fma(c[PLAN_TERMS], delta, ax[1]);
+                sm[lp.out[1] + k * lp.out_kstride[1]] = (a0 + a1) + (a2 + a3);
             }
         }
         __syncthreads();

@@ -6,6 +6,7 @@
 #include "mpc_handle.h"
 
 #include <cmath>
+#include <algorithm>
 #include <cstring>
 #include <utility>
 #include <vector>
@@ -121,6 +122,10 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
     for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.p), L.qu + a, 0, L.rb + a, UD, 0.0});
     for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.lam), L.gU + a, UD, L.r + a, UD, 0.0});
     if ((int)items.size() > PLAN_ITEMS) return AMK_ERR_UNSUPPORTED;
+    // heavy items first: lane l executes items l (<= 9 terms) and 64 + l (<= PLAN_TERMS_LIGHT terms)
+    std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.t.size() > b.t.size(); });
+    for (size_t e = 64; e < items.size(); ++e)
+        if ((int)items[e].t.size() > PLAN_TERMS_LIGHT) return AMK_ERR_UNSUPPORTED;
     coef.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2, 0.0);
     meta.assign((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS, 0);
     for (int e = 0; e < PLAN_ITEMS; ++e) {
