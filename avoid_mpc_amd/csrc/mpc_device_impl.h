@@ -108,27 +108,36 @@ __device__ __forceinline__ real collide_point(const real p[3], const real v[3], 
         unsafeAtomicAdd(gq + i, ls * (gp * (-n[i]) * s + g * (-t[i] * ir)));       // state slots 0,1,2 = p
         unsafeAtomicAdd(gq + 4 + i, ls * g * n[i]);                                // state slots 4,5,6 = v
     }
-    const real gs[6] = {-t[0] * ir, -t[1] * ir, -t[2] * ir, n[0], n[1], n[2]};
+    // Model Hessian of the term w.r.t. (p, v), written out in the three rank-structured blocks (n = unit vector to the
+    // obstacle, t = v - s n, s = v.n, g/g'/g'' the softplus and its derivatives in rho):
+    //   H_pp = al t t' + A n n' + C (n t' + t n') + B I     H_vp = -be n t' + D n n' + E I     H_vv = wk n n'
+    // (the same sums as oracle collide_point's entry-by-entry expressions, common factors pulled out)
     const real wk = lam * g * fast_rcp(as > kAbsEps ? as : kAbsEps);
+    const real ir2 = ir * ir, gir = g * ir, gpir = gp * ir;
+    const real al = wk * ir2, be = wk * ir;
+    const real A = ls * s * (gpp - gpir + g * ir2), B = ls * s * (gpir - g * ir2), Cc = ls * (gpir - g * ir2);
+    const real D = ls * (gir - gp), E = -ls * gir;
     // lower triangle, row-major: (i,j), j <= i, index i(i+1)/2 + j
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
+    for (int i = 0; i < 3; ++i)
 #pragma unroll
         for (int j = 0; j <= i; ++j) {
-            real h = wk * gs[i] * gs[j];
-            if (i < 3) {  // pp block
-                const real nn = n[i] * n[j];
-                const real Pn = (i == j ? RL(1.0) : RL(0.0)) - nn;
-                h += ls * (gpp * nn * s + gp * Pn * ir * s + gp * (n[i] * t[j] * ir + t[i] * ir * n[j]) +
-                           g * (-(t[i] * n[j] + n[i] * t[j]) * ir * ir - s * Pn * ir * ir));
-            } else if (j < 3) {  // vp block: H[v_i][p_j] = Hpv[j][i-3] (symmetric expression)
-                const int a = i - 3;
-                const real nn = n[a] * n[j];
-                const real Pn = (a == j ? RL(1.0) : RL(0.0)) - nn;
-                h += ls * (-gp * nn - g * Pn * ir);
-            }
+            real h = al * t[i] * t[j] + A * n[i] * n[j] + Cc * (n[i] * t[j] + t[i] * n[j]);
+            if (i == j) h += B;
             unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
         }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = 3 + a;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // H[v_a][p_j]
+            real h = n[a] * (D * n[j] - be * t[j]);
+            if (a == j) h += E;
+            unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
+        }
+#pragma unroll
+        for (int bb = 0; bb <= a; ++bb) unsafeAtomicAdd(h21 + i * (i + 1) / 2 + 3 + bb, wk * n[a] * n[bb]);
+    }
     return cost;
 }
 
