@@ -14,13 +14,17 @@ def scene_range(rank, world, total):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_controls(u_local, counts=None):
+def gather_controls(u_local, counts=None, out=None):
     """all_gather of per-scene controls [S_local, 4] -> [S_total, 4] in global scene order.
-    Uneven shards are padded to the largest one (RCCL/gloo all_gather wants equal shapes)."""
+    Uneven shards are padded to the largest one (RCCL/gloo all_gather wants equal shapes).
+    out: optional preallocated [world * S_local, 4] for the equal-shard case (one collective, no temporaries)."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return u_local
     world = dist.get_world_size()
     if counts is None:
+        if out is not None:
+            dist.all_gather_into_tensor(out, u_local.contiguous())
+            return out
         counts = [u_local.shape[0]] * world
     m = max(counts)
     pad = u_local

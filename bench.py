@@ -169,6 +169,7 @@ def main():
             self.kd_o, self.kd_e = KdBatch(S, n), KdBatch(S, ne)
             self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm); self.mpc.set_precision(args.precision)
             self.ref = ref0_d.clone()
+            self.u_all = torch.empty((S * world, 4), dtype=torch.float64, device=dev) if world > 1 else None
             self.out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
                             x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
                             flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
@@ -187,7 +188,7 @@ def main():
             sl.kd_e.build(edges, stream=sl.stream)    # ... and edge index (FrameKDMap.cpp:44-47)
             step_batch(sl.kd_o, sl.kd_e, sl.mpc, prm, sq_d, posx_d, sl.ref, stream=sl.stream, out=sl.out)
             if world > 1:
-                shard.gather_controls(sl.out["u"])    # the one exchange step: controls to every rank
+                shard.gather_controls(sl.out["u"], out=sl.u_all)   # the one exchange step: controls to every rank
 
     def barrier():
         torch.cuda.synchronize()
