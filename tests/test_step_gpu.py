@@ -111,3 +111,15 @@ def test_edge_snap_and_unsafe_and_tiny_clouds(torch_cuda):
     assert fl[0, 0] == 1 and fl[1, 0] == 0 and fl[2, 0] == 0          # isSafety
     assert fl[6, 1] == 1                                              # one solve, then :333-335 exit
     assert np.allclose(gpu[0]["ref_path"][0][0, :3], cpu[0][0]["ref_path"][0, :3])
+
+
+def test_results_are_bit_reproducible(torch_cuda):
+    """The LDS atomics of the objective evaluation are applied in lane order and every reduction has a fixed shape:
+    the same inputs give the same bits, run after run."""
+    prm = synth.MpcParams(T=0.66, K=8)
+    scenes = [synth.make_scene(20000, 900 + i, prm) for i in range(6)]
+    outs = []
+    for _ in range(3):
+        gpu, _cpu = run_both(torch_cuda, scenes, prm, n_steps=2)
+        outs.append(np.concatenate([gpu[1]["u"].ravel(), gpu[1]["x0array"].ravel()]).view(np.uint64))
+    assert all(np.array_equal(outs[0], o) for o in outs[1:])
