@@ -219,14 +219,16 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
 }
 
 // Exact k nearest neighbours of (qx,qy,qz).  On return lane i < k holds the i-th best (squared
-// distance, index) in (ld, li); empty slots hold (DBL_MAX, kNoIndex).  Ties order by index.
+// distance, index) in (ld, li) and the position of its record in gs.pt in lpos (the neighbour's coordinates are
+// gs.pt[lpos]: the index build keeps no index-ordered copy of the points); empty slots hold (DBL_MAX, kNoIndex, 0).
+// Ties order by index.
 //
 // The cells are visited in Chebyshev rings around the query's cell (shell (rp, r] with r = rp + 1; two rings per
 // round were measured slower: the BASELINE clouds are dense enough that ring r + 1 is rarely needed).  Once k
 // candidates are known, a ring only visits the cells that the ball of the current k-th distance reaches: a row
 // (iy, iz) is skipped when its slab is farther than that, and its run of cells is clipped to the ball's x extent.
 __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double qy, double qz, int k, double &ld,
-                                         int &li, GridWaveLds *ws) {
+                                         int &li, int &lpos, GridWaveLds *ws) {
     const int lane = threadIdx.x & 63;
     const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
     const double h = gs.gp[3], inv_h = gs.gp[4];
@@ -237,6 +239,7 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     for (int a = 0; a < 3; ++a) c[a] = (q[a] == q[a]) ? cell_of(q[a], b[a], inv_h, g[a]) : 0;
     ld = DBL_MAX;
     li = kNoIndex;
+    lpos = 0;
     double tau = DBL_MAX;
     int rmax = 0;
 #pragma unroll
@@ -294,9 +297,10 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             const int total = __builtin_amdgcn_readlane(incl, 63);
             ws->pre[lane] = incl - (lA + lB);
             ws->sA[lane] = sA; ws->lA[lane] = lA; ws->sB[lane] = sB;
-            auto fetch = [&](int t, double &d, int &ic) {
+            auto fetch = [&](int t, double &d, int &ic, int &ip) {
                 d = __builtin_nan("");
                 ic = kNoIndex;
+                ip = 0;
                 if (t < total) {
                     int lo = 0, hi = 64;  // largest o with pre[o] <= t
 #pragma unroll
@@ -310,37 +314,42 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     const float4 p4 = gs.pt[pos];
                     d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
                     ic = __float_as_int(p4.w);
+                    ip = pos;
                 }
             };
             double d, dn;
-            int ic, icn;
-            fetch(lane, d, ic);
+            int ic, icn, ip, ipn;
+            fetch(lane, d, ic, ip);
             for (int t0 = 0; t0 < total; t0 += 64) {
-                if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn);  // next batch in flight while this one is merged
+                if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn, ipn);  // next batch in flight while this one is merged
                 unsigned long long m = __ballot(d <= tau);
                 while (m) {  // a lane beats (or ties) the current k-th best
                     const int src = __ffsll((long long)m) - 1;
                     m &= m - 1;
                     const double dc = readlane_f64(d, src);
                     const int icc = __builtin_amdgcn_readlane(ic, src);
+                    const int ipc = __builtin_amdgcn_readlane(ip, src);
                     // rank of the candidate in (distance, index) order among the kept entries
                     const bool lt = (lane < k) && (ld < dc || (ld == dc && li < icc));
                     const int pos = __popcll(__ballot(lt));
                     if (pos < k && dc < DBL_MAX) {
                         const double up_d = wave_shr1_f64(ld);
-                        const int up_i = wave_shr1_i32(li);
+                        const int up_i = wave_shr1_i32(li), up_p = wave_shr1_i32(lpos);
                         if (lane > pos) {
                             ld = up_d;
                             li = up_i;
+                            lpos = up_p;
                         } else if (lane == pos) {
                             ld = dc;
                             li = icc;
+                            lpos = ipc;
                         }
                         tau = readlane_f64(ld, k - 1);
                     }
                 }
                 d = dn;
                 ic = icn;
+                ip = ipn;
             }
         }
         // everything within Chebyshev radius r of the query's cell has been seen.  A cell outside that box

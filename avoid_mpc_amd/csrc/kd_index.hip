@@ -261,10 +261,7 @@ __global__ __launch_bounds__(512) void kd_scan_kernel(
 }
 
 // search over the bucketed index: one wavefront per (scene, query), four queries of a scene per block
-__global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, const float *__restrict__ X,
-                                                             const float *__restrict__ Y,
-                                                             const float *__restrict__ Z,
-                                                             const int *__restrict__ sizes, int n_scenes,
+__global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, const int *__restrict__ sizes, int n_scenes,
                                                              const double *__restrict__ queries, int n_queries,
                                                              int k, int *__restrict__ out_idx,
                                                              double *__restrict__ out_d2,
@@ -280,8 +277,9 @@ __global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, 
     const size_t row = (size_t)s * n_queries + q;
     const double *qp = queries + row * 3;
     double ld;
-    int li;
-    amk::grid_knn(gpt.scene(s), qp[0], qp[1], qp[2], k, ld, li, &wl[w]);
+    int li, lpos;
+    const amk::GridScene gs = gpt.scene(s);
+    amk::grid_knn(gs, qp[0], qp[1], qp[2], k, ld, li, lpos, &wl[w]);
     const int size = sizes[s];
     const int cnt = size < k ? size : (size > k ? k : 0);  // kd_tree_two.h:119-124
     if (lane == 0 && out_cnt) out_cnt[row] = cnt;
@@ -291,11 +289,11 @@ __global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, 
         if (out_idx) out_idx[row * k + lane] = idx;
         if (out_d2) out_d2[row * k + lane] = ok ? ld : DBL_MAX;
         if (out_pts) {
-            const size_t base = (size_t)s * gpt.cap;
+            const float4 rec = gs.pt[lpos];  // lpos = 0 for empty slots: a valid address
             float *o = out_pts + (row * k + lane) * 3;
-            o[0] = ok ? X[base + idx] : 0.f;
-            o[1] = ok ? Y[base + idx] : 0.f;
-            o[2] = ok ? Z[base + idx] : 0.f;
+            o[0] = ok ? rec.x : 0.f;
+            o[1] = ok ? rec.y : 0.f;
+            o[2] = ok ? rec.z : 0.f;
         }
     }
 }
@@ -573,9 +571,8 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
     if (kd->mode == 0) {
         const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap};
         const int blocks = (kd->n_scenes + 7) / 8 * 8 * ((n_queries + 3) / 4);
-        hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->x.p, kd->y.p,
-                           kd->z.p, kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts,
-                           d_counts);
+        hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p,
+                           kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts);
         AMK_HIP(hipGetLastError());
         return AMK_OK;
     }

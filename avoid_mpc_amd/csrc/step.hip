@@ -77,12 +77,7 @@ __global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict_
 // Same outputs through the bucketed indices (kd_grid.h), both trees in one launch: wavefront q < N answers
 // the K-NN of reference point q in the obstacle index, wavefront q == N the 1-NN of reference point 0 in
 // the edge index (the Edge-KD-tree query of PlanWapionts, :270).
-__global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridPtrs gedge, const float *__restrict__ Xo,
-                                                            const float *__restrict__ Yo,
-                                                            const float *__restrict__ Zo,
-                                                            const float *__restrict__ Xe,
-                                                            const float *__restrict__ Ye,
-                                                            const float *__restrict__ Ze, int n_scenes,
+__global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridPtrs gedge, int n_scenes,
                                                             const double *__restrict__ ref_path, int N, int K,
                                                             float *__restrict__ knn_pts, double *__restrict__ knn_d2,
                                                             float *__restrict__ edge_pt, double *__restrict__ edge_d2,
@@ -100,24 +95,24 @@ __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridP
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;  // read in place from mRefPath
     const int k = is_edge ? 1 : K;
     double ld;
-    int li;
-    grid_knn(is_edge ? gedge.scene(s) : gobs.scene(s), qp[0], qp[1], qp[2], k, ld, li, &wl[w]);
+    int li, lpos;
+    const GridScene gs = is_edge ? gedge.scene(s) : gobs.scene(s);
+    grid_knn(gs, qp[0], qp[1], qp[2], k, ld, li, lpos, &wl[w]);
     if (lane < k) {
         const bool ok = li != kNoIndex;
+        const float4 rec = gs.pt[lpos];  // the neighbour's coordinates (lpos = 0 for an empty slot: a valid address)
         if (is_edge) {
-            const size_t base = (size_t)s * gedge.cap;
             edge_d2[s] = ok ? ld : DBL_MAX;
-            edge_pt[3 * s + 0] = ok ? Xe[base + li] : 0.f;
-            edge_pt[3 * s + 1] = ok ? Ye[base + li] : 0.f;
-            edge_pt[3 * s + 2] = ok ? Ze[base + li] : 0.f;
+            edge_pt[3 * s + 0] = ok ? rec.x : 0.f;
+            edge_pt[3 * s + 1] = ok ? rec.y : 0.f;
+            edge_pt[3 * s + 2] = ok ? rec.z : 0.f;
         } else {
-            const size_t base = (size_t)s * gobs.cap;
             const size_t row = (size_t)s * N + q;
             knn_d2[row * K + lane] = ok ? ld : DBL_MAX;
             float *o = knn_pts + (row * K + lane) * 3;
-            o[0] = ok ? Xo[base + li] : 0.f;
-            o[1] = ok ? Yo[base + li] : 0.f;
-            o[2] = ok ? Zo[base + li] : 0.f;
+            o[0] = ok ? rec.x : 0.f;
+            o[1] = ok ? rec.y : 0.f;
+            o[2] = ok ? rec.z : 0.f;
         }
     }
 }
@@ -157,9 +152,10 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_
             __shared__ GridWaveLds wl1;
             __shared__ double q1[3];
             double gld = DBL_MAX;
-            int gli = kNoIndex;
+            int gli = kNoIndex, glpos = 0;
+            const GridScene gs = gpt.scene(s);
             if (use_grid) {
-                grid_knn(gpt.scene(s), ex, ey, ez, K, gld, gli, &wl1);
+                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl1);
             } else {
                 q1[0] = ex; q1[1] = ey; q1[2] = ez;  // every lane stores the same values
                 scan_cloud<1>(xs, ys, zs, size_o, pmax_obs[s], q1, 3, K, &ws1);
@@ -169,9 +165,16 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_
                 const bool ok = li != kNoIndex;
                 knn_d2[(size_t)s * N * K + lane] = ok ? (use_grid ? gld : ws1.ld[0][lane]) : DBL_MAX;
                 float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
-                o[0] = ok ? xs[li] : 0.f;
-                o[1] = ok ? ys[li] : 0.f;
-                o[2] = ok ? zs[li] : 0.f;
+                float nx = 0.f, ny = 0.f, nz = 0.f;
+                if (use_grid) {
+                    const float4 rec = gs.pt[glpos];
+                    nx = rec.x; ny = rec.y; nz = rec.z;
+                } else if (ok) {
+                    nx = xs[li]; ny = ys[li]; nz = zs[li];
+                }
+                o[0] = ok ? nx : 0.f;
+                o[1] = ok ? ny : 0.f;
+                o[2] = ok ? nz : 0.f;
             }
             if (lane == 0) {
                 p1[0] = ex;
@@ -261,9 +264,9 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         if (use_grid) {
             TimedLaunch tl(KC_SCAN_OBS, stream);
-            hipLaunchKernelGGL(step_knn_grid_kernel, dim3(S8 * ((N + 4) / 4)), dim3(256), 0, stream, gobs, gedge,
-                               obstacle->x.p, obstacle->y.p, obstacle->z.p, edge->x.p, edge->y.p, edge->z.p, S, d_ref_path,
-                               N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p);
+            hipLaunchKernelGGL(step_knn_grid_kernel, dim3(S8 * ((N + 4) / 4)), dim3(256), 0, stream, gobs, gedge, S,
+                               d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
+                               mpc->done.p);
         } else {
         { TimedLaunch tl(KC_SCAN_OBS, stream);
         hipLaunchKernelGGL(step_scan_kernel<5>, dim3(S8 * bps), dim3(wpb * kWave), scan_lds_bytes<5>(wpb), stream,
