@@ -77,7 +77,10 @@ struct amk_kd {
     int n_scenes = 0;
     int max_points = 0;
     int cap = 0;  // per-scene SoA capacity, multiple of 256 with >= 1024 floats of NaN padding
-    amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded
+    amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded -- made ON DEMAND from the
+                                 // bucket records (ensure_soa, kd_index.hip): the build does not write them
+    int soa_valid = 0;           // host flag: x/y/z match the current index
+    amk::DevBuf<int> grp;        // [S][cap/64 + 2] kept points before every 64-point group of the caller's cloud
     amk::DevBuf<int> size;       // [S] cloud.pts.size() after the NaN-x filter
     amk::DevBuf<float> pmax;     // [S] max |coordinate| of the kept points (bounds the fp32 pre-filter error)
     // bucketed index (kd_grid.h): bucket-contiguous copy of the points, their cloud indices, bucket starts

@@ -43,13 +43,35 @@ __device__ __forceinline__ int cell_of(double p, double bbmin, double inv_h, int
     return (int)c;
 }
 
-// the index of scene s from its compacted SoA planes; called by every thread of a kGridBuildThreads block
-__device__ __forceinline__ void grid_build_scene(int s, const float *__restrict__ X, const float *__restrict__ Y,
-                                                 const float *__restrict__ Z, int cap, int n,
+// Where the build reads its points.  SoaSrc: the compacted planes (the keyframe sweep rebuilds from them).
+// RawSrc: the caller's AoS cloud, straight (amk_kd_build): the NaN-x filter of KDTreeTwo::InitializeNew
+// (kd_tree_two.h:96-101) is applied on the fly and a kept point's cloud index is the number of kept points before it
+// = base of its 64-point group (a small table made by the pre-pass) + kept lanes below it in the wave.  No
+// index-ordered copy of the cloud is written: that copy cost a third of the build (197 vs 294 us in flight).
+struct SoaSrc {
+    static constexpr bool kFilter = false;
+    const float *xs, *ys, *zs;
+    __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const { x = xs[i]; y = ys[i]; z = zs[i]; }
+    __device__ __forceinline__ int group_base(int) const { return 0; }
+};
+struct RawSrc {
+    static constexpr bool kFilter = true;
+    const float *p;
+    int stride;
+    const int *grp;  // kept points before 64-point group g
+    __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const {
+        const float *q = p + (size_t)i * stride;
+        x = q[0]; y = q[1]; z = q[2];
+    }
+    __device__ __forceinline__ int group_base(int g) const { return grp[g]; }
+};
+
+// the index of scene s; called by every thread of a kGridBuildThreads block.  nvis points are visited, n of them kept.
+template <class Src>
+__device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, int nvis, int n,
                                                  const float *__restrict__ bbox, float4 *__restrict__ GP,
                                                  int *__restrict__ cell_start, double *__restrict__ gparams) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
     float4 *gpt4 = GP + (size_t)s * cap;  // bucket-contiguous points: (x, y, z, cloud index as int bits)
     int *cs = cell_start + (size_t)s * (kGridMaxCells + 2);
     double *gp = gparams + (size_t)s * kGridParamDoubles;
@@ -105,17 +127,18 @@ __device__ __forceinline__ void grid_build_scene(int s, const float *__restrict_
                    ? (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0)
                    : ncell;
     };
-    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
+    for (int i0 = tid; i0 < nvis; i0 += kGridUnroll * kGridBuildThreads) {
         float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            const int ii = i < n ? i : i0;
-            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
+            src.load(i < nvis ? i : i0, x[j], y[j], z[j]);
         }
 #pragma unroll
-        for (int j = 0; j < kGridUnroll; ++j)
-            if (i0 + j * kGridBuildThreads < n) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+        for (int j = 0; j < kGridUnroll; ++j) {
+            const bool keep = i0 + j * kGridBuildThreads < nvis && (!Src::kFilter || !(x[j] != x[j]));
+            if (keep) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+        }
     }
     __syncthreads();
     // 4. exclusive scan of hist[0 .. ncell] -> bucket starts (global) and scatter cursors (LDS)
@@ -148,20 +171,25 @@ __device__ __forceinline__ void grid_build_scene(int s, const float *__restrict_
     __syncthreads();
     // 5. scatter into bucket-contiguous order (order inside a bucket is irrelevant: results are ordered by
     // (distance, original index))
-    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
+    for (int i0 = tid; i0 < nvis; i0 += kGridUnroll * kGridBuildThreads) {
         float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            const int ii = i < n ? i : i0;
-            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
+            src.load(i < nvis ? i : i0, x[j], y[j], z[j]);
         }
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            if (i < n) {
+            const bool keep = i < nvis && (!Src::kFilter || !(x[j] != x[j]));
+            int idx = i;
+            if (Src::kFilter) {  // cloud index = kept points before this one (i >> 6 is the same for the whole wave)
+                const unsigned long long m = __ballot(keep);
+                idx = src.group_base((i < nvis ? i : i0) >> 6) + __popcll(m & ((1ull << lane) - 1ull));
+            }
+            if (keep) {
                 const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
-                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(i));  // one 16-byte store per point
+                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));  // one 16-byte store per point
             }
         }
     }
@@ -171,7 +199,9 @@ static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel
     const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
     const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP,
     int *__restrict__ cell_start, double *__restrict__ gparams) {
-    grid_build_scene(blockIdx.x, X, Y, Z, cap, sizes[blockIdx.x], bbox, GP, cell_start, gparams);
+    const int s = blockIdx.x, n = sizes[s];
+    const SoaSrc src{X + (size_t)s * cap, Y + (size_t)s * cap, Z + (size_t)s * cap};
+    grid_build_scene(s, src, cap, n, n, bbox, GP, cell_start, gparams);
 }
 
 // ------------------------------------------------------------------------------------------------

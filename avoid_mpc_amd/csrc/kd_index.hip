@@ -78,31 +78,22 @@ using amk::kWave;
 #endif
 constexpr int kCompactThreads = AMK_BUILD_THREADS;
 
-// returns (to every thread) the number of points kept
-__device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xyz, int point_stride, long long scene_stride,
-                                             const int *__restrict__ counts, int max_points, float *__restrict__ X,
-                                             float *__restrict__ Y, float *__restrict__ Z, int cap,
-                                             int *__restrict__ size_out, float *__restrict__ pmax_out,
-                                             float *__restrict__ bbox_out) {
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, w = tid >> 6;
-    const float *src = xyz + (long long)s * scene_stride;
-    float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
-    int n = counts ? counts[s] : max_points;
-    n = n < 0 ? 0 : (n > max_points ? max_points : n);
-
+// Pre-pass of the index build over the caller's cloud: how many points the NaN-x filter keeps (kd_tree_two.h:96-101),
+// the kept-point count before every 64-point group (-> grp, exclusive prefix), bounding box of the finite kept
+// points, max |coordinate| of the kept ones.  Returns the number kept (to every thread).
+__device__ __forceinline__ int prefilter_scene(int s, const float *__restrict__ src, int point_stride, int n,
+                                               int *__restrict__ grp, int *__restrict__ size_out,
+                                               float *__restrict__ pmax_out, float *__restrict__ bbox_out) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NW = kCompactThreads / kWave;
-    constexpr int UNR = 4;  // points per thread per round: 12 independent loads in flight, one barrier pair per 4096 points
-    __shared__ int wave_tot[UNR][NW];
+    constexpr int UNR = 4;
     __shared__ float wave_max[NW];
     __shared__ float wave_bb[6][NW];
+    __shared__ int wave_sum[NW];
     float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
     float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};  // bbox of the finite points
-    int base = 0;
     for (int c0 = 0; c0 < n; c0 += UNR * kCompactThreads) {
         float px[UNR], py[UNR], pz[UNR];
-        bool valid[UNR];
-        int prefix[UNR];
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             const int i = c0 + j * kCompactThreads + tid;
@@ -117,27 +108,11 @@ __device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xy
 #pragma unroll
         for (int j = 0; j < UNR; ++j) {
             const int i = c0 + j * kCompactThreads + tid;
-            valid[j] = i < n && !(px[j] != px[j]);  // only x is tested by the reference
-            const unsigned long long m = __ballot(valid[j]);
-            prefix[j] = __popcll(m & ((1ull << lane) - 1ull));
-            if (lane == 0) wave_tot[j][w] = __popcll(m);
-        }
-        __syncthreads();
-        int run = base;
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            int woff = 0, tot = 0;
-#pragma unroll
-            for (int ww = 0; ww < NW; ++ww) {
-                const int t = wave_tot[j][ww];
-                woff += (ww < w) ? t : 0;
-                tot += t;
-            }
-            if (valid[j]) {
-                const int o = run + woff + prefix[j];
-                xs[o] = px[j];
-                ys[o] = py[j];
-                zs[o] = pz[j];
+            const bool valid = i < n && !(px[j] != px[j]);  // only x is tested by the reference
+            const unsigned long long m = __ballot(valid);
+            const int g = (c0 + j * kCompactThreads) / kWave + w;
+            if (lane == 0 && g * kWave < n) grp[g] = __popcll(m);
+            if (valid) {
                 amax = fmaxf(amax, fmaxf(fabsf(px[j]), fmaxf(fabsf(py[j]), fabsf(pz[j]))));
                 if (amk::finite3(px[j], py[j], pz[j])) {
                     bmn[0] = fminf(bmn[0], px[j]); bmx[0] = fmaxf(bmx[0], px[j]);
@@ -145,16 +120,7 @@ __device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xy
                     bmn[2] = fminf(bmn[2], pz[j]); bmx[2] = fmaxf(bmx[2], pz[j]);
                 }
             }
-            run += tot;
         }
-        base = run;
-        __syncthreads();
-    }
-    const float qnan = __builtin_nanf("");
-    for (int i = base + tid; i < cap; i += kCompactThreads) {
-        xs[i] = qnan;
-        ys[i] = qnan;
-        zs[i] = qnan;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
@@ -170,11 +136,41 @@ __device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xy
 #pragma unroll
         for (int a = 0; a < 3; ++a) { wave_bb[a][w] = bmn[a]; wave_bb[3 + a][w] = bmx[a]; }
     }
+    __threadfence_block();
+    __syncthreads();  // the group counts are this block's own stores
+    // exclusive prefix of the group counts, in place
+    const int ng = (n + kWave - 1) / kWave;
+    const int per = (ng + kCompactThreads - 1) / kCompactThreads;
+    const int g0 = tid * per;
+    int loc = 0;
+    for (int j = 0; j < per; ++j)
+        if (g0 + j < ng) loc += grp[g0 + j];
+    int incl = loc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(incl, off);
+        if (lane >= off) incl += v;
+    }
+    if (lane == 63) wave_sum[w] = incl;
     __syncthreads();
+    int wbase = 0, total = 0;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int t = wave_sum[j];
+        wbase += j < w ? t : 0;
+        total += t;
+    }
+    int run = wbase + incl - loc;
+    for (int j = 0; j < per; ++j)
+        if (g0 + j < ng) {
+            const int c = grp[g0 + j];
+            grp[g0 + j] = run;
+            run += c;
+        }
     if (tid == 0) {
         float m = 0.f;
         for (int j = 0; j < NW; ++j) m = fmaxf(m, wave_max[j]);
-        size_out[s] = base;
+        size_out[s] = total;
         pmax_out[s] = m;
     }
     if (tid < 6) {
@@ -182,24 +178,59 @@ __device__ __forceinline__ int compact_scene(int s, const float *__restrict__ xy
         for (int j = 1; j < NW; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
         bbox_out[6 * s + tid] = v;
     }
-    return base;
+    __threadfence_block();
+    __syncthreads();  // group bases and the bounding box are read back by the index build below
+    return total;
 }
 
-// InitializeNew for scene s = blockIdx.x: compaction, then the bucketed index from the planes this block has just
-// written (one launch instead of two: under 16 steps in flight every launch of a stream queues behind the others)
+// InitializeNew for scene s = blockIdx.x in one launch: the pre-pass, then the bucketed index straight from the
+// caller's cloud (two more passes over it, L2/MALL-warm).  The index-ordered SoA planes are NOT written: whoever
+// needs them (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand
+// (ensure_soa).
 static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
 __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(
     const float *__restrict__ xyz, int point_stride, long long scene_stride, const int *__restrict__ counts,
-    int max_points, float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Z, int cap,
-    int *__restrict__ size_out, float *__restrict__ pmax_out, float *__restrict__ bbox_out, float4 *__restrict__ GP,
+    int max_points, int cap, int *__restrict__ grp_all, int grp_stride, int *__restrict__ size_out,
+    float *__restrict__ pmax_out, float *__restrict__ bbox_out, float4 *__restrict__ GP,
     int *__restrict__ cell_start, double *__restrict__ gparams) {
     const int s = blockIdx.x;
-    const int n = compact_scene(s, xyz, point_stride, scene_stride, counts, max_points, X, Y, Z, cap, size_out, pmax_out,
-                                bbox_out);
-    __threadfence_block();
-    __syncthreads();  // the planes and the bounding box are this block's own stores
-    amk::grid_build_scene(s, X, Y, Z, cap, n, bbox_out, GP, cell_start, gparams);
+    const float *src = xyz + (long long)s * scene_stride;
+    int n = counts ? counts[s] : max_points;
+    n = n < 0 ? 0 : (n > max_points ? max_points : n);
+    int *grp = grp_all + (size_t)s * grp_stride;
+    const int kept = prefilter_scene(s, src, point_stride, n, grp, size_out, pmax_out, bbox_out);
+    const amk::RawSrc rs{src, point_stride, grp};
+    amk::grid_build_scene(s, rs, cap, n, kept, bbox_out, GP, cell_start, gparams);
 }
+
+// index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
+__global__ __launch_bounds__(256) void kd_records_to_soa_kernel(const float4 *__restrict__ GP, const int *__restrict__ sizes,
+                                                                float *__restrict__ X, float *__restrict__ Y,
+                                                                float *__restrict__ Z, int cap) {
+    const int s = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= cap) return;
+    const size_t base = (size_t)s * cap;
+    if (i < sizes[s]) {
+        const float4 r = GP[base + i];
+        const int idx = __float_as_int(r.w);
+        X[base + idx] = r.x; Y[base + idx] = r.y; Z[base + idx] = r.z;
+    } else {
+        const float qnan = __builtin_nanf("");
+        X[base + i] = qnan; Y[base + i] = qnan; Z[base + i] = qnan;
+    }
+}
+
+// makes the SoA planes of `kd` valid on `stream` (no-op when they already are)
+static int ensure_soa(amk_kd *kd, hipStream_t stream) {
+    if (kd->soa_valid) return AMK_OK;
+    if (kd->cap > 0)
+        hipLaunchKernelGGL(kd_records_to_soa_kernel, dim3((kd->cap + 255) / 256, kd->n_scenes), dim3(256), 0, stream,
+                           kd->gpt.p, kd->size.p, kd->x.p, kd->y.p, kd->z.p, kd->cap);
+    AMK_HIP(hipGetLastError());
+    kd->soa_valid = 1;
+    return AMK_OK;
+}
+extern "C" int amk__kd_ensure_soa(amk_kd *kd, void *stream) { return kd ? ensure_soa(kd, (hipStream_t)stream) : AMK_ERR_INVALID_ARG; }
 
 // ------------------------------------------------------------------------------------------------
 // search: one wavefront per (scene, group of QPW queries); device scan in kd_device.h
@@ -430,6 +461,10 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
         AMK_HIP(keyframe->sweep_cnt.alloc((size_t)S * 2));
     }
     const amk::GridPtrs cur{current->gpt.p, current->cell_start.p, current->gparams.p, current->cap};
+    {   // the key frame's points are the queries and are compacted in place: they must exist in index order
+        const int st = ensure_soa(keyframe, stream);
+        if (st != AMK_OK) return st;
+    }
     if (keyframe->max_points > 0) {
         hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((keyframe->max_points + 255) / 256, S), dim3(256), 0, stream, cur,
                            current->size.p, keyframe->x.p, keyframe->y.p, keyframe->z.p, keyframe->cap, keyframe->size.p,
@@ -463,6 +498,11 @@ extern "C" int amk_kd_keyframe_sweep_host(amk_kd *keyframe, amk_kd *current, dou
 extern "C" int amk_kd_points_host(amk_kd *kd, float *h_xyz, int *h_sizes) {
     if (!kd || !h_xyz || !h_sizes) return AMK_ERR_INVALID_ARG;
     AMK_HIP(hipDeviceSynchronize());
+    {
+        const int st = ensure_soa(kd, nullptr);
+        if (st != AMK_OK) return st;
+        AMK_HIP(hipDeviceSynchronize());
+    }
     AMK_HIP(hipMemcpy(h_sizes, kd->size.p, sizeof(int) * kd->n_scenes, hipMemcpyDeviceToHost));
     std::vector<float> plane((size_t)kd->cap);
     for (int s = 0; s < kd->n_scenes; ++s) {
@@ -529,6 +569,7 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
         (e = kd->gpt.alloc(tot)) != hipSuccess || (e = kd->bbox.alloc((size_t)n_scenes * 6)) != hipSuccess ||
         (e = kd->cell_start.alloc((size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
         (e = kd->gparams.alloc((size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess ||
+        (e = kd->grp.alloc((size_t)n_scenes * (kd->cap / kWave + 2))) != hipSuccess ||
         (e = hipMemset(kd->cell_start.p, 0, sizeof(int) * (size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
         (e = hipMemset(kd->gparams.p, 0, sizeof(double) * (size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess) {
         delete kd;
@@ -550,8 +591,9 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
         hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
-                           point_stride, scene_stride, d_counts, kd->max_points, kd->x.p, kd->y.p, kd->z.p, kd->cap,
+                           point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p, kd->cap / kWave + 2,
                            kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p);
+        kd->soa_valid = 0;
     }
     AMK_HIP(hipGetLastError());
     return AMK_OK;
@@ -575,6 +617,10 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
                            kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts);
         AMK_HIP(hipGetLastError());
         return AMK_OK;
+    }
+    {   // the streaming scan reads the index-ordered planes
+        const int st = ensure_soa(kd, (hipStream_t)stream);
+        if (st != AMK_OK) return st;
     }
     int qpw, groups, wpb;
     amk::scan_geometry(n_queries, qpw, groups, wpb);

@@ -14,6 +14,8 @@
 
 using namespace amk;
 
+extern "C" int amk__kd_ensure_soa(amk_kd *kd, void *stream);  // kd_index.hip
+
 namespace {
 
 __global__ void step_begin_kernel(int S, int *__restrict__ done, int *__restrict__ flags, double *__restrict__ u) {
@@ -259,6 +261,11 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     const int bps = (groups + wpb - 1) / wpb;
     const int S8 = (S + 7) / 8 * 8;
     const int use_grid = (obstacle->mode == 0 && edge->mode == 0) ? 1 : 0;
+    if (!use_grid) {  // the streaming-scan cross-check path reads the index-ordered planes
+        int st = amk__kd_ensure_soa(obstacle, stream_);
+        if (st == AMK_OK) st = amk__kd_ensure_soa(edge, stream_);
+        if (st != AMK_OK) return st;
+    }
     const GridPtrs gobs{obstacle->gpt.p, obstacle->cell_start.p, obstacle->gparams.p, obstacle->cap};
     const GridPtrs gedge{edge->gpt.p, edge->cell_start.p, edge->gparams.p, edge->cap};
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
