@@ -238,7 +238,7 @@ def main():
         achieved = alg_launch / (solve_ms * 1e-3) / 1e9
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
         build_ms = ms[7] / max(cnt[7], 1)
-        build_alg = 64 * S * (n + ne) // 2       # mean of the obstacle and the edge launch
+        build_alg = 28 * S * (n + ne) // 2       # 12 B read + 16 B written per point; mean of the obstacle and the edge launch
         build_traffic = None
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
@@ -280,8 +280,9 @@ def main():
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(build_alg / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                   "traffic": build_traffic,
-                                  "note": "the HBM-heavy kernel: 64 B per point (12 read + 12 written as SoA planes, "
-                                          "12 re-read twice, 16 written as bucket records)"},
+                                  "note": "the HBM-heavy kernel: algorithmic 28 B per point (12 read, 16 written as a bucket "
+                                          "record); the kernel reads the cloud three times (two of them L2/MALL-warm) and "
+                                          "its scattered 16-byte stores leave L2 about twice"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},
