@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256) void kd_records_to_soa_kernel(const float4 *__
 // makes the SoA planes of `kd` valid on `stream` (no-op when they already are)
 static int ensure_soa(amk_kd *kd, hipStream_t stream) {
     if (kd->soa_valid) return AMK_OK;
+    if (!kd->x.p) {
+        const size_t tot = (size_t)kd->n_scenes * kd->cap;
+        AMK_HIP(kd->x.alloc(tot));
+        AMK_HIP(kd->y.alloc(tot));
+        AMK_HIP(kd->z.alloc(tot));
+    }
     if (kd->cap > 0)
         hipLaunchKernelGGL(kd_records_to_soa_kernel, dim3((kd->cap + 255) / 256, kd->n_scenes), dim3(256), 0, stream,
                            kd->gpt.p, kd->size.p, kd->x.p, kd->y.p, kd->z.p, kd->cap);
@@ -559,8 +565,8 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
     kd->cap = amk::round_up(max_points, 256) + 1024;  // NaN padding: full vector loads + 3-tile look-ahead
     const size_t tot = (size_t)n_scenes * kd->cap;
     hipError_t e;
-    if ((e = kd->x.alloc(tot)) != hipSuccess || (e = kd->y.alloc(tot)) != hipSuccess ||
-        (e = kd->z.alloc(tot)) != hipSuccess || (e = kd->size.alloc(n_scenes)) != hipSuccess ||
+    // the index-ordered planes x/y/z are allocated by ensure_soa, the first time something asks for them
+    if ((e = kd->size.alloc(n_scenes)) != hipSuccess ||
         (e = kd->pmax.alloc(n_scenes)) != hipSuccess || (e = hipMemset(kd->pmax.p, 0, sizeof(float) * n_scenes)) != hipSuccess) {
         delete kd;
         return amk::hip_fail(e);
