@@ -51,6 +51,9 @@ __device__ __forceinline__ int cell_of(double p, double bbmin, double inv_h, int
 struct SoaSrc {
     static constexpr bool kFilter = false;
     const float *xs, *ys, *zs;
+    int *grp = nullptr;
+    int *size_out = nullptr;
+    float *pmax_out = nullptr;
     __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const { x = xs[i]; y = ys[i]; z = zs[i]; }
     __device__ __forceinline__ int group_base(int) const { return 0; }
 };
@@ -58,7 +61,9 @@ struct RawSrc {
     static constexpr bool kFilter = true;
     const float *p;
     int stride;
-    const int *grp;  // kept points before 64-point group g
+    int *grp;        // kept points per 64-point group (histogram pass), then before group g (exclusive prefix)
+    int *size_out;   // [1] number of kept points
+    float *pmax_out; // [1] max |coordinate| of the kept points
     __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const {
         const float *q = p + (size_t)i * stride;
         x = q[0]; y = q[1]; z = q[2];
@@ -66,7 +71,10 @@ struct RawSrc {
     __device__ __forceinline__ int group_base(int g) const { return grp[g]; }
 };
 
-// the index of scene s; called by every thread of a kGridBuildThreads block.  nvis points are visited, n of them kept.
+// the index of scene s; called by every thread of a kGridBuildThreads block.  nvis points are visited; for a filtering
+// source the number kept (n) is found by the histogram pass, which also leaves the group table, size and pmax.
+// bbox need not contain every point (amk_kd_build passes the box of a strided sample): a point outside is clamped
+// into a boundary cell, which every rule of the search tolerates (boundary faces are never used as bounds).
 template <class Src>
 __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, int nvis, int n,
                                                  const float *__restrict__ bbox, float4 *__restrict__ GP,
@@ -78,6 +86,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
 
     __shared__ int hist[kGridMaxCells + 2];
     __shared__ int wsum[kGridBuildThreads / 64];
+    __shared__ float wmax[kGridBuildThreads / 64];
     __shared__ double geo[kGridParamDoubles];
 
     // 1. bounding box of the finite points: reduced by the compaction kernel (bbox[s][6] = min xyz, max xyz)
@@ -94,7 +103,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
         const double efloor = fmax(emax * 1e-6, 1e-30);
         double vol = 1.0;
         for (int a = 0; a < 3; ++a) vol *= fmax(ext[a], efloor);
-        double target = fmin(fmax((double)n / 8.0, 1.0), (double)kGridMaxCells);
+        double target = fmin(fmax((double)(Src::kFilter ? nvis : n) / 8.0, 1.0), (double)kGridMaxCells);
         double h = cbrt(vol / target);
         if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
         int g[3];
@@ -127,6 +136,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
                    ? (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0)
                    : ncell;
     };
+    float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
     for (int i0 = tid; i0 < nvis; i0 += kGridUnroll * kGridBuildThreads) {
         float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
 #pragma unroll
@@ -136,9 +146,57 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
         }
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
-            const bool keep = i0 + j * kGridBuildThreads < nvis && (!Src::kFilter || !(x[j] != x[j]));
+            const int i = i0 + j * kGridBuildThreads;
+            const bool keep = i < nvis && (!Src::kFilter || !(x[j] != x[j]));
+            if (Src::kFilter) {
+                const unsigned long long m = __ballot(keep);
+                if (lane == 0 && i < nvis) src.grp[i >> 6] = __popcll(m);  // lane 0 holds the wave's smallest i
+                if (keep) amax = fmaxf(amax, fmaxf(fabsf(x[j]), fmaxf(fabsf(y[j]), fabsf(z[j]))));
+            }
             if (keep) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
         }
+    }
+    if (Src::kFilter) {  // group bases (exclusive prefix, in place), number kept, max |coordinate|
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+        if (lane == 0) wmax[w] = amax;
+        __threadfence_block();
+        __syncthreads();  // the group counts are this block's own stores
+        const int ng = (nvis + 63) / 64;
+        const int per = (ng + kGridBuildThreads - 1) / kGridBuildThreads;
+        const int g0b = tid * per;
+        int loc = 0;
+        for (int j = 0; j < per; ++j)
+            if (g0b + j < ng) loc += src.grp[g0b + j];
+        int incl = loc;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v = __shfl_up(incl, off);
+            if (lane >= off) incl += v;
+        }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int wbase = 0, total = 0;
+        for (int j = 0; j < kGridBuildThreads / 64; ++j) {
+            const int t = wsum[j];
+            wbase += j < w ? t : 0;
+            total += t;
+        }
+        int run = wbase + incl - loc;
+        for (int j = 0; j < per; ++j)
+            if (g0b + j < ng) {
+                const int c = src.grp[g0b + j];
+                src.grp[g0b + j] = run;
+                run += c;
+            }
+        n = total;
+        if (tid == 0) {
+            float mx = 0.f;
+            for (int j = 0; j < kGridBuildThreads / 64; ++j) mx = fmaxf(mx, wmax[j]);
+            *src.size_out = total;
+            *src.pmax_out = mx;
+        }
+        __threadfence_block();
     }
     __syncthreads();
     // 4. exclusive scan of hist[0 .. ncell] -> bucket starts (global) and scatter cursors (LDS)

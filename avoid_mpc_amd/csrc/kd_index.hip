@@ -78,113 +78,47 @@ using amk::kWave;
 #endif
 constexpr int kCompactThreads = AMK_BUILD_THREADS;
 
-// Pre-pass of the index build over the caller's cloud: how many points the NaN-x filter keeps (kd_tree_two.h:96-101),
-// the kept-point count before every 64-point group (-> grp, exclusive prefix), bounding box of the finite kept
-// points, max |coordinate| of the kept ones.  Returns the number kept (to every thread).
-__device__ __forceinline__ int prefilter_scene(int s, const float *__restrict__ src, int point_stride, int n,
-                                               int *__restrict__ grp, int *__restrict__ size_out,
-                                               float *__restrict__ pmax_out, float *__restrict__ bbox_out) {
+// Pre-pass of the index build: bounding box of a strided SAMPLE of the caller's cloud (every 16th point of a large
+// cloud; finite points whose x is not NaN).  The grid geometry only needs a box that holds most points: a point
+// outside is clamped into a boundary cell (kd_grid.h), so 1/16 of the cloud is read here instead of all of it.
+__device__ __forceinline__ void sample_bbox_scene(int s, const float *__restrict__ src, int point_stride, int n,
+                                                  float *__restrict__ bbox_out) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NW = kCompactThreads / kWave;
-    constexpr int UNR = 4;
-    __shared__ float wave_max[NW];
     __shared__ float wave_bb[6][NW];
-    __shared__ int wave_sum[NW];
-    float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
-    float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};  // bbox of the finite points
-    for (int c0 = 0; c0 < n; c0 += UNR * kCompactThreads) {
-        float px[UNR], py[UNR], pz[UNR];
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            const int i = c0 + j * kCompactThreads + tid;
-            px[j] = py[j] = pz[j] = 0.f;
-            if (i < n) {
-                const float *p = src + (size_t)i * point_stride;
-                px[j] = p[0];
-                py[j] = p[1];
-                pz[j] = p[2];
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < UNR; ++j) {
-            const int i = c0 + j * kCompactThreads + tid;
-            const bool valid = i < n && !(px[j] != px[j]);  // only x is tested by the reference
-            const unsigned long long m = __ballot(valid);
-            const int g = (c0 + j * kCompactThreads) / kWave + w;
-            if (lane == 0 && g * kWave < n) grp[g] = __popcll(m);
-            if (valid) {
-                amax = fmaxf(amax, fmaxf(fabsf(px[j]), fmaxf(fabsf(py[j]), fabsf(pz[j]))));
-                if (amk::finite3(px[j], py[j], pz[j])) {
-                    bmn[0] = fminf(bmn[0], px[j]); bmx[0] = fmaxf(bmx[0], px[j]);
-                    bmn[1] = fminf(bmn[1], py[j]); bmx[1] = fmaxf(bmx[1], py[j]);
-                    bmn[2] = fminf(bmn[2], pz[j]); bmx[2] = fmaxf(bmx[2], pz[j]);
-                }
-            }
+    const int step = n >= 16384 ? 16 : 1;
+    float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (int t = tid; (long long)t * step < n; t += kCompactThreads) {
+        const float *p = src + (size_t)t * step * point_stride;
+        const float px = p[0], py = p[1], pz = p[2];
+        if (amk::finite3(px, py, pz)) {
+            bmn[0] = fminf(bmn[0], px); bmx[0] = fmaxf(bmx[0], px);
+            bmn[1] = fminf(bmn[1], py); bmx[1] = fmaxf(bmx[1], py);
+            bmn[2] = fminf(bmn[2], pz); bmx[2] = fmaxf(bmx[2], pz);
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-        amax = fmaxf(amax, __shfl_xor(amax, off));
+    for (int off = 32; off > 0; off >>= 1)
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             bmn[a] = fminf(bmn[a], __shfl_xor(bmn[a], off));
             bmx[a] = fmaxf(bmx[a], __shfl_xor(bmx[a], off));
         }
-    }
-    if (lane == 0) {
-        wave_max[w] = amax;
+    if (lane == 0)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { wave_bb[a][w] = bmn[a]; wave_bb[3 + a][w] = bmx[a]; }
-    }
-    __threadfence_block();
-    __syncthreads();  // the group counts are this block's own stores
-    // exclusive prefix of the group counts, in place
-    const int ng = (n + kWave - 1) / kWave;
-    const int per = (ng + kCompactThreads - 1) / kCompactThreads;
-    const int g0 = tid * per;
-    int loc = 0;
-    for (int j = 0; j < per; ++j)
-        if (g0 + j < ng) loc += grp[g0 + j];
-    int incl = loc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int v = __shfl_up(incl, off);
-        if (lane >= off) incl += v;
-    }
-    if (lane == 63) wave_sum[w] = incl;
     __syncthreads();
-    int wbase = 0, total = 0;
-#pragma unroll
-    for (int j = 0; j < NW; ++j) {
-        const int t = wave_sum[j];
-        wbase += j < w ? t : 0;
-        total += t;
-    }
-    int run = wbase + incl - loc;
-    for (int j = 0; j < per; ++j)
-        if (g0 + j < ng) {
-            const int c = grp[g0 + j];
-            grp[g0 + j] = run;
-            run += c;
-        }
-    if (tid == 0) {
-        float m = 0.f;
-        for (int j = 0; j < NW; ++j) m = fmaxf(m, wave_max[j]);
-        size_out[s] = total;
-        pmax_out[s] = m;
-    }
     if (tid < 6) {
         float v = wave_bb[tid][0];
         for (int j = 1; j < NW; ++j) v = tid < 3 ? fminf(v, wave_bb[tid][j]) : fmaxf(v, wave_bb[tid][j]);
         bbox_out[6 * s + tid] = v;
     }
     __threadfence_block();
-    __syncthreads();  // group bases and the bounding box are read back by the index build below
-    return total;
+    __syncthreads();  // read back by the index build below
 }
 
-// InitializeNew for scene s = blockIdx.x in one launch: the pre-pass, then the bucketed index straight from the
-// caller's cloud (two more passes over it, L2/MALL-warm).  The index-ordered SoA planes are NOT written: whoever
+// InitializeNew for scene s = blockIdx.x in one launch: the sampled bounding box, then the bucketed index straight
+// from the caller's cloud (two passes over it, the second L2/MALL-warm).  The index-ordered SoA planes are NOT written: whoever
 // needs them (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand
 // (ensure_soa).
 static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
@@ -198,9 +132,9 @@ __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(
     int n = counts ? counts[s] : max_points;
     n = n < 0 ? 0 : (n > max_points ? max_points : n);
     int *grp = grp_all + (size_t)s * grp_stride;
-    const int kept = prefilter_scene(s, src, point_stride, n, grp, size_out, pmax_out, bbox_out);
-    const amk::RawSrc rs{src, point_stride, grp};
-    amk::grid_build_scene(s, rs, cap, n, kept, bbox_out, GP, cell_start, gparams);
+    sample_bbox_scene(s, src, point_stride, n, bbox_out);
+    const amk::RawSrc rs{src, point_stride, grp, size_out + s, pmax_out + s};
+    amk::grid_build_scene(s, rs, cap, n, n, bbox_out, GP, cell_start, gparams);
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them

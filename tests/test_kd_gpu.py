@@ -181,3 +181,23 @@ def test_argument_errors(torch_cuda):
     q = torch_cuda.zeros((1, 1, 3), dtype=torch_cuda.float64, device="cuda")
     assert lib.amk_kd_search(h, C.c_void_p(q.data_ptr()), 1, 65, None, None, None, None, None) == 4
     assert lib.amk_kd_destroy(h) == 0
+
+
+def test_points_outside_the_sampled_box_and_nan_runs(torch_cuda, oracle):
+    """amk_kd_build takes its grid box from every 16th point of a large cloud: far outliers at unsampled positions are
+    clamped into boundary cells and must still be found (or correctly ignored); runs of NaN-x points shift the cloud
+    indices of everything behind them."""
+    rng = np.random.default_rng(21)
+    n = 40000
+    pts = rng.uniform([-5, -5, 0], [5, 5, 3], (n, 3)).astype(np.float32)
+    out = np.arange(n)[np.arange(n) % 16 != 0][::97][:300]          # never a sampled position
+    pts[out] = rng.uniform(-60, 60, (len(out), 3)).astype(np.float32)
+    q = np.concatenate([rng.uniform([-6, -6, -1], [6, 6, 4], (40, 3)), pts[out[:12]].astype(np.float64) + 0.25,
+                        rng.uniform(-70, 70, (12, 3))])                # (a NaN query is undefined in the reference too)
+    pts[1000:1200, 0] = np.nan                                        # three full 64-point groups and two ragged ones
+    pts[rng.choice(n, 500, replace=False), 0] = np.nan
+    res = _gpu_search(torch_cuda, [pts], q[None], 8)
+    tree = _oracle.kd_oracle(pts)
+    for j, qq in enumerate(q):
+        ri, rd, _ = tree.search(qq, 8)
+        assert np.array_equal(res["indices"][0, j], ri) and np.array_equal(res["sqdist"][0, j], rd), j
