@@ -217,7 +217,7 @@ def main():
     flags = out["flags"].cpu().numpy()
     solves = float(flags[:, 1].mean()); ipm_iters = float(flags[:, 3].mean())
     breakdown = None
-    if args.breakdown and rank == 0:
+    if args.breakdown and world == 1:   # (extra steps on one rank would unbalance the collectives)
         lib.amk__timing_enable(2)
         for _ in range(max(3, args.steps // 4)):
             one_step()
