@@ -6,8 +6,8 @@
 // Per outer iteration (<= mpc_max_iter):
 //   step_scan_kernel<2>  N K-NN queries at the reference points against the obstacle cloud     (:204-215)
 //   step_scan_kernel<1>  1-NN of reference point 0 against the edge cloud                      (:270)
-//   step_plan_kernel     PlanWapionts: nearest-obstacle test, snap to the edge point, re-query (:259-281)
-//   step_pack_kernel     ProcessWaypoints padding/needReplan, early exit, GetRefStates         (:216-257,333-335)
+//   step_plan_pack_kernel  PlanWapionts: nearest-obstacle test, snap to the edge point, re-query (:259-281), then
+//                          ProcessWaypoints padding/needReplan, early exit, GetRefStates      (:216-257,333-335)
 //   mpc_solve_kernel     Solve + refill of the reference path                                  (:337-342)
 #include "kd_grid.h"
 #include "mpc_handle.h"
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridP
     }
 }
 
-// PlanWapionts (:259-281) for reference point 0; one wavefront per scene.
-__global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_grid,
+// PlanWapionts (:259-281) for reference point 0; called by the one wavefront that owns scene s.
+__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid,
                                                           const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
@@ -130,9 +130,7 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_
                                                           float *__restrict__ knn_pts, double *__restrict__ knn_d2,
                                                           const float *__restrict__ edge_pt,
                                                           const double *__restrict__ edge_d2,
-                                                          const int *__restrict__ done, int *__restrict__ flags) {
-    const int s = blockIdx.x;
-    if (done[s]) return;
+                                                          int *__restrict__ flags) {
     const int lane = threadIdx.x;
     const int size_o = sizes_obs[s];
     // GetNearestDistance (FrameKDMap.cpp:400-427): SearchForNearest(p, 1) -> no result unless the cloud
@@ -189,8 +187,8 @@ __global__ __launch_bounds__(kWave) void step_plan_kernel(GridPtrs gpt, int use_
 }
 
 // ProcessWaypoints' padding and needReplan (:216-231), the early exit (:333-335) and GetRefStates
-// (:236-257).  One wavefront per scene.
-__global__ __launch_bounds__(kWave) void step_pack_kernel(const int *__restrict__ sizes_obs, int N, int K, int nref,
+// (:236-257); called by the one wavefront that owns scene s.
+__device__ __forceinline__ void pack_scene(int s, const int *__restrict__ sizes_obs, int N, int K, int nref,
                                                           int iter, int max_iter, double speed, double T,
                                                           double safety_distance,
                                                           const double *__restrict__ state_quad,
@@ -200,8 +198,6 @@ __global__ __launch_bounds__(kWave) void step_pack_kernel(const int *__restrict_
                                                           const double *__restrict__ knn_d2,
                                                           double *__restrict__ ref_states, int *__restrict__ done,
                                                           const int *__restrict__ flags) {
-    const int s = blockIdx.x;
-    if (done[s]) return;
     const int lane = threadIdx.x;
     // QueryNearest through either path returns K points iff the cloud holds more than K, else none
     // (FrameKDMap.cpp:298,339-345 + kd_tree_two.h:119-124)
@@ -233,6 +229,26 @@ __global__ __launch_bounds__(kWave) void step_pack_kernel(const int *__restrict_
         if (lane == 1) v = 0.;
         P[SD + SD * N + 3 * K * N + lane] = v;
     }
+}
+
+// PlanWapionts, then ProcessWaypoints' bookkeeping + GetRefStates, for scene s = blockIdx.x (one wavefront): the
+// second half reads what the first one wrote for this scene only (snapped point, its neighbours, isSafety).
+__global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
+    GridPtrs gpt, int use_grid, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+    int cap, const int *__restrict__ sizes_obs, const float *__restrict__ pmax_obs, const int *__restrict__ sizes_edge,
+    int N, int K, int nref, int iter, int max_iter, double speed, double T, double safety_distance,
+    const double *__restrict__ state_quad, const double *__restrict__ pos_x, double *__restrict__ ref_path,
+    float *__restrict__ knn_pts, double *__restrict__ knn_d2, const float *__restrict__ edge_pt,
+    const double *__restrict__ edge_d2, double *__restrict__ ref_states, int *__restrict__ done,
+    int *__restrict__ flags) {
+    const int s = blockIdx.x;
+    if (done[s]) return;
+    plan_scene(s, gpt, use_grid, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
+               knn_d2, edge_pt, edge_d2, flags);
+    __threadfence_block();
+    __syncthreads();
+    pack_scene(s, sizes_obs, N, K, nref, iter, max_iter, speed, T, safety_distance, state_quad, pos_x, ref_path, knn_pts,
+               knn_d2, ref_states, done, flags);
 }
 
 }  // namespace
@@ -285,15 +301,11 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         }
         { TimedLaunch tl(KC_PLAN, stream);
-        hipLaunchKernelGGL(step_plan_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, obstacle->x.p, obstacle->y.p,
-                           obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N, K,
-                           prm->safety_distance,
-                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p,
-                           d_flags); }
-        { TimedLaunch tl(KC_PACK, stream);
-        hipLaunchKernelGGL(step_pack_kernel, dim3(S), dim3(kWave), 0, stream, obstacle->size.p, N, K, mpc->nref, iter,
-                           prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
-                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags); }
+        hipLaunchKernelGGL(step_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, obstacle->x.p,
+                           obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
+                           K, mpc->nref, iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
+                           d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
+                           mpc->ref_states.p, mpc->done.p, d_flags); }
         AMK_HIP(hipGetLastError());
         int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
         if (st != AMK_OK) return st;
