@@ -107,7 +107,7 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--T", type=float, default=0.66)
     ap.add_argument("--K", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=20,
                     help="independent steps in flight (each on its own HIP stream with its own handles)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
@@ -117,7 +117,7 @@ def main():
 
     # one hardware queue per in-flight step (ROCm defaults to 4 and multiplexes streams onto them: two streams on one
     # queue serialise); measured on MI355X: 4 queues 280k, 8 -> 315k, 24 -> 390k steps/s at 16 streams
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import numpy as np
     import torch
     from avoid_mpc_amd import capi, synth
