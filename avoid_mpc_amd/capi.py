@@ -14,6 +14,7 @@ AMK_MAX_K = 64
 AMK_MAX_QUERIES = 64
 AMK_MAX_HORIZON = 32
 AMK_MAX_OUTER_ITER = 8
+AMK_MPC_DEFAULT_MAX_ITER = 40
 
 # every symbol include/avoid_mpc_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -25,7 +26,8 @@ SYMBOLS = [
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
-    "amk_mpc_solve_host", "amk_step_batch", "amk_step_batch_host",
+    "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
+    "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_step_batch", "amk_step_batch_host",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -102,6 +104,13 @@ def load():
         "amk_mpc_set_warm_start": (i, [vp, vp, vp]),
         "amk_mpc_reset_warm_start": (i, [vp, vp]),
         "amk_mpc_solve_host": (i, [vp, vp, vp, vp, vp, i]),
+        "amk_mpc_ng": (i, [vp]),
+        "amk_mpc_jac_nnz": (i, [vp]),
+        "amk_mpc_hess_nnz": (i, [vp]),
+        "amk_mpc_jac_sparsity": (i, [vp, vp, vp]),
+        "amk_mpc_hess_sparsity": (i, [vp, vp, vp]),
+        "amk_mpc_eval": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "amk_mpc_eval_host": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),

@@ -9,10 +9,12 @@
 //   collide_k = sum_j lam * softplus(-32(|o_kj - p_{k+1}| - r)) * |v_{k+1}.(o_kj - p_{k+1})/|.||
 //
 // Algorithm (the contract the CPU oracle restates; DESIGN.md "MPC solve"): feasible-start
-// primal-dual interior point on the controls; every Newton system is an LQR problem solved by a
-// backward Riccati sweep (stage blocks: 10x10 state, 4x4 control) + forward roll; inertia
-// correction by a uniform diagonal shift when a 4x4 block is not positive definite; Armijo
-// backtracking on the barrier function.  The stacked shooting Jacobian is block-banded with
+// primal-dual interior point on the controls, the non-smooth |v.n| of every collision term carried
+// as an l1 term (epigraph variable at its closed-form optimum, two multipliers per term, same
+// barrier parameter); every Newton system is an LQR problem solved by a backward Riccati sweep
+// (stage blocks: 10x10 state, 4x4 control) + forward roll; inertia correction by a uniform
+// diagonal shift when a 4x4 block is not positive definite; Armijo backtracking on the (smooth)
+// barrier function; monotone barrier update; stop when the last barrier problem is solved to tol.  The stacked shooting Jacobian is block-banded with
 // 19-nnz / 10-nnz constant blocks, so there is no dense GEMM here and MFMA does not apply; the
 // work is 64-lane fp64 VALU with LDS as the per-scene scratchpad.
 #pragma once
@@ -45,13 +47,16 @@ constexpr int PRM_B = 142;      // B[10][4]
 constexpr int PRM_C = 182;      // c[10]
 constexpr int PRM_LEN = 192;
 
-struct SolveOpts {
+struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the tests carries the same defaults
     double tol;       // ipopt.tol            HighLvlMpc.cpp:19
-    int max_iter;     // ipopt.max_iter       HighLvlMpc.cpp:20
+    int max_iter;     // iteration cap of THIS method (default 40); the reference's ipopt.max_iter = 10 counts IPOPT's
     int max_ls;       // 12
     double mu_init;   // 0.1  (IPOPT default)
     double bound_push, bound_frac;  // 1e-3 (IPOPT warm_start_bound_push / _frac)
-    double kappa_mu;  // 0.2
+    double kappa_mu;  // 0.2: mu <- max(mu_min, min(kappa_mu mu, mu^1.5))
+    double kappa_eps; // 100: barrier update when E_mu <= kappa_eps mu
+    double mu_min_fac;  // 1e-2: mu_min = mu_min_fac * tol
+    double maj;       // 1: weight of the majoriser curvature of |s| at mu_init (fades with mu / mu_init)
     double tau_min;   // 0.99
     double eta_phi;   // 1e-8
     double s_max;     // 100

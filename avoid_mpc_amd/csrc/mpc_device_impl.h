@@ -7,7 +7,6 @@ using namespace amk;
 typedef AMK_REAL real;
 #define RL(x) ((real)(x))
 constexpr real kGz = RL(9.81);   // mpc_obstacle_casadi.py:39
-constexpr real kAbsEps = RL(1e-3);
 
 // ---- cross-lane reductions on DPP (no LDS crossbar): quad_perm for lane^1 / lane^2, row_half_mirror and
 // row_mirror for the 8- and 16-lane levels (valid because every lane of the lower level already holds
@@ -78,13 +77,128 @@ __device__ __forceinline__ real seg_sum(real v, int seg) {
     return v;
 }
 
-// ---- one obstacle term: its cost is returned; when DERIV its gradient (6) and model Hessian (21 unique,
-// row-major lower triangle of the (p,v) 6x6 block) are ADDED to the stage's LDS cells with ds_add_f64 --
-// no per-lane accumulators (they were the register peak of the kernel) and no cross-lane reduction.
-// Lanes of one wave-instruction that hit the same cell are applied in lane order, so the sums are
-// reproducible.  Mirrors oracle collide_point statement by statement.
+// ---- collision terms.  c |s| is handled as an l1 term of an interior-point method:
+// epigraph variable t >= |s| kept at the optimum of its own barrier, t = mu + sqrt(mu^2 + s^2), slacks w1 = t - s,
+// w2 = t + s, multipliers yh1, yh2 (global memory, two doubles per term; yh1 < 0 = none yet), barrier form
+//   F = c (t - mu log(w1 w2)).
+// Mirrors oracle term_geo / slacks / term_mult / term_merit / term_derivs / term_step statement by statement.
+__device__ __forceinline__ void slacks(real s, real mu, real &w1, real &w2) {
+    const real as = fabs(s), r = sqrt(mu * mu + s * s);
+    const real ws = mu + mu * mu * fast_rcp(r + as), wb = mu + r + as;  // no cancellation in the small slack
+    w1 = s > RL(0.0) ? ws : wb;
+    w2 = s > RL(0.0) ? wb : ws;
+}
+__device__ __forceinline__ void term_mult(real y1, real y2, real mu, real kappa_sigma, real iw1, real iw2, real &a1,
+                                          real &a2) {
+    if (y1 < RL(0.0)) {  // dormant so far: central path
+        a1 = mu * iw1;
+        a2 = mu * iw2;
+    } else {             // within a factor kappa_sigma of the central path
+        const real ik = fast_rcp(kappa_sigma);
+        a1 = fmax(fmin(y1, kappa_sigma * mu * iw1), mu * iw1 * ik);
+        a2 = fmax(fmin(y2, kappa_sigma * mu * iw2), mu * iw2 * ik);
+    }
+}
+
+// MODE 0: merit value only.  MODE 1: also the condensed gradient (6) and Hessian (21 unique, row-major lower triangle
+// of the (p,v) 6x6 block) ADDED to the stage's LDS cells with ds_add_f64 (no per-lane accumulators, no cross-lane
+// reduction; lanes of one wave-instruction that hit the same cell are applied in lane order, so the sums are
+// reproducible), and the complementarity maxima cmax = max yh_i w_i, cdev = max |yh_i w_i - mu|.
+// MODE 2: Newton step of the term's multipliers for the state step (dp, dv), own fraction-to-the-boundary length;
+// y1/y2 are updated in place (a term that is dormant here forgets its multipliers).
+template <int MODE>
+__device__ __forceinline__ real collide_term(const real p[3], const real v[3], const real o[3], real lam, real radius,
+                                               real mu, real kappa_sigma, real maj, real tau, real &y1, real &y2,
+                                               const real *dp, const real *dv, real *gq, real *h21, real &cmax,
+                                               real &cdev) {
+    const real d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
+    const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+    const real x = -RL(32.0) * (rho - radius);
+    const real ex = exp(x);
+    const real g = log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
+    const real c = lam * g;
+    if (!(c > RL(0.0))) {              // dormant: c == 0 exactly, the term and all its derivatives vanish
+        if (MODE == 2) { y1 = -RL(1.0); y2 = -RL(1.0); }
+        return RL(0.0);
+    }
+    const real ir = fast_rcp(rho);
+    const real n[3] = {d0 * ir, d1 * ir, d2 * ir};
+    const real s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
+    real w1, w2;
+    slacks(s, mu, w1, w2);
+    const real t = RL(0.5) * (w1 + w2);
+    if (MODE == 0) return c * (t - mu * log(w1 * w2));
+    const real sg = ex * fast_rcp(RL(1.0) + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
+    const real gp = -RL(32.0) * sg;
+    const real tv[3] = {v[0] - s * n[0], v[1] - s * n[1], v[2] - s * n[2]};
+    const real iw1 = fast_rcp(w1), iw2 = fast_rcp(w2);
+    real a1, a2;
+    term_mult(y1, y2, mu, kappa_sigma, iw1, iw2, a1, a2);
+    const real D1 = a1 * iw1, D2 = a2 * iw2, Dh = D1 + D2, dD = D2 - D1, iDh = fast_rcp(Dh);
+    const real e = RL(1.0) - a1 - a2;
+    if (MODE == 2) {
+        const real ndp = n[0] * dp[0] + n[1] * dp[1] + n[2] * dp[2];
+        const real ds = -(tv[0] * dp[0] + tv[1] * dp[1] + tv[2] * dp[2]) * ir + (n[0] * dv[0] + n[1] * dv[1] + n[2] * dv[2]);
+        const real dlc = -(gp * fast_rcp(g)) * ndp;      // (grad c / c)' dz
+        const real dt = (-e * dlc - dD * ds) * iDh;      // the t row of the Newton system (its residual is 0)
+        const real dy1 = mu * iw1 - a1 - D1 * (dt - ds), dy2 = mu * iw2 - a2 - D2 * (dt + ds);
+        real al = RL(1.0);
+        if (dy1 < RL(0.0)) al = fmin(al, -tau * a1 * fast_rcp(dy1));
+        if (dy2 < RL(0.0)) al = fmin(al, -tau * a2 * fast_rcp(dy2));
+        y1 = a1 + al * dy1;
+        y2 = a2 + al * dy2;
+        return RL(0.0);
+    }
+    const real gpp = RL(1024.0) * sg * (RL(1.0) - sg);
+    const real sig = a1 - a2;
+    const real bs = mu * (iw1 - iw2);  // d/ds of the barrier form; its d/dt vanishes at the optimal t
+    const real Psi = t - mu * log(w1 * w2);
+    const real lgp = lam * gp;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        unsafeAtomicAdd(gq + i, -lgp * Psi * n[i] - c * bs * tv[i] * ir);  // state slots 0,1,2 = p
+        unsafeAtomicAdd(gq + 4 + i, c * bs * n[i]);                        // state slots 4,5,6 = v
+    }
+    // Hessian with t eliminated, in the three rank-structured blocks (n = unit vector to the obstacle, tv = v - s n):
+    //   H_pp = al tv tv' + A n n' + C (n tv' + tv n') + B I     H_vp = -be n tv' + D n n' + E I     H_vv = k2 n n'
+    const real k1 = sig - e * dD * iDh, k2 = RL(4.0) * c * D1 * D2 * iDh + maj * c * fast_rcp(t), k3 = e * e * iDh * fast_rcp(c);
+    const real ir2 = ir * ir, cs = c * sig;
+    const real al = k2 * ir2, be = k2 * ir;
+    const real B = Psi * lgp * ir - cs * s * ir2;
+    const real A = Psi * lam * gpp - B - k3 * lgp * lgp;
+    const real Cc = k1 * lgp * ir - cs * ir2;
+    const real D = -k1 * lgp + cs * ir, E = -cs * ir;
+    // lower triangle, row-major: (i,j), j <= i, index i(i+1)/2 + j
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            real h = al * tv[i] * tv[j] + A * n[i] * n[j] + Cc * (n[i] * tv[j] + tv[i] * n[j]);
+            if (i == j) h += B;
+            unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int i = 3 + a;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {  // H[v_a][p_j]
+            real h = n[a] * (D * n[j] - be * tv[j]);
+            if (a == j) h += E;
+            unsafeAtomicAdd(h21 + i * (i + 1) / 2 + j, h);
+        }
+#pragma unroll
+        for (int bb = 0; bb <= a; ++bb) unsafeAtomicAdd(h21 + i * (i + 1) / 2 + 3 + bb, k2 * n[a] * n[bb]);
+    }
+    cmax = fmax(cmax, fmax(a1 * w1, a2 * w2));
+    cdev = fmax(cdev, fmax(fabs(a1 * w1 - mu), fabs(a2 * w2 - mu)));
+    return c * Psi;
+}
+
+// ---- the plugin's own form of one obstacle term (amk_mpc_eval: nlp_f / nlp_grad_f / nlp_hess_l): value lam g |s|,
+// gradient and Hessian as CasADi differentiates it -- d|s|/ds = sign(s) (0 at s = 0), no curvature from the abs()
+// itself.  Same LDS accumulation as collide_term.  Mirrors oracle collide_point (majorise = 0).
 template <bool DERIV>
-__device__ __forceinline__ real collide_point(const real p[3], const real v[3], const real o[3], real lam,
+__device__ __forceinline__ real collide_exact(const real p[3], const real v[3], const real o[3], real lam,
                                                 real radius, real *gq, real *h21) {
     const real d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
     const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
@@ -112,7 +226,7 @@ __device__ __forceinline__ real collide_point(const real p[3], const real v[3], 
     // obstacle, t = v - s n, s = v.n, g/g'/g'' the softplus and its derivatives in rho):
     //   H_pp = al t t' + A n n' + C (n t' + t n') + B I     H_vp = -be n t' + D n n' + E I     H_vv = wk n n'
     // (the same sums as oracle collide_point's entry-by-entry expressions, common factors pulled out)
-    const real wk = lam * g * fast_rcp(as > kAbsEps ? as : kAbsEps);
+    const real wk = RL(0.0);
     const real ir2 = ir * ir, gir = g * ir, gpir = gp * ir;
     const real al = wk * ir2, be = wk * ir;
     const real A = ls * s * (gpp - gpir + g * ir2), B = ls * s * (gpir - g * ir2), Cc = ls * (gpir - g * ir2);
@@ -141,15 +255,18 @@ __device__ __forceinline__ real collide_point(const real p[3], const real v[3], 
     return cost;
 }
 
-// Evaluate the objective on (Xs, Us) held in LDS.  DERIV: also q, r, H6 (36 per stage, full
-// symmetric), rotQ.  Returns J (wave-uniform).  One wave; caller syncs before/after.
-template <bool DERIV>
-__device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, int Kpad, const real *Xs,
-                           const real *Us, long long *tclk = nullptr) {
+
+// Objective on (Xs, Us) held in LDS, in the solver's barrier form (EXACT = false) or as the plugin defines it (EXACT).  DERIV: also q, r, H6 (21 per stage), and acc[0] = max yh_i w_i,
+// acc[1] = max |yh_i w_i - mu| over the collision terms (wave-uniform).  Returns the value (wave-uniform).  Reads the
+// multipliers (ybuf, [N-1][K][2] doubles in global memory), writes none.  One wave; caller syncs before/after.
+template <bool DERIV, bool EXACT = false>
+__device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, const real *Xs,
+                           const real *Us, real mu, real kappa_sigma, real maj, const double *ybuf, real *acc,
+                           long long *tclk = nullptr) {
     const int lane = threadIdx.x;
     const real *prm = sm + L.prm;
     const real lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
-    real Jloc = RL(0.0);
+    real Jloc = RL(0.0), cmax = RL(0.0), cdev = RL(0.0);
     // ---- collision terms: lane = (stage, obstacle point), 64 terms per round
     if (DERIV) {  // the cells the terms add into
         for (int e = lane; e < (N - 1) * 21; e += 64) sm[L.H6 + e] = RL(0.0);
@@ -169,7 +286,17 @@ __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneI
             const real p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
             const double *op = io.obs + ((size_t)k * K + j) * 3;  // [k][j][3]
             const real o[3] = {(real)op[0], (real)op[1], (real)op[2]};
-            Jloc += collide_point<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
+            if (EXACT) {  // the plugin's form c |s| (amk_mpc_eval)
+                Jloc += collide_exact<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
+            } else {
+                real y1 = RL(0.0), y2 = RL(0.0);
+                if (DERIV) {
+                    const double2 yy = *reinterpret_cast<const double2 *>(ybuf + ((size_t)k * K + j) * 2);
+                    y1 = (real)yy.x; y2 = (real)yy.y;
+                }
+                Jloc += collide_term<DERIV ? 1 : 0>(p, v, o, lamw, radius, mu, kappa_sigma, maj, RL(0.0), y1, y2, nullptr,
+                                                    nullptr, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21, cmax, cdev);
+            }
         }
     }
     if (kTrace && tclk) tclk[0] += AMK_CLK() - tc0;
@@ -232,7 +359,70 @@ __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneI
         }
     }
     if (kTrace && tclk) tclk[2] += AMK_CLK() - tc3;
+    if (DERIV && !EXACT) {
+        acc[0] = wave_max(cmax);
+        acc[1] = wave_max(cdev);
+    }
     return wave_sum(Jloc);
+}
+
+// Newton step of the collision terms' multipliers for the state step dX (oracle term_step), same lane = (slot, stage) map.
+__device__ __forceinline__ void update_term_multipliers(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, real mu,
+                                                        real tau, real kappa_sigma, double *ybuf) {
+    const int lane = threadIdx.x;
+    const real *prm = sm + L.prm;
+    const real lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
+    const int ns = N - 1, per = 64 / ns;
+    const int jl = lane / ns, k = lane - jl * ns;
+    real dummy0 = RL(0.0), dummy1 = RL(0.0);
+    for (int j0 = 0; j0 < K; j0 += per) {
+        const int j = j0 + jl;
+        if (jl < per && j < K) {
+            const real *xk = sm + L.X + (k + 1) * SD, *dk = sm + L.dX + (k + 1) * SD;
+            const real p[3] = {xk[0], xk[1], xk[2]}, v[3] = {xk[4], xk[5], xk[6]};
+            const real dp[3] = {dk[0], dk[1], dk[2]}, dv[3] = {dk[4], dk[5], dk[6]};
+            const double *op = io.obs + ((size_t)k * K + j) * 3;
+            const real o[3] = {(real)op[0], (real)op[1], (real)op[2]};
+            double2 *yp = reinterpret_cast<double2 *>(ybuf + ((size_t)k * K + j) * 2);
+            const double2 yy = *yp;
+            real y1 = (real)yy.x, y2 = (real)yy.y;
+            collide_term<2>(p, v, o, lamw, radius, mu, kappa_sigma, RL(0.0), tau, y1, y2, dp, dv, nullptr, nullptr, dummy0, dummy1);
+            *yp = make_double2((double)y1, (double)y2);
+        }
+    }
+}
+
+// Reduced gradient gU_k = r_k + B' lam_{k+1} by the adjoint sweep lam_k = q_k + A' lam_{k+1}, lam_N = q_N (oracle
+// eval_iterate).  Lane i < 10 owns lam[i], lanes 10..13 own gU[a]; column i of A / a of B has <= 3 non-zero rows
+// (rows_of_A / rows_of_B), read from a double-buffered copy of lam_{k+1} in LDS: one barrier per stage.
+__device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N) {
+    const int lane = threadIdx.x;
+    const real *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
+    int rows[3] = {0, 0, 0};
+    real cf[3] = {RL(0.0), RL(0.0), RL(0.0)};
+    if (lane < SD) {
+        const int nr = rows_of_A(lane, rows);
+        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? A[rows[t] * SD + lane] : RL(0.0);
+    } else if (lane < SD + UD) {
+        const int nr = rows_of_B(lane - SD, rows);
+        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? B[rows[t] * UD + (lane - SD)] : RL(0.0);
+    }
+    real *buf0 = sm + L.lam, *buf1 = sm + L.Atl;
+    if (lane < SD) buf0[lane] = sm[L.q + N * SD + lane];
+    __syncthreads();
+#pragma unroll 1
+    for (int k = N - 1; k >= 0; --k) {
+        const real *src = ((N - 1 - k) & 1) ? buf1 : buf0;
+        real *dst = ((N - 1 - k) & 1) ? buf0 : buf1;
+        const real l0 = src[rows[0]], l1 = src[rows[1]], l2 = src[rows[2]];
+        const real acc3 = (cf[0] * l0 + cf[1] * l1) + cf[2] * l2;
+        if (lane < SD) {
+            if (k > 0) dst[lane] = sm[L.q + k * SD + lane] + acc3;
+        } else if (lane < SD + UD) {
+            sm[L.gU + k * UD + (lane - SD)] = sm[L.r + k * UD + (lane - SD)] + acc3;
+        }
+        __syncthreads();
+    }
 }
 
 struct LanePlan {                // the two items + the role of this lane, in registers for one backward sweep
@@ -401,16 +591,47 @@ __device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N
     }
 }
 
+// Box part of the barrier function and the optimality errors at the iterate (oracle eval_iterate, second half):
+// returns -mu sum log(sl su); err[0] = E_mu, err[1] = E_0 (IPOPT eq. (5) with c == 0; the collision terms enter through
+// acc = their complementarity maxima from evaluate<true>).
+__device__ __forceinline__ real box_errors(const real *sm, const LdsMap &L, int nvar, real mu, real s_max, const real *acc,
+                                           real *err) {
+    const int lane = threadIdx.x;
+    const real *prm = sm + L.prm;
+    real zs = RL(0.0), ed = RL(0.0), ec = RL(0.0), ecm = RL(0.0), lg = RL(0.0);
+    for (int e = lane; e < nvar; e += 64) {
+        const int i = e % UD;
+        const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e];
+        const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
+        zs += zl + zu;
+        ed = fmax(ed, fabs(sm[L.gU + e] - zl + zu));
+        ec = fmax(ec, fmax(sl * zl, su * zu));
+        ecm = fmax(ecm, fmax(fabs(sl * zl - mu), fabs(su * zu - mu)));
+        lg -= mu * log(sl * su);  // both slacks are positive and bounded by the box: no overflow
+    }
+    zs = wave_sum(zs); ed = wave_max(ed); ec = fmax(wave_max(ec), acc[0]); ecm = fmax(wave_max(ecm), acc[1]);
+    const real is_d = s_max * fast_rcp(fmax(s_max, zs / (RL(2.0) * nvar)));
+    err[0] = fmax(ed, ecm) * is_d;
+    err[1] = fmax(ed, ec) * is_d;
+    return wave_sum(lg);
+}
+
+__device__ __forceinline__ real next_mu(real mu, real mu_min, real kappa_mu) {
+    const real m = fmax(mu_min, fmin(kappa_mu * mu, mu * sqrt(mu)));  // IPOPT eq. (7), theta_mu = 1.5
+    return m < RL(10.0) * mu_min ? mu_min : m;                       // no short last level
+}
+
 // The whole solve for one scene.  w0/w_out: decision vector [X_0,U_0,...,U_{N-1},X_N] in global
-// memory (warm start in, solution out; may alias).  info[4] as in the C ABI.
+// memory (warm start in, solution out; may alias).  info[4] as in the C ABI.  ybuf: [N][K][2] doubles of scratch.
+// Statement by statement the algorithm of DESIGN.md section 5, as the CPU restatement of the tests (one difference in bookkeeping only: an accepted first
+// line-search trial is evaluated WITH derivatives, so the next iteration finds q, r, H6 of its iterate in LDS).
 __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
                             const double *x_init, const double *target, const SceneIO &io, const double *w0,
-                            double *w_out, int *info, const double *plan_coef, const int *plan_meta,
+                            double *w_out, int *info, const double *plan_coef, const int *plan_meta, double *ybuf,
                             double *trace = nullptr) {
     const int lane = threadIdx.x;
     const real o_tol = (real)opt.tol, o_mu_init = (real)opt.mu_init, o_bound_push = (real)opt.bound_push, o_bound_frac = (real)opt.bound_frac, o_kappa_mu = (real)opt.kappa_mu, o_tau_min = (real)opt.tau_min, o_eta_phi = (real)opt.eta_phi, o_s_max = (real)opt.s_max, o_kappa_sigma = (real)opt.kappa_sigma;
-    int Kpad = 1;
-    while (Kpad < K) Kpad <<= 1;
+    const real o_kappa_eps = (real)opt.kappa_eps, o_maj = (real)opt.maj;
     for (int e = lane; e < PRM_LEN; e += 64) sm[L.prm + e] = (real)prm_g[e];
     if (lane < SD) {
         sm[L.xinit + lane] = (real)x_init[lane];
@@ -434,20 +655,18 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             sm[L.rotQ + lane * 6 + b * 3 + 2] = sy * sy * w0q + cy * cy * w1q;
         }
     }
-    real mu = o_mu_init;
-    // warm start pushed into the interior; duals on the central path
-    for (int e = lane; e < N * UD; e += 64) {
+    const int nvar = UD * N;
+    // warm start pushed into the interior
+    for (int e = lane; e < nvar; e += 64) {
         const int k = e / UD, i = e % UD;
         const real lb = prm[PRM_LB + i], ub = prm[PRM_UB + i];
         const real pl = fmin(o_bound_push * fmax(RL(1.0), fabs(lb)), o_bound_frac * (ub - lb));
         const real pu = fmin(o_bound_push * fmax(RL(1.0), fabs(ub)), o_bound_frac * (ub - lb));
-        real u = (real)w0[14 * k + 10 + i];
-        u = fmin(fmax(u, lb + pl), ub - pu);
-        sm[L.U + e] = u;
-        sm[L.zl + e] = mu / (u - lb);
-        sm[L.zu + e] = mu / (ub - u);
+        sm[L.U + e] = fmin(fmax((real)w0[14 * k + 10 + i], lb + pl), ub - pu);
     }
     if (lane < SD) sm[L.X + lane] = sm[L.xinit + lane];
+    for (int e = lane; e < (N - 1) * K; e += 64)  // no collision term has multipliers yet
+        *reinterpret_cast<double2 *>(ybuf + (size_t)e * 2) = make_double2(-1.0, -1.0);
     __syncthreads();
     {  // rollout X_{k+1} = A X_k + B U_k + c
         const real *A = prm + PRM_A, *B = prm + PRM_B, *c = prm + PRM_C;
@@ -463,23 +682,51 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             __syncthreads();
         }
     }
-    const real mu_min = o_tol / RL(10.0);
-    real delta_last = RL(0.0), a_last = RL(0.0);
+    const real mu_min = o_tol * (real)opt.mu_min_fac;
+    real mu = o_mu_init, phi0 = RL(0.0);
+    real err[2] = {RL(0.0), RL(0.0)}, acc[2] = {RL(0.0), RL(0.0)};
+    // derivatives, reduced gradient and optimality errors of the iterate under mu (oracle eval_iterate)
+    auto eval_iterate = [&](bool derivs_in_lds, real J_known, long long *tclk) -> real {
+        const real J = derivs_in_lds ? J_known
+                                     : evaluate<true>(sm, L, io, N, K, sm + L.X, sm + L.U, mu, o_kappa_sigma,
+                                                      o_maj * mu / o_mu_init, ybuf, acc, tclk);
+        __syncthreads();
+        adjoint_sweep(sm, L, N);
+        return J + box_errors(sm, L, nvar, mu, o_s_max, acc, err);
+    };
+    // starting barrier parameter: the duals start on the central path of whatever mu is chosen, so mu_init is lowered
+    // level by level while the start already solves that level's barrier problem to the accuracy at which the barrier
+    // update below would leave it (a warm start from a previous solution begins several levels down)
+#pragma unroll 1
+    for (;;) {
+        for (int e = lane; e < nvar; e += 64) {
+            const int i = e % UD;
+            const real u = sm[L.U + e];
+            sm[L.zl + e] = mu / (u - prm[PRM_LB + i]);
+            sm[L.zu + e] = mu / (prm[PRM_UB + i] - u);
+        }
+        __syncthreads();
+        phi0 = eval_iterate(false, RL(0.0), nullptr);
+        if (!(err[0] <= o_kappa_eps * mu) || mu <= mu_min) break;
+        mu = next_mu(mu, mu_min, o_kappa_mu);
+    }
+    real delta_last = RL(0.0);
     int status = 1, n_reg = 0, ls_fail = 0, it = 0;
-    const int nvar = UD * N;
-    // The first line-search trial is evaluated with derivatives: when it is accepted (the common case) the next
-    // iteration finds q, r, H6 and J of its iterate already in LDS.  Same values as a fresh evaluation.
-    bool have_derivs = false;
-    real J_carried = RL(0.0);
 #pragma unroll 1
     for (it = 0; it < opt.max_iter; ++it) {
         const long long t0 = AMK_CLK();
         long long tclk[3] = {0, 0, 0};
-        const real J = have_derivs ? J_carried
-                                   : evaluate<true>(sm, L, io, N, K, Kpad, sm + L.X, sm + L.U, kTrace ? tclk : nullptr);
+        if (kTrace && trace && lane == 0) {
+            trace[16 * it + 0] = phi0; trace[16 * it + 1] = err[1]; trace[16 * it + 2] = mu; trace[16 * it + 3] = err[0];
+        }
+        if (mu <= mu_min && err[0] <= o_tol) { status = 0; break; }  // the last barrier problem is solved to tol
+        if (it > 0 && err[0] <= o_kappa_eps * mu && mu > mu_min) {   // barrier update (one level per iteration)
+            mu = next_mu(mu, mu_min, o_kappa_mu);
+            __syncthreads();
+            phi0 = eval_iterate(false, RL(0.0), kTrace ? tclk : nullptr);
+        }
         __syncthreads();
         const long long t1 = AMK_CLK();
-        if (it > 0 && a_last >= RL(0.5)) mu = fmax(mu_min, o_kappa_mu * mu);
         const real tau = fmax(o_tau_min, RL(1.0) - mu);
         for (int e = lane; e < nvar; e += 64) {
             const int i = e % UD;
@@ -502,32 +749,13 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
         }
         if (!ok) { status = 2; break; }
-        // KKT error E_0 at the current iterate (gU from the adjoint sweep inside the backward pass)
-        {
-            real zs = RL(0.0), ed = RL(0.0), ec = RL(0.0);
-            for (int e = lane; e < nvar; e += 64) {
-                const int i = e % UD;
-                const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e];
-                const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
-                zs += zl + zu;
-                ed = fmax(ed, fabs(sm[L.gU + e] - zl + zu));
-                ec = fmax(ec, fmax(fabs(sl * zl), fabs(su * zu)));
-            }
-            zs = wave_sum(zs); ed = wave_max(ed); ec = wave_max(ec);
-            const real s_d = fmax(o_s_max, zs / (RL(2.0) * nvar)) / o_s_max;
-            if (kTrace && trace && lane == 0) {
-                trace[16 * it + 0] = J; trace[16 * it + 1] = fmax(ed, ec) / s_d; trace[16 * it + 2] = mu;
-                trace[16 * it + 3] = delta;
-            }
-            if (fmax(ed, ec) / s_d <= o_tol) { status = 0; break; }
-        }
         n_reg += reg_now;
         if (delta > RL(0.0)) delta_last = delta;
         const long long t2 = AMK_CLK();
         riccati_forward(sm, L, N);
         const long long t3 = AMK_CLK();
-        // dual steps, fraction to the boundary, directional derivative, barrier value
-        real a_pr = RL(1.0), a_du = RL(1.0), dphi = RL(0.0), phi0 = RL(0.0);
+        // dual steps, fraction to the boundary, directional derivative: control box ...
+        real a_pr = RL(1.0), a_du = RL(1.0), dphi = RL(0.0);
         for (int e = lane; e < nvar; e += 64) {
             const int i = e % UD;
             const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e], du = sm[L.dU + e];
@@ -544,27 +772,27 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             if (dzl < RL(0.0)) a_du = fmin(a_du, -tau * zl * fast_rcp(dzl));
             if (dzu < RL(0.0)) a_du = fmin(a_du, -tau * zu * fast_rcp(dzu));
             dphi += (sm[L.gU + e] - mu * isl + mu * isu) * du;
-            phi0 -= mu * log(sl * su);  // both slacks are positive and bounded by the box: no overflow
         }
-        a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi); phi0 = J + wave_sum(phi0);
+        a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi);
+        // ... and the multipliers of the collision terms (they do not enter the merit function)
+        update_term_multipliers(sm, L, io, N, K, mu, tau, o_kappa_sigma, ybuf);
         // backtracking Armijo line search on the barrier function
         const long long t4 = AMK_CLK();
-        real a = a_pr;
-        bool accepted = false;
+        real a = a_pr, phi_t = RL(0.0), J_t = RL(0.0);
+        bool accepted = false, have_derivs = false;
         const bool speculate = it + 1 < opt.max_iter;  // the last iteration has no successor to hand derivatives to
-        have_derivs = false;
+        // a Newton step whose predicted decrease is below the rounding level of phi is taken as it is
+        const bool tiny = -dphi <= RL(100.0) * (AMK_REAL_F32 ? RL(1.1920929e-7) : RL(2.220446049250313e-16)) * (RL(1.0) + fabs(phi0));
         for (int ls = 0; ls < opt.max_ls; ++ls) {
             __syncthreads();
             for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
             for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
             __syncthreads();
-            real phi;
             if (ls == 0 && speculate) {
-                phi = evaluate<true>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
-                J_carried = phi;
+                J_t = evaluate<true>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, mu, o_kappa_sigma, o_maj * mu / o_mu_init, ybuf, acc);
                 have_derivs = true;
             } else {
-                phi = evaluate<false>(sm, L, io, N, K, Kpad, sm + L.Xt, sm + L.Ut);
+                J_t = evaluate<false>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, mu, o_kappa_sigma, RL(0.0), ybuf, nullptr);
                 have_derivs = false;  // the iterate moves on to a point that has no derivatives yet
             }
             real lg = RL(0.0);
@@ -573,23 +801,26 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
                 const real u = sm[L.Ut + e];
                 lg -= mu * log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
             }
-            phi += wave_sum(lg);
-            if (phi <= phi0 + o_eta_phi * a * dphi) { accepted = true; break; }
+            phi_t = J_t + wave_sum(lg);
+            if (tiny || phi_t <= phi0 + o_eta_phi * a * dphi) { accepted = true; break; }
             if (ls + 1 < opt.max_ls) a *= RL(0.5);
         }
-        if (!accepted) ++ls_fail;
-        a_last = accepted ? a : RL(0.0);
+        if (!accepted) {  // no decrease found (rounding level of phi): stay; the duals still move
+            ++ls_fail;
+            a = RL(0.0);
+            have_derivs = false;
+        }
         if (kTrace && trace && lane == 0) {
             trace[16 * it + 4] = a; trace[16 * it + 5] = a_pr; trace[16 * it + 6] = a_du; trace[16 * it + 7] = dphi;
             trace[16 * it + 8] = (double)(t1 - t0); trace[16 * it + 9] = (double)(t2 - t1);
             trace[16 * it + 10] = (double)(t3 - t2); trace[16 * it + 11] = (double)(t4 - t3);
-            trace[16 * it + 12] = (double)(AMK_CLK() - t4); trace[16 * it + 13] = (double)tclk[0]; trace[16 * it + 14] = (double)tclk[1]; trace[16 * it + 15] = (double)tclk[2];
+            trace[16 * it + 12] = (double)(AMK_CLK() - t4); trace[16 * it + 13] = (double)tclk[0]; trace[16 * it + 14] = delta; trace[16 * it + 15] = (double)tclk[2];
         }
         __syncthreads();
-        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] = sm[L.Xt + e];
+        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] += a * sm[L.dX + e];
         for (int e = lane; e < nvar; e += 64) {
             const int i = e % UD;
-            const real u = sm[L.Ut + e];
+            const real u = sm[L.U + e] + a * sm[L.dU + e];
             sm[L.U + e] = u;
             const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
             real zl = sm[L.zl + e] + a_du * sm[L.dzl + e], zu = sm[L.zu + e] + a_du * sm[L.dzu + e];
@@ -599,6 +830,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             sm[L.zu + e] = zu;
         }
         __syncthreads();
+        if (speculate) phi0 = eval_iterate(have_derivs, J_t, nullptr);
     }
     __syncthreads();
     for (int e = lane; e < (N + 1) * SD; e += 64) w_out[14 * (e / SD) + (e % SD)] = sm[L.X + e];

@@ -12,8 +12,11 @@ struct amk_mpc {
     int precision = 64;       // arithmetic of the solve: 64 (default) or 32 (amk_mpc_set_precision)
     amk::DevBuf<double> prm;  // [PRM_LEN]
     amk::DevBuf<double> w0;   // [S][nx]  mNlpW0
+    amk::DevBuf<double> ybuf; // [S][N][K][2]  multipliers of the collision terms (scratch of one solve)
     amk::DevBuf<double> plan_coef;  // item coefficients + lane-role constants of the Riccati plan (mpc_device.h)
     amk::DevBuf<int> plan_meta;     // [PLAN_ITEMS] PlanItemMeta + [64] LaneRole
+    // staging for amk_mpc_eval_host
+    amk::DevBuf<double> ev_w, ev_ref, ev_out;
     // staging for amk_mpc_solve_host
     amk::DevBuf<double> st_ref, st_u, st_x0;
     amk::DevBuf<int> st_info;

@@ -231,7 +231,7 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
                                                   double *__restrict__ x0array, int *__restrict__ info, double *trace,
                                                   const int *__restrict__ done, double *__restrict__ ref_path,
                                                   int *__restrict__ step_flags, const double *__restrict__ plan_coef,
-                                                  const int *__restrict__ plan_meta) {
+                                                  const int *__restrict__ plan_meta, double *__restrict__ ybuf) {
     using namespace amk32;  // solve_scene / sm_status / sm_iters overload on the scratchpad type
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     R *sm = reinterpret_cast<R *>(sm_raw);
@@ -246,7 +246,7 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     const double *target = P + SD + SD * N + 3 * K * N;
     double *w = w0 + (size_t)s * nx;
     solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, plan_coef, plan_meta,
-                s == 0 ? trace : nullptr);
+                ybuf + (size_t)s * N * (K > 0 ? K : 1) * 2, s == 0 ? trace : nullptr);
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
@@ -269,8 +269,8 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
         const double *__restrict__ ref_states, double *__restrict__ w0, double *__restrict__ u_out,                      \
         double *__restrict__ x0array, int *__restrict__ info, double *trace, const int *__restrict__ done,               \
         double *__restrict__ ref_path, int *__restrict__ step_flags, const double *__restrict__ plan_coef,               \
-        const int *__restrict__ plan_meta
-#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta
+        const int *__restrict__ plan_meta, double *__restrict__ ybuf
+#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta, ybuf
 
 template <int NT>
 __global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(AMK_SOLVE_ARGS) {
@@ -288,7 +288,7 @@ int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_
 #define AMK_LAUNCH_SOLVE(KERNEL, NT, LDS)                                                                            \
     hipLaunchKernelGGL(KERNEL<NT>, dim3(m->S), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
                        d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, d_step_flags,         \
-                       m->plan_coef.p, m->plan_meta.p)
+                       m->plan_coef.p, m->plan_meta.p, m->ybuf.p)
     if (m->precision == 32) {  // fp32 arithmetic, half the scratchpad
         const size_t lds = m->lds_bytes / 2;
         switch (m->N) {
@@ -360,8 +360,11 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     std::memcpy(m->h_prm + PRM_LB, lb, sizeof lb);
     std::memcpy(m->h_prm + PRM_UB, ub, sizeof ub);
     refresh_dynamics(m);
-    m->opt.tol = 1e-4; m->opt.max_iter = 10; m->opt.max_ls = 12; m->opt.mu_init = 0.1;
-    m->opt.bound_push = 1e-3; m->opt.bound_frac = 1e-3; m->opt.kappa_mu = 0.2; m->opt.tau_min = 0.99;
+    // solver options.  tol is ipopt.tol (HighLvlMpc.cpp:19); max_iter counts the
+    // iterations of this project's method, not IPOPT's 10 (HighLvlMpc.cpp:20)
+    m->opt.tol = 1e-4; m->opt.max_iter = AMK_MPC_DEFAULT_MAX_ITER; m->opt.max_ls = 12; m->opt.mu_init = 0.1;
+    m->opt.bound_push = 1e-3; m->opt.bound_frac = 1e-3; m->opt.kappa_mu = 0.2; m->opt.kappa_eps = 100.0;
+    m->opt.mu_min_fac = 1e-2; m->opt.maj = 1.0; m->opt.tau_min = 0.99;
     m->opt.eta_phi = 1e-8; m->opt.s_max = 100.0; m->opt.kappa_sigma = 1e10;
     m->lds_bytes = sizeof(double) * (size_t)LdsMap(N).total;
     if (m->lds_bytes < (size_t)AMK_SOLVE_LDS_MIN) m->lds_bytes = AMK_SOLVE_LDS_MIN;
@@ -369,6 +372,7 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess ||
         (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2)) != hipSuccess ||
         (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
+        (e = m->ybuf.alloc((size_t)n_scenes * N * (m->K > 0 ? m->K : 1) * 2)) != hipSuccess ||
         (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = hipFuncSetAttribute(N == 10   ? (const void *)mpc_solve_kernel<10>
                                  : N == 20 ? (const void *)mpc_solve_kernel<20>

@@ -141,7 +141,7 @@ class MpcBatch:
         capi.check(self.lib.amk_mpc_set_drone_accel_limits(self.h, float(aMinZ), float(aMaxZ), float(aMaxXy),
                                                            float(aMaxYawDot)), "SetDroneAccelLimits")
 
-    def set_solver_options(self, tol=1e-4, max_iter=10):
+    def set_solver_options(self, tol=1e-4, max_iter=capi.AMK_MPC_DEFAULT_MAX_ITER):
         capi.check(self.lib.amk_mpc_set_solver_options(self.h, float(tol), int(max_iter)), "set_solver_options")
 
     def set_precision(self, bits):
@@ -164,6 +164,27 @@ class MpcBatch:
                                           capi.dptr(info), int(bool(faster)), capi.stream_ptr(stream)),
                    "amk_mpc_solve")
         return u, x0, info
+
+    def eval(self, w, ref_states, lam_f=None, stream=None, want=("f", "grad_f", "g", "jac_g", "hess_l")):
+        """amk_mpc_eval: the plugin's nlp_f / nlp_grad_f / nlp_g / nlp_jac_g / nlp_hess_l at w [S, nx] -> dict of tensors."""
+        assert w.dtype == torch.float64 and tuple(w.shape) == (self.S, self.nx)
+        assert ref_states.dtype == torch.float64 and tuple(ref_states.shape) == (self.S, self.ref_len)
+        dev = w.device
+        shp = dict(f=(self.S,), grad_f=(self.S, self.nx), g=(self.S, self.lib.amk_mpc_ng(self.h)),
+                   jac_g=(self.S, self.lib.amk_mpc_jac_nnz(self.h)), hess_l=(self.S, self.lib.amk_mpc_hess_nnz(self.h)))
+        out = {k: torch.empty(shp[k], dtype=torch.float64, device=dev) for k in want}
+        capi.check(self.lib.amk_mpc_eval(self.h, capi.dptr(w), capi.dptr(ref_states), capi.dptr(lam_f),
+                                         *[capi.dptr(out.get(k)) for k in ("f", "grad_f", "g", "jac_g", "hess_l")],
+                                         capi.stream_ptr(stream)), "amk_mpc_eval")
+        return out
+
+    def sparsity(self, which):
+        """CCS pattern ('jac_g' or 'hess_l') -> (colind int32 [nx + 1], row int32 [nnz])."""
+        nnz = (self.lib.amk_mpc_jac_nnz if which == "jac_g" else self.lib.amk_mpc_hess_nnz)(self.h)
+        colind = np.zeros(self.nx + 1, np.int32); row = np.zeros(nnz, np.int32)
+        fn = self.lib.amk_mpc_jac_sparsity if which == "jac_g" else self.lib.amk_mpc_hess_sparsity
+        capi.check(fn(self.h, colind.ctypes.data_as(C.c_void_p), row.ctypes.data_as(C.c_void_p)), which + " sparsity")
+        return colind, row
 
     def get_warm_start(self, stream=None):
         w = torch.empty((self.S, self.nx), dtype=torch.float64, device=_dev())

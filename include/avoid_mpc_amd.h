@@ -39,6 +39,7 @@ typedef enum amk_status {
 #define AMK_MAX_HORIZON 32  /* N = int(T/dt); reference default 30                               */
 #define AMK_S_DIM 10        /* [px,py,pz,yaw,vx,vy,vz,ax,ay,az]  mpc_obstacle_casadi.py:41-46    */
 #define AMK_U_DIM 4         /* [ax_cmd,ay_cmd,az_cmd,yaw_dot]    mpc_obstacle_casadi.py:75       */
+#define AMK_MPC_DEFAULT_MAX_ITER 40 /* iteration cap of this library's interior-point method (see amk_mpc_create) */
 
 int amk_version(void);
 const char *amk_status_string(int status);
@@ -111,8 +112,10 @@ typedef struct amk_mpc amk_mpc;
  * N = int(T/dt) and K = nearest_point_num into the generated plugin behind soPath
  * (mpc_obstacle_casadi.py:36-37,76-85); here they are constructor arguments.  Defaults after
  * create are the constructor's: weights/tau/gains of HighLvlMpc.cpp:53-56, control bounds
- * [-10,-10,1,-10]..[10,10,20,10] (:13-16,29-30), zero warm start (:26-27,35), tol 1e-4,
- * max_iter 10 (:19-20).                                                                          */
+ * [-10,-10,1,-10]..[10,10,20,10] (:13-16,29-30), zero warm start (:26-27,35), tol 1e-4 (:19).
+ * The iteration cap defaults to AMK_MPC_DEFAULT_MAX_ITER, not to the reference's ipopt.max_iter = 10 (:20): that
+ * number counts IPOPT's iterations, which this library does not reproduce; the default is
+ * what brings >= 90 % of cold starts within 1e-3 of the converged optimum (tests/test_mpc_parity_gpu.py).      */
 int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out);
 int amk_mpc_destroy(amk_mpc *mpc);
 int amk_mpc_horizon(const amk_mpc *mpc);   /* N                                                  */
@@ -125,7 +128,7 @@ int amk_mpc_setup_gains(amk_mpc *mpc, const double *h_gains4);      /* SetupGain
 int amk_mpc_set_drone_radius(amk_mpc *mpc, double radius);          /* SetDroneRadius .cpp:64-66 */
 int amk_mpc_set_drone_accel_limits(amk_mpc *mpc, double aMinZ, double aMaxZ, double aMaxXy,
                                    double aMaxYawDot);              /* .cpp:70-92                */
-/* ipopt.tol / ipopt.max_iter of HighLvlMpc.cpp:19-20                                            */
+/* ipopt.tol of HighLvlMpc.cpp:19 and the iteration cap of this library's method (see amk_mpc_create) */
 int amk_mpc_set_solver_options(amk_mpc *mpc, double tol, int max_iter);
 /* Arithmetic of the NLP evaluation and the interior-point method: 64 (default; the reference's CasADi/IPOPT
  * path is fp64 throughout) or 32 (BASELINE.json configs[4], "fp32 tolerance check vs CPU trajectory").  The
@@ -139,7 +142,7 @@ int amk_mpc_set_precision(amk_mpc *mpc, int bits);
  *                                    radius are appended internally as in .cpp:97-107
  *   d_u          [S][4]           = sol[10..13]                         (.cpp:124-128)
  *   d_x0array    [S][N][14]       = rows [X_k, U_k], k < N              (.cpp:130-136) (may be NULL)
- *   d_info       [S][4] int       = {status (0 converged, 1 iteration cap), iterations,
+ *   d_info       [S][4] int       = {status (0 converged, 1 iteration cap, 2 regularisation overflow), iterations,
  *                                    regularisations, line-search failures}   (may be NULL)
  * The full primal solution is kept as the next call's warm start (.cpp:110,129).  The reference
  * never inspects the solver status (.cpp:116-122); neither does this function -- it reports it.  */
@@ -153,6 +156,29 @@ int amk_mpc_reset_warm_start(amk_mpc *mpc, void *stream); /* back to the constru
 
 int amk_mpc_solve_host(amk_mpc *mpc, const double *h_ref_states, double *h_u, double *h_x0array,
                        int *h_info, int faster);
+
+/* The NLP functions of the generated solver plugin (mpc_obstacle_casadi.py:290-300; loaded at HighLvlMpc.cpp:50,52),
+ * SURVEY.md section 8 rows a14-a18, evaluated for every scene at caller-supplied points:
+ *   nlp_f      f(x, p)                  objective                     mpc_obstacle_casadi.py:153-214
+ *   nlp_g      g(x, p)                  [X_0 - x_init ; F(X_k,U_k) - X_{k+1}]           :156-160,219,338-357
+ *   nlp_grad_f grad_x f                 (d|s|/ds = sign(s), as CasADi differentiates fabs)
+ *   nlp_jac_g  dg/dx, CCS values        constant: the dynamics are affine (drag off, mpc_parameters.yaml:4)
+ *   nlp_hess_l lam_f * triu(hess_x f)   CCS values; the constraints are linear, lam_g contributes nothing
+ *   d_w          [S][nx]    x = [X_0, U_0, X_1, ..., U_{N-1}, X_N]                        :158,164,217,224
+ *   d_ref_states [S][nref]  P[0 : 20+10N+3KN]; gains, taus, weights, radius come from the handle (HighLvlMpc.cpp:97-107)
+ *   d_lam_f      [S] or NULL (= 1)
+ *   d_f [S], d_grad_f [S][nx], d_g [S][ng], d_jac_g [S][jac_nnz], d_hess_l [S][hess_nnz]: each may be NULL.
+ * ng = 10 + 10 N; jac_nnz = 10 + 39 N; hess_nnz = 25 (N - 1) + 10 + 4 N.  The CCS patterns
+ * (column pointers colind[nx + 1], row indices, rows ascending inside a column) come from the *_sparsity calls.      */
+int amk_mpc_ng(const amk_mpc *mpc);
+int amk_mpc_jac_nnz(const amk_mpc *mpc);
+int amk_mpc_hess_nnz(const amk_mpc *mpc);
+int amk_mpc_jac_sparsity(const amk_mpc *mpc, int *h_colind, int *h_row);
+int amk_mpc_hess_sparsity(const amk_mpc *mpc, int *h_colind, int *h_row);
+int amk_mpc_eval(amk_mpc *mpc, const double *d_w, const double *d_ref_states, const double *d_lam_f, double *d_f,
+                 double *d_grad_f, double *d_g, double *d_jac_g, double *d_hess_l, void *stream);
+int amk_mpc_eval_host(amk_mpc *mpc, const double *h_w, const double *h_ref_states, const double *h_lam_f, double *h_f,
+                      double *h_grad_f, double *h_g, double *h_jac_g, double *h_hess_l);
 
 /* ------------------------------------------------------------------------------------------ */
 /* One control step: TASK branch of AvoidanceStateMachine::Step       AvoidanceStateMachine.cpp */

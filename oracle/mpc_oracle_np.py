@@ -1,4 +1,4 @@
-"""NumPy restatement of the Avoid-MPC NLP and of the solver contract.  TEST INFRASTRUCTURE ONLY.
+"""NumPy restatement of the Avoid-MPC NLP (values, derivatives, constraint Jacobian).  TEST INFRASTRUCTURE ONLY.
 
 This file is part of the oracle: only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import it.  The product path (HIP kernels behind include/avoid_mpc_amd.h)
@@ -290,23 +290,9 @@ def nlp_jac_g(w, P, N, K, dt):
 
 
 # ----------------------------------------------------------------------------------------------
-# solver: feasible-start primal-dual interior point with a Riccati (stage-wise) Newton solve.
-#
-# The reference hands the NLP to IPOPT (HighLvlMpc.cpp:17-23: tol 1e-4, max_iter 10, primal warm
-# start).  The only solver-independent contract is the KKT point; this solver is the algorithm the
-# HIP kernel implements line by line (avoid_mpc_amd/csrc/mpc_solve.hip) so that GPU-vs-oracle
-# parity is tight.  Because F is affine, the shooting defects are eliminated exactly
-# (X = rollout(U)); the remaining problem is box-constrained in U and each Newton system is an LQR
-# problem solved by a backward/forward Riccati sweep.
+# condensed form (the shooting defects eliminated: X = rollout(U)), used by the fixture generators to hand the
+# problem to scipy.optimize as an independent optimiser
 # ----------------------------------------------------------------------------------------------
-class IpmOptions:
-    def __init__(self, tol=1e-4, max_iter=10, mu_init=0.1, bound_push=1e-3, bound_frac=1e-3,
-                 kappa_mu=0.2, tau_min=0.99, eta_phi=1e-8,
-                 max_ls=12, s_max=100.0, kappa_sigma=1e10):
-        self.__dict__.update(locals())
-        del self.__dict__["self"]
-
-
 def rollout(x0, U, A, B, c):
     N = U.shape[0]
     X = np.zeros((N + 1, S_DIM))
@@ -325,145 +311,3 @@ def total_cost(X, U, pp, N, derivs):
         J += ck
         q[k + 1], Q[k + 1], r[k], Rd[k] = qk, Qk, rk, Rdk
     return J, q, Q, r, Rd
-
-
-def riccati(A, B, q, Q, r, Rdiag, delta):
-    """Solve  min 1/2 dU'(R)dU + r'dU + 1/2 dX'Q dX + q'dX,  dX_0=0, dX_{k+1}=A dX_k+B dU_k.
-    Returns (ok, dU, dX, pvec) -- ok False when some Quu_k is not positive definite."""
-    N = r.shape[0]
-    P = Q[N] + delta * np.eye(S_DIM)
-    p = q[N].copy()
-    Ks = np.zeros((N, U_DIM, S_DIM)); ds = np.zeros((N, U_DIM))
-    for k in range(N - 1, -1, -1):
-        PB = P @ B
-        Quu = np.diag(Rdiag[k] + delta) + B.T @ PB
-        Qux = PB.T @ A
-        qu = r[k] + B.T @ p
-        # Quu = L D L^T; not positive definite <=> some D_j <= 0
-        L = np.eye(U_DIM); D = np.zeros(U_DIM)
-        for j in range(U_DIM):
-            dj = Quu[j, j] - np.sum(L[j, :j] ** 2 * D[:j])
-            if not dj > 0.0:
-                return False, None, None
-            D[j] = dj
-            for i in range(j + 1, U_DIM):
-                L[i, j] = (Quu[i, j] - np.sum(L[i, :j] * L[j, :j] * D[:j])) / dj
-        Y = np.linalg.solve(L, Qux); yv = np.linalg.solve(L, qu)
-        Kk = -np.linalg.solve(L.T, Y / D[:, None])
-        dk = -np.linalg.solve(L.T, yv / D)
-        Ks[k], ds[k] = Kk, dk
-        if k > 0:
-            Pn = Q[k] + delta * np.eye(S_DIM) + A.T @ P @ A - Y.T @ (Y / D[:, None])
-            pn = q[k] + A.T @ p - Y.T @ (yv / D)
-            P = 0.5 * (Pn + Pn.T)
-            p = pn
-    dU = np.zeros((N, U_DIM)); dX = np.zeros((N + 1, S_DIM))
-    for k in range(N):
-        dU[k] = Ks[k] @ dX[k] + ds[k]
-        dX[k + 1] = A @ dX[k] + B @ dU[k]
-    return True, dU, dX
-
-
-def ipm_solve(P, w0, lbu, ubu, N, K, dt, opt=None, trace=None):
-    """Returns (w, info).  w0 is the primal warm start in the reference's layout (only its U part
-    matters: X is the rollout of U from x_init).  lbu/ubu: (4,) control bounds
-    (HighLvlMpc.cpp:70-92)."""
-    opt = opt or IpmOptions()
-    pp = split_p(P, N, K)
-    A, B, c = affine_dynamics(pp["tau"], dt)
-    _, U = unpack_w(w0, N)
-    lb = np.tile(np.asarray(lbu, float), (N, 1)); ub = np.tile(np.asarray(ubu, float), (N, 1))
-    # push the warm start into the interior (IPOPT warm_start_bound_push/frac = 1e-3)
-    pl = np.minimum(opt.bound_push * np.maximum(1.0, np.abs(lb)), opt.bound_frac * (ub - lb))
-    pu = np.minimum(opt.bound_push * np.maximum(1.0, np.abs(ub)), opt.bound_frac * (ub - lb))
-    U = np.minimum(np.maximum(U, lb + pl), ub - pu)
-    mu = opt.mu_init
-    zl = mu / (U - lb); zu = mu / (ub - U)
-    delta_last = 0.0
-    a_last = 0.0
-    X = rollout(pp["x_init"], U, A, B, c)
-    info = dict(iters=0, status=1, mu=mu, err=np.inf, n_reg=0, ls_fail=0)
-    nvar = U.size
-
-    def barrier(Uc, Jc, mu_):
-        return Jc - mu_ * np.sum(np.log(Uc - lb)) - mu_ * np.sum(np.log(ub - Uc))
-
-    for it in range(opt.max_iter):
-        J, q, Q, r, Rd = total_cost(X, U, pp, N, True)
-        # reduced gradient by the adjoint sweep
-        lam = q[N].copy()
-        gU = np.zeros_like(U)
-        for k in range(N - 1, -1, -1):
-            gU[k] = r[k] + B.T @ lam
-            if k > 0:
-                lam = q[k] + A.T @ lam
-        sl = U - lb; su = ub - U
-
-        def kkt_err(mu_):
-            s_d = max(opt.s_max, (np.sum(zl) + np.sum(zu)) / (2 * nvar)) / opt.s_max
-            e_d = np.max(np.abs(gU - zl + zu)) / s_d
-            e_c = max(np.max(np.abs(sl * zl - mu_)), np.max(np.abs(su * zu - mu_))) / s_d
-            return max(e_d, e_c)
-
-        err0 = kkt_err(0.0)
-        info.update(iters=it, err=err0, mu=mu, cost=J)
-        if trace is not None:
-            trace.append(dict(it=it, J=J, err=err0, mu=mu))
-        if err0 <= opt.tol:
-            info["status"] = 0
-            break
-        # barrier update: shrink after every iteration that took at least half a step
-        if it > 0 and a_last >= 0.5:
-            mu = max(opt.tol / 10.0, opt.kappa_mu * mu)
-        tau = max(opt.tau_min, 1.0 - mu)
-        Sig = zl / sl + zu / su
-        # Newton rhs in stage form: r_k - mu/sl + mu/su  (q unchanged)
-        rb = r - mu / sl + mu / su
-        delta = 0.0
-        ok, dU, dX = riccati(A, B, q, Q, rb, Rd + Sig, delta)
-        while not ok:
-            if delta == 0.0:
-                delta = 1e-4 if delta_last == 0.0 else max(1e-20, delta_last / 3.0)
-            else:
-                delta = delta * (100.0 if delta_last == 0.0 else 8.0)
-            info["n_reg"] += 1
-            if delta > 1e20:
-                raise RuntimeError("regularisation blew up")
-            ok, dU, dX = riccati(A, B, q, Q, rb, Rd + Sig, delta)
-        if delta > 0.0:
-            delta_last = delta
-        dzl = mu / sl - zl - (zl / sl) * dU
-        dzu = mu / su - zu + (zu / su) * dU
-        # fraction to the boundary
-        def max_step(v, dv):
-            m = dv < 0
-            return min(1.0, np.min(-tau * v[m] / dv[m])) if np.any(m) else 1.0
-        a_pr = min(max_step(sl, dU), max_step(su, -dU))
-        a_du = min(max_step(zl, dzl), max_step(zu, dzu))
-        # backtracking Armijo on the barrier function (always feasible => no filter needed)
-        phi0 = barrier(U, J, mu)
-        dphi = np.sum((gU - mu / sl + mu / su) * dU)
-        a = a_pr
-        accepted = False
-        for _ in range(opt.max_ls):
-            Ut = U + a * dU
-            Xt = X + a * dX          # affine dynamics: X(U + a dU) = X + a dX exactly
-            Jt = total_cost(Xt, Ut, pp, N, False)[0]
-            if barrier(Ut, Jt, mu) <= phi0 + opt.eta_phi * a * dphi:
-                accepted = True
-                break
-            if _ + 1 < opt.max_ls:
-                a *= 0.5
-        if not accepted:
-            info["ls_fail"] += 1
-        a_last = a if accepted else 0.0
-        U, X = Ut, Xt
-        zl = zl + a_du * dzl; zu = zu + a_du * dzu
-        # keep duals in the IPOPT safeguard box (eq. (16))
-        sl = U - lb; su = ub - U
-        zl = np.maximum(np.minimum(zl, opt.kappa_sigma * mu / sl), mu / (opt.kappa_sigma * sl))
-        zu = np.maximum(np.minimum(zu, opt.kappa_sigma * mu / su), mu / (opt.kappa_sigma * su))
-    else:
-        info["iters"] = opt.max_iter
-    info["cost"] = total_cost(X, U, pp, N, False)[0]
-    return pack_w(X, U), info

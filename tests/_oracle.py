@@ -139,8 +139,9 @@ def kd_ref(xyz, stride=None, strict=True):
 class MpcoOpts(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("mu_init", C.c_double),
                 ("bound_push", C.c_double), ("bound_frac", C.c_double), ("kappa_mu", C.c_double),
+                ("theta_mu", C.c_double), ("kappa_eps", C.c_double), ("mu_min_fac", C.c_double), ("maj", C.c_double),
                 ("tau_min", C.c_double), ("eta_phi", C.c_double), ("max_ls", C.c_int),
-                ("s_max", C.c_double), ("kappa_sigma", C.c_double)]
+                ("s_max", C.c_double), ("kappa_sigma", C.c_double), ("trace", C.POINTER(C.c_double))]
 
 
 def _decl_mpc(lib):
@@ -151,7 +152,7 @@ def _decl_mpc(lib):
     lib.mpco_affine.argtypes = [_f64p, d, _f64p, _f64p, _f64p]
     lib.mpco_nlp_f.restype = d; lib.mpco_nlp_f.argtypes = [_f64p, _f64p, i, i]
     lib.mpco_nlp_grad_f.argtypes = [_f64p, _f64p, i, i, _f64p]
-    lib.mpco_nlp_hess_blocks.argtypes = [_f64p, _f64p, i, i, _f64p, _f64p]
+    lib.mpco_nlp_hess_blocks.argtypes = [_f64p, _f64p, i, i, _f64p, _f64p, i]
     lib.mpco_nlp_g.argtypes = [_f64p, _f64p, i, i, d, _f64p]
     lib.mpco_solve.restype = i
     lib.mpco_solve.argtypes = [_f64p, _f64p, _f64p, _f64p, i, i, d, C.POINTER(MpcoOpts), _f64p, _i32p, _f64p]
@@ -174,10 +175,19 @@ def _decl_mpc(lib):
         lib.stepo_get_init_path.argtypes = [_f64p, i, d, d, d, d, d]
 
 
-def mpco_solve(P, w0, lbu, ubu, N, K, dt, tol=1e-4, max_iter=10):
-    """-> (w, info[4], stats[4]) from the C solver."""
+MPC_DEFAULT_MAX_ITER = 40   # oracle/mpc_oracle.c MPCO_DEFAULT_MAX_ITER == the product's default (amk_mpc_create)
+
+
+def mpco_solve(P, w0, lbu, ubu, N, K, dt, tol=1e-4, max_iter=MPC_DEFAULT_MAX_ITER, trace=None, **kw):
+    """-> (w, info[4], stats[4]) from the C solver.  trace: optional float64 [max_iter, 8] array filled per iteration
+    with (phi, E_0, mu, E_mu, alpha, alpha_dual, delta, dphi); kw: other mpco_opts fields."""
     lib = load_oracle()
     opt = MpcoOpts(); lib.mpco_default_opts(C.byref(opt)); opt.tol = tol; opt.max_iter = max_iter
+    for k, v in kw.items():
+        setattr(opt, k, v)
+    if trace is not None:
+        assert trace.dtype == np.float64 and trace.shape == (max_iter, 8) and trace.flags.c_contiguous
+        opt.trace = trace.ctypes.data_as(C.POINTER(C.c_double))
     w = np.zeros(10 + 14 * N); info = np.zeros(4, np.int32); stats = np.zeros(4)
     lib.mpco_solve(np.ascontiguousarray(P, np.float64), np.ascontiguousarray(w0, np.float64),
                    np.ascontiguousarray(lbu, np.float64), np.ascontiguousarray(ubu, np.float64), N, K, dt,
@@ -200,7 +210,7 @@ class MpcOracle:
         self.lib.mpco_setup_gains(self.h, f(prm.gain)); self.lib.mpco_set_drone_radius(self.h, prm.radius)
         self.lib.mpco_set_drone_accel_limits(self.h, prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot)
 
-    def set_solver_options(self, tol=1e-4, max_iter=10):
+    def set_solver_options(self, tol=1e-4, max_iter=MPC_DEFAULT_MAX_ITER):
         self.lib.mpco_set_solver_options(self.h, tol, max_iter)
 
     def Solve(self, ref_states, faster=False):
