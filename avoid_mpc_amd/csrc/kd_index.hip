@@ -269,6 +269,35 @@ __global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, 
     }
 }
 
+// Tie visibility (amk_kd_tie_flags): the k + 1 nearest of every query; flag = 1 when two of them are at the same squared
+// distance -- either two kept neighbours, or the k-th kept one and the best rejected one.  Only then can the index list
+// (and, at the k-th slot, the neighbour SET) differ from nanoflann's, which keeps the first VISITED of equal distances
+// (KNNResultSet::addPoint, nanoflann_two.hpp:219-246) where this library keeps the lowest index.
+__global__ __launch_bounds__(256) void kd_tie_flags_kernel(amk::GridPtrs gpt, const int *__restrict__ sizes, int n_scenes,
+                                                           const double *__restrict__ queries, int query_stride,
+                                                           int n_queries, int k, int *__restrict__ out_flags) {
+    __shared__ amk::GridWaveLds wl[4];
+    const int bps = (n_queries + 3) / 4;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / bps) * 8 + xcd;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (j % bps) * 4 + w;
+    if (s >= n_scenes || q >= n_queries) return;
+    const size_t row = (size_t)s * n_queries + q;
+    const double *qp = queries + row * query_stride;
+    double ld;
+    int li, lpos;
+    amk::grid_knn(gpt.scene(s), qp[0], qp[1], qp[2], k + 1, ld, li, lpos, &wl[w]);
+    const int size = sizes[s];
+    const int cnt = size < k ? size : (size > k ? k : 0);  // what SearchForNearest(k) returns, kd_tree_two.h:119-124
+    const double ld_next = __shfl_down(ld, 1);
+    const int li_next = __shfl_down(li, 1);
+    const bool tie = lane < cnt && li != amk::kNoIndex && li_next != amk::kNoIndex && ld == ld_next;
+    const unsigned long long any = __ballot(tie);
+    if (lane == 0) out_flags[row] = any != 0ull;
+}
+
 // ------------------------------------------------------------------------------------------------
 // keyframe sweep (FrameKDMap::KeyframeThreadWorker, AM/src/FrameKDMap.cpp:462-485)
 // ------------------------------------------------------------------------------------------------
@@ -573,6 +602,18 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
     if (qpw == 1) AMK_LAUNCH_SCAN(1);
     else AMK_LAUNCH_SCAN(5);
 #undef AMK_LAUNCH_SCAN
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int n_queries, int k, int *d_tie_flags,
+                     void *stream) {
+    if (!kd || !d_queries || !d_tie_flags || n_queries <= 0 || k <= 0 || query_stride < 3) return AMK_ERR_INVALID_ARG;
+    if (k + 1 > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
+    const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap};
+    const int blocks = (kd->n_scenes + 7) / 8 * 8 * ((n_queries + 3) / 4);
+    hipLaunchKernelGGL(kd_tie_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p, kd->n_scenes,
+                       d_queries, query_stride, n_queries, k, d_tie_flags);
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }

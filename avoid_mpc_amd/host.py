@@ -101,6 +101,16 @@ class KdBatch:
         return dict(indices=idx, sqdist=d2, pts=pts, counts=cnt)
 
 
+def kd_tie_flags(kd, queries, k, query_stride=3, stream=None):
+    """amk_kd_tie_flags: int32 [S, n_queries], 1 where the k nearest (or the k-th and the best rejected) hold an exact tie."""
+    S = kd.S if hasattr(kd, "S") else queries.shape[0]
+    nq = int(queries.shape[1])
+    out = torch.empty((S, nq), dtype=torch.int32, device=queries.device)
+    capi.check(capi.load().amk_kd_tie_flags(kd.h, capi.dptr(queries), int(query_stride), nq, int(k), capi.dptr(out),
+                                            capi.stream_ptr(stream)), "amk_kd_tie_flags")
+    return out
+
+
 class MpcBatch:
     def __init__(self, T, dt, nearest_point_num, n_scenes):
         self.lib = capi.load()

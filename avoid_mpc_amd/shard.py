@@ -18,9 +18,9 @@ def gather_controls(u_local, counts=None, out=None):
     """all_gather of per-scene controls [S_local, 4] -> [S_total, 4] in global scene order.
     Uneven shards are padded to the largest one (RCCL/gloo all_gather wants equal shapes).
     out: optional preallocated [world * S_local, 4] for the equal-shard case (one collective, no temporaries)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and out is None):
         return u_local
-    world = dist.get_world_size()
+    world = dist.get_world_size()   # (world 1 with `out`: the collective still runs -- the single-GPU RCCL exercise)
     if counts is None:
         if out is not None:
             dist.all_gather_into_tensor(out, u_local.contiguous())

@@ -118,3 +118,36 @@ def make_scene(n, seed, prm: MpcParams):
     pos, vel, acc, yaw = make_odom(seed, prm)
     return dict(cloud=cloud, edge=edge, pos=pos, vel=vel, acc=acc, yaw=yaw,
                 ref_path=make_ref_path(pos, prm))
+
+
+def make_clouds_torch(n, S, seed, device):
+    """Batch of S synthetic frames generated ON the device (bench.py: every in-flight step gets its own frames, so the
+    working set is far beyond the 256 MiB Infinity Cache and the builds stream from HBM).  Same scene model as make_cloud
+    (20-60 vertical cylinders carrying 70 % of the points, 30 % clutter, randomly permuted; n/10 silhouette points as the
+    edge cloud); different random stream, so the values differ from the numpy generator's.
+    -> (cloud float32 [S, n, 3], edge float32 [S, n // 10, 3])"""
+    import math
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(int(seed))
+    rnd = lambda *shape: torch.rand(shape, generator=g, device=device, dtype=torch.float32)
+    ncyl = torch.randint(20, 61, (S, 1), generator=g, device=device)
+    cx = 2.0 + 28.0 * rnd(S, 60); cy = -8.0 + 16.0 * rnd(S, 60); cr = 0.1 + 0.4 * rnd(S, 60)
+    n1 = int(0.7 * n)
+    ci = (rnd(S, n1) * ncyl).long().clamp_(max=59)
+    th = 2.0 * math.pi * rnd(S, n1)
+    gx, gy, gr = cx.gather(1, ci), cy.gather(1, ci), cr.gather(1, ci)
+    on_cyl = torch.stack([gx + gr * torch.cos(th), gy + gr * torch.sin(th), 4.0 * rnd(S, n1)], dim=2)
+    n2 = n - n1
+    clutter = torch.stack([30.0 * rnd(S, n2), -8.0 + 16.0 * rnd(S, n2), 4.0 * rnd(S, n2)], dim=2)
+    cloud = torch.cat([on_cyl, clutter], dim=1)
+    perm = torch.argsort(rnd(S, n), dim=1)
+    cloud = cloud.gather(1, perm[:, :, None].expand(S, n, 3)).contiguous()
+    ne = n // 10
+    ei = (rnd(S, ne) * ncyl).long().clamp_(max=59)
+    side = (rnd(S, ne) < 0.5).float() * 2.0 - 1.0
+    ex0, ey0, er = cx.gather(1, ei), cy.gather(1, ei), cr.gather(1, ei)
+    dist = torch.sqrt(ex0 * ex0 + ey0 * ey0)
+    ang = torch.atan2(ey0, ex0) + side * (math.pi / 2.0 + torch.asin((er / dist).clamp(-1.0, 1.0)))
+    edge = torch.stack([ex0 + er * torch.cos(ang), ey0 + er * torch.sin(ang), 4.0 * rnd(S, ne)], dim=2).contiguous()
+    return cloud, edge

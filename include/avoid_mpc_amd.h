@@ -79,6 +79,15 @@ int amk_kd_sizes(amk_kd *kd, int *h_sizes, void *stream);
 int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int *d_indices,
                   double *d_sqdist, float *d_pts, int *d_counts, void *stream);
 
+/* Tie visibility.  For every query: d_tie_flags[s][q] = 1 when, among the k + 1 nearest points, two are at exactly the same
+ * squared distance (two returned neighbours, or the k-th returned one and the best rejected one), else 0.  nanoflann keeps
+ * the first VISITED of equal distances (KNNResultSet::addPoint, nanoflann_two.hpp:219-246; traversal order), this library
+ * the lowest index: with flag 0 indices and neighbour set are identical to the reference's, with flag 1 only the distance
+ * list is guaranteed identical (DESIGN.md "tie policy").  Queries are read at d_queries[(s*n_queries + q)*query_stride
+ * + {0,1,2}] (query_stride 3 = packed; 10 = the position part of mRefPath).  k + 1 <= AMK_MAX_K.                     */
+int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int n_queries, int k, int *d_tie_flags,
+                     void *stream);
+
 /* Keyframe sweep of FrameKDMap::KeyframeThreadWorker (AM/src/FrameKDMap.cpp:462-485), for every scene:
  * for each point of `keyframe` the nearest-neighbour distance in `current` (SearchForNearest(pt, 1));
  * points with sqrt(d2) > th_dist are outliers (a point gets no result, hence is no outlier, when `current`

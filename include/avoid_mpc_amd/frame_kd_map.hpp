@@ -51,9 +51,33 @@ public:
         PtCloudKdPtr edgeCloud;
     };
 
-    // PtIsInFrame (FrameKDMap.cpp:215-231) needs the camera model; the default accepts every point
-    // (both query paths return the same neighbours for a single-frame map).
-    std::function<bool(const Vector3d &)> ptIsInCurFrame = [](const Vector3d &) { return true; };
+    // PtIsInFrame (FrameKDMap.cpp:215-231): the point in the camera frame of `Twc` (row-major 4x4), 0 <= z <= depth_max,
+    // projected with the intrinsics DIVIDED by the resize scale (:21-24) inside the down-scaled image [0,W) x [0,H)
+    // (mParamWidth / mParamHeight are set by ProcessDepth, :106-107).  Twc is rigid: its inverse is [R' | -R' t] (the
+    // reference calls Eigen's general 4x4 inverse on the same matrix).
+    bool PtIsInFrame(const Vector3d &ptw, const double *Twc) const {
+        const double dx = vx(ptw) - Twc[3], dy = vy(ptw) - Twc[7], dz = vz(ptw) - Twc[11];
+        const double x = Twc[0] * dx + Twc[4] * dy + Twc[8] * dz;
+        const double y = Twc[1] * dx + Twc[5] * dy + Twc[9] * dz;
+        const double z = Twc[2] * dx + Twc[6] * dy + Twc[10] * dz;
+        if (z > depthParams.depth_max || z < 0) return false;                                       // :222-224
+        const double sc = depthParams.resize_scale;
+        const double u = (depthParams.fx / sc) * x / z + depthParams.cx / sc;                       // :225
+        const double v = (depthParams.fy / sc) * y / z + depthParams.cy / sc;                       // :226
+        if (u < 0 || u >= mParamWidth || v < 0 || v >= mParamHeight) return false;                  // :227-229
+        return true;
+    }
+    // Camera model of the fast-path test when the clouds are supplied directly (no ProcessDepth call has set them).
+    void SetImageSize(int rows, int cols) {
+        mParamWidth = (int)(cols / depthParams.resize_scale);                                       // :106-107
+        mParamHeight = (int)(rows / depthParams.resize_scale);
+    }
+    // The fast-path predicate of QueryNearest (:339-340).  Default: the reference's PtIsInFrame(point, mCurFrame.Twc)
+    // once the image size is known (after the first ProcessDepth / SetImageSize); before that the reference reads
+    // uninitialised members -- here every point counts as inside.  Replaceable for hosts with their own camera model.
+    std::function<bool(const Vector3d &)> ptIsInCurFrame = [this](const Vector3d &p) {
+        return mParamWidth <= 0 ? true : PtIsInFrame(p, mTwc);
+    };
     // mCurFrame.Twc (row-major).  The reference leaves it uninitialised until the first AddVertex; identity here.
     double mTwc[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
@@ -65,6 +89,7 @@ public:
     void ProcessDepth(const void *depth, int depthType, int rows, int cols, const double *Twb, Cloud &cloud) {
         int w = 0, h = 0;
         amk_throw(amk_depth_out_size(rows, cols, depthParams.resize_scale, &w, &h), "amk_depth_out_size");
+        mParamWidth = w; mParamHeight = h;                                                         // :106-107
         std::vector<float> xyz((size_t)w * h * 3);
         int n = 0;
         amk_throw(amk_depth_to_cloud_host(depth, depthType, rows, cols, (long long)rows * cols, 1, &depthParams, Twb,
@@ -233,6 +258,7 @@ private:
         return true;
     }
     int mLastSweepOutliers = 0;
+    int mParamWidth = 0, mParamHeight = 0;
     void UpdateQueryVector() {  // :64-74: current frame + all key frames but the newest
         mVecQueryVector.clear();
         mVecQueryVector.push_back(mCurFrame);

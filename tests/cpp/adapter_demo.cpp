@@ -165,6 +165,11 @@ int main(int argc, char **argv) {
         dmap.QueryNearest(Vector3d(3.0, -1.0, 1.5), 1, epts, ed2, true);
         int ec = (int)ed2.size();
         wr(o, &ec, 1); wr(o, ed2.data(), ec);
+        // 8. PtIsInFrame (FrameKDMap.cpp:215-231) with the current frame's Twc and the down-scaled camera model
+        for (int i = 0; i < nq; ++i) {
+            int in = dmap.PtIsInFrame(Vector3d(qs[3 * i], qs[3 * i + 1], qs[3 * i + 2]), dmap.CurTwc()) ? 1 : 0;
+            wr(o, &in, 1);
+        }
     }
     fclose(o);
     return 0;

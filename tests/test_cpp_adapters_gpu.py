@@ -117,4 +117,18 @@ def test_adapters_match_oracle(tmp_path):
     ec = int(take(np.int32, 1)[0]); ed2 = take(np.float64, ec)
     et = _oracle.kd_oracle(eref)
     assert ec == 1 and ed2[0] == et.search(np.array([3.0, -1.0, 1.5]), 1)[1][0]
+    # 8. PtIsInFrame: the reference's formula (general inverse of Twc, resized intrinsics, image bounds), FrameKDMap.cpp:215-231
+    Twb2 = np.array([[1, 0, 0, 2.5], [0, 1, 0, -1.0], [0, 0, 1, 1.5], [0, 0, 0, 1.0]])
+    Twc = Twb2 @ dprm["Tbc"]
+    W, H, sc_ = 160 // 4, 120 // 4, dprm["resize_scale"]
+    inside = []
+    for q in qs:
+        x, y, z, _ = np.linalg.inv(Twc) @ np.array([q[0], q[1], q[2], 1.0])
+        ok = not (z > dprm["depth_max"] or z < 0)
+        if ok:
+            u = dprm["fx"] / sc_ * x / z + dprm["cx"] / sc_; v = dprm["fy"] / sc_ * y / z + dprm["cy"] / sc_
+            ok = not (u < 0 or u >= W or v < 0 or v >= H)
+        inside.append(int(ok))
+    got = take(np.int32, len(qs))
+    assert np.array_equal(got, inside) and 0 < sum(inside) < len(qs), (got, inside)
     assert off == len(buf)

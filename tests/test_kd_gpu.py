@@ -201,3 +201,42 @@ def test_points_outside_the_sampled_box_and_nan_runs(torch_cuda, oracle):
     for j, qq in enumerate(q):
         ri, rd, _ = tree.search(qq, 8)
         assert np.array_equal(res["indices"][0, j], ri) and np.array_equal(res["sqdist"][0, j], rd), j
+
+
+def test_tie_flags_mark_every_query_whose_indices_may_differ_from_nanoflann(torch_cuda, oracle):
+    """amk_kd_tie_flags.  (a) tie-free random cloud: no flag, indices == the reference-pinned oracle (traversal order).
+    (b) a QUANTISED cloud as the edge pipeline makes them (8-bit depth on a pixel grid, FrameKDMap.cpp:180-200: exact
+    ties are common): wherever the index list differs from nanoflann's the flag is set, wherever the flag is clear the
+    index list is identical; the distance lists are identical everywhere.  Reports how often the SETS differ."""
+    torch = torch_cuda
+    from avoid_mpc_amd.host import KdBatch, kd_tie_flags
+    rng = np.random.default_rng(5)
+    clouds = {"random": rng.uniform(-5, 5, (4000, 3)).astype(np.float32)}
+    u, v = np.meshgrid(np.arange(64), np.arange(48))
+    depth = (rng.integers(20, 200, (48, 64)) * (100.0 / 200.0)).astype(np.float64)        # byte * (max - min) / 200
+    clouds["quantised"] = np.stack([(u - 32.0) * depth / 32.0, (v - 24.0) * depth / 32.0, depth], -1).reshape(-1, 3).astype(np.float32)
+    for name, c in clouds.items():
+        t = _oracle.kd_oracle(c)
+        qs = c[rng.integers(0, len(c), 48)].astype(np.float64) + (0.0 if name == "quantised" else 0.01)
+        for k in (1, 3, 8):
+            kd = KdBatch(1, len(c)); kd.build(torch.from_numpy(c[None]).cuda())
+            qd = torch.from_numpy(qs[None].copy()).cuda()
+            r = kd.search(qd, k)
+            fl = kd_tie_flags(kd, qd, k).cpu().numpy()[0]
+            torch.cuda.synchronize()
+            idx, d2 = r["indices"].cpu().numpy()[0], r["sqdist"].cpu().numpy()[0]
+            differ = sets_differ = 0
+            for i, q in enumerate(qs):
+                ia, da = t.search_raw(q, k)                      # nanoflann's order (oracle pinned to the reference)
+                assert np.array_equal(d2[i][:len(da)], da)
+                if not np.array_equal(idx[i][:len(ia)], ia):
+                    differ += 1
+                    sets_differ += set(idx[i][:len(ia)]) != set(ia)
+                    assert fl[i] == 1, (name, k, i)
+                # the flag itself: an exact tie among the k + 1 nearest
+                db = t.bruteforce(q, k + 1)[1]
+                assert fl[i] == int(np.any(np.diff(db) == 0)), (name, k, i, db)
+            print(f"{name} k={k}: flagged {int(fl.sum())}/48, index lists differing from nanoflann {differ}, sets differing {sets_differ}")
+            if name == "random":
+                assert fl.sum() == 0 and differ == 0
+            kd.close()

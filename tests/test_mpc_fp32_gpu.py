@@ -2,15 +2,15 @@
 vs CPU trajectory".  amk_mpc_set_precision(32) runs the same interior-point algorithm in fp32 (kNN stays fp64, so
 the neighbour sets are unchanged); the CPU trajectory is the fp64 oracle's.
 
-Stated tolerances (measured on MI355X, 32 C5 problems, N = 30, K = 8, in brackets):
-  * smooth part of the problem (collision weight 0: a box-constrained QP): |u32 - u64|_inf and |w32 - w64|_inf
-    <= 1e-4 [1.1e-5] -- this is the rounding level of the fp32 Riccati/line-search arithmetic;
-  * full problem, the reference's 10-iteration cap: the truncated solve of the non-convex, kinked problem is a
-    chaotic map of its inputs -- the *fp64* path itself moves u by up to O(1) m/s^2 when x_init is perturbed by
-    1e-7 relative -- so a pointwise bound is not meaningful [|du| median 0.11, p90 1.1,
-    max 4.3 m/s^2].  What fp32 does preserve is the quality of the iterate: the fp64-evaluated objective of the
-    fp32 solution is within 25 % of the fp64 solution's on every scene [-12 % .. +15 %] and within 1 % in the
-    median [6e-5]."""
+Stated tolerances (measured on MI355X, in brackets):
+  * smooth part of the problem (collision weight 0: a box-constrained QP), 32 C5 problems: |u32 - u64|_inf and
+    |w32 - w64|_inf <= 1e-4 [1e-5] -- the rounding level of the fp32 Riccati / line-search arithmetic;
+  * full problem, shipped options, the 64 C5 fixture scenes (tests/golden/mpc_parity_golden.npz, N = 30, K = 8): against
+    the converged fp64 CPU optimum u*, |u32 - u*|_inf <= 1e-2 m/s^2 on >= 85 % of the scenes [90.6 %], median <= 2e-3
+    [5.9e-4]; the fp64-evaluated objective of the fp32 solution is within 1e-5 of J* in the median [< 1e-6].  fp32
+    cannot resolve the last barrier levels (its gradient noise floor is ~0.5 in E_mu against tol 1e-4), so it returns
+    the iterate of a coarser level at the iteration cap: a tenth of the fp64 path's accuracy, not a different optimum.
+    (The fp64 path: 98 % within 1e-3, tests/test_mpc_parity_gpu.py.)"""
 import numpy as np
 import pytest
 
@@ -28,7 +28,7 @@ def torch_cuda():
     return torch
 
 
-def _solve_gpu(torch, prm, ref, bits, max_iter=10):
+def _solve_gpu(torch, prm, ref, bits, max_iter=40):
     from avoid_mpc_amd.host import MpcBatch
     g = MpcBatch(prm.T, prm.dt, prm.K, len(ref)); g.configure(prm)
     g.set_solver_options(1e-4, max_iter); g.set_precision(bits)
@@ -57,27 +57,20 @@ def test_fp32_matches_fp64_oracle_on_the_smooth_part(torch_cuda):
     assert du <= 1e-4 and dw <= 1e-4
 
 
-def test_fp32_objective_parity_on_the_full_problem(torch_cuda):
-    prm, ref = _problems(1.0)
-    u32, w32, info32 = _solve_gpu(torch_cuda, prm, ref, 32)
-    lib = _oracle.load_oracle()
-    tail = np.concatenate([prm.gain, prm.tau, prm.weights, [prm.radius]])
-    rel, du = [], []
-    for s in range(len(ref)):
-        m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)
-        uc, xc, ic = m.Solve(ref[s], True)
-        P = np.ascontiguousarray(np.concatenate([ref[s], tail]))
-        j64 = lib.mpco_nlp_f(np.ascontiguousarray(m.warm_start), P, prm.N, prm.K)
-        j32 = lib.mpco_nlp_f(np.ascontiguousarray(w32[s]), P, prm.N, prm.K)
-        rel.append((j32 - j64) / abs(j64)); du.append(np.abs(u32[s] - uc).max())
-        lo = np.array([-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot])
-        hi = np.array([prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot])
-        assert np.all(np.isfinite(w32[s])) and np.all(u32[s] > lo) and np.all(u32[s] < hi)   # strictly interior
-    rel, du = np.array(rel), np.array(du)
-    print(f"fp32 vs fp64 oracle, full problem: (J32-J64)/J64 median {np.median(rel):.2e} min {rel.min():.2e} "
-          f"max {rel.max():.2e}; |du| median {np.median(du):.2e} p90 {np.quantile(du, 0.9):.2e} max {du.max():.2e}")
-    assert np.abs(rel).max() <= 0.25 and abs(np.median(rel)) <= 1e-2
-    assert np.array_equal(info32[:, 1], np.full(len(ref), 10))          # the iteration cap, as in fp64
+def test_fp32_tolerance_against_the_converged_cpu_trajectory(torch_cuda):
+    from tests.test_mpc_parity import G, gate_report
+    from tests.test_mpc_parity_gpu import solve_fixture_on_gpu
+    u32, w32, J32, info32 = solve_fixture_on_gpu(torch_cuda, "C5", precision=32)
+    ws = G["C5.wstar"]
+    du = np.abs(u32 - ws[:, 10:14]).max(axis=1)
+    rep = gate_report("C5", u32, w32, J32)
+    print("fp32 vs converged fp64 optimum (C5):", rep, "frac |du| <= 1e-2: %.3f" % np.mean(du <= 1e-2))
+    prm = synth.MpcParams(T=1.0, K=8)
+    lo = np.array([-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot])
+    hi = np.array([prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot])
+    assert np.all(np.isfinite(w32)) and np.all(u32 > lo) and np.all(u32 < hi)   # strictly interior
+    assert np.mean(du <= 1e-2) >= 0.85 and np.median(du) <= 2e-3
+    assert abs(rep["dJ_rel_median"]) <= 1e-5
 
 
 def test_fp32_full_size_c5_step_and_setter_errors(torch_cuda):

@@ -1,0 +1,65 @@
+"""CPU: the MPC parity gate on the oracle and the fixture behind it (tests/golden/mpc_parity_golden.npz, made by
+tests/golden/make_mpc_parity_golden.py).
+
+SURVEY.md section 8(d): `|u - u*|_inf <= 1e-3 m/s^2` and `|x - x*|_inf <= 1e-3` against the CONVERGED optimum (IPOPT's
+iterates are not reproducible: CasADi/IPOPT are absent -- PARITY UNPINNED against them).  u*, x*, J* are the local optimum
+reached from the reference's zero warm start (HighLvlMpc.cpp:26-27,35), cross-checked by scipy's L-BFGS-B.  The shipped
+options (tol 1e-4, AMK_MPC_DEFAULT_MAX_ITER iterations) must put >= 90 % of the 64 bench scenes of every BASELINE size
+inside the bound; the GPU twin of this test is tests/test_mpc_parity_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_parity_golden.npz"))
+GATE_U = 1e-3
+GATE_FRACTION = 0.9
+
+
+def gate_report(cfg, u, w, J):
+    """-> dict of the numbers quoted with every result (also used by the GPU test and by bench.py's parity block)."""
+    ws, Js = G[cfg + ".wstar"], G[cfg + ".Jstar"]
+    du = np.abs(u - ws[:, 10:14]).max(axis=1)
+    dw = np.abs(w - ws).max(axis=1)
+    dJ = (J - Js) / Js
+    return dict(scenes=len(du), frac_u_within_1e3=float(np.mean(du <= GATE_U)), du_median=float(np.median(du)),
+                du_p90=float(np.quantile(du, 0.9)), du_max=float(du.max()), frac_x_within_1e3=float(np.mean(dw <= GATE_U)),
+                dJ_rel_median=float(np.median(dJ)), dJ_rel_max=float(dJ.max()))
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C5"])
+def test_fixture_optimum_is_confirmed_by_an_independent_optimiser(cfg):
+    """L-BFGS-B (scipy) started at u* on the condensed problem, confined to |U - U*|_inf <= 0.05 (unconfined it jumps
+    into other basins from the kink points, see the generator), neither finds a lower objective nor moves the first
+    control, and no random feasible perturbation of U* lowers the objective: u* is a local minimiser of the restated
+    NLP, not an artefact of the interior-point method that found it."""
+    Js, Jl, dul, probe = G[cfg + ".Jstar"], G[cfg + ".J_lbfgs"], G[cfg + ".du_lbfgs"], G[cfg + ".dJ_probe"]
+    assert len(Js) == 64
+    assert np.all(Jl <= Js + 1e-9 * Js)            # scipy was started there, it cannot end higher
+    assert np.all(Js - Jl <= 1e-7 * Js), float(((Js - Jl) / Js).max())
+    assert np.quantile(dul, 0.9) <= 1e-5 and dul.max() <= 1e-3, (np.quantile(dul, 0.9), dul.max())
+    assert np.all(probe >= -1e-9 * Js), float(probe.min())
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C5"])
+def test_oracle_with_the_shipped_options_meets_the_gate(cfg):
+    c = synth.CONFIGS[cfg]
+    prm = synth.MpcParams(T=c["T"], K=c["K"])
+    N, K = prm.N, prm.K
+    lbu = [-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot]
+    ubu = [prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot]
+    refs = G[cfg + ".ref"]
+    W, J, it = [], [], []
+    for ref in refs:
+        P = np.concatenate([ref, prm.gain, prm.tau, prm.weights, [prm.radius]])
+        w, info, st = _oracle.mpco_solve(P, np.zeros(10 + 14 * N), lbu, ubu, N, K, prm.dt)   # defaults
+        W.append(w); J.append(st[0]); it.append(info[1])
+    W = np.array(W)
+    rep = gate_report(cfg, W[:, 10:14], W, np.array(J))
+    print(cfg, rep, "iterations mean %.1f max %d" % (np.mean(it), np.max(it)))
+    assert rep["frac_u_within_1e3"] >= GATE_FRACTION, rep
+    assert rep["frac_x_within_1e3"] >= GATE_FRACTION, rep
+    assert rep["dJ_rel_median"] <= 1e-7, rep
