@@ -27,7 +27,7 @@ SYMBOLS = [
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
-    "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_step_batch", "amk_step_batch_host",
+    "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -40,6 +40,12 @@ class AmkError(RuntimeError):
 class StepParams(C.Structure):
     _fields_ = [("speed", C.c_double), ("safety_distance", C.c_double),
                 ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
+
+
+class FrameCamera(C.Structure):
+    """amk_frame_camera: PtIsInFrame's camera model (FrameKDMap.cpp:215-231), intrinsics already divided by the resize scale."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("depth_max", C.c_double), ("width", C.c_int), ("height", C.c_int)]
 
 
 class DepthParams(C.Structure):
@@ -114,6 +120,8 @@ def load():
         "amk_mpc_eval_host": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
+        "amk_step_batch_frames": (i, [vp, vp, i, vp, C.POINTER(FrameCamera), vp, C.POINTER(StepParams), vp, vp, vp, vp, vp,
+                                      vp, vp]),
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
         "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
         "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),

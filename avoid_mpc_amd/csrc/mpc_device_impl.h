@@ -742,7 +742,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
         while (!ok) {
             __syncthreads();
-            if (delta == RL(0.0)) delta = (delta_last == RL(0.0)) ? RL(1e-4) : fmax(RL(1e-20), delta_last / RL(3.0));
+            if (delta == RL(0.0)) delta = (delta_last == RL(0.0)) ? RL(1.0) : fmax(RL(1e-20), delta_last / RL(3.0));
             else delta *= (delta_last == RL(0.0)) ? RL(100.0) : RL(8.0);
             ++reg_now;
             if (delta > (AMK_REAL_F32 ? RL(1e30) : RL(1e40))) break;

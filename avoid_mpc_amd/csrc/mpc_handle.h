@@ -27,6 +27,10 @@ struct amk_mpc {
     amk::DevBuf<double> edge_d2;    // [S]
     amk::DevBuf<double> ref_states; // [S][nref]    vecRefStates handed to Solve
     amk::DevBuf<int> done;          // [S]          scene left the re-plan loop (:333-335)
+    // per-frame raw query results of amk_step_batch_frames (allocated by its first call)
+    int mf_frames = 0;
+    amk::DevBuf<float> mf_knn_pts, mf_edge_pt;    // [F][S][N][K][3], [F][S][3]
+    amk::DevBuf<double> mf_knn_d2, mf_edge_d2;    // [F][S][N][K],    [F][S]
     // staging for amk_step_batch_host
     amk::DevBuf<double> sh_sq, sh_posx, sh_ref, sh_u, sh_x0;
     amk::DevBuf<int> sh_flags;

@@ -1,0 +1,313 @@
+// One control step over a MULTI-FRAME map (current frame + keyframes) for a batch of scenes on gfx950.
+//
+// amk_step_batch (step.hip) covers the map of BASELINE's synthetic configs, mVecQueryVector = [cur].  With keyframes
+// FrameKDMap answers a query differently (AM/src/FrameKDMap.cpp):
+//   QueryNearest (:322-376)     fast path -- current frame only -- when that frame's cloud holds >= k points AND the query
+//                               projects into the current image (PtIsInFrame, :215-231); otherwise every frame f of
+//                               mVecQueryVector is searched with k' = min(k, size_f) (:298) and the union is sorted by
+//                               squared distance, first k kept (:371-375).  With KDTreeTwo's count rule (kd_tree_two.h:
+//                               119-124: size == n -> no result) a frame contributes k points iff it holds MORE than k.
+//   GetNearestDistance (:400-427)  min over the frames (non-empty obstacle cloud) of the 1-NN squared distance, sqrt.
+// This file is the TASK branch of Step (AM/src/AvoidanceStateMachine.cpp:322-355) on such a map: obstacles remembered only
+// through keyframes (already out of the field of view) stay in needReplan, PlanWapionts and P.
+//
+// Per outer iteration:
+//   step_knn_frames_kernel        raw K-NN of the N reference points + edge 1-NN of point 0 in EVERY frame (grid.y = frame)
+//   step_merge_plan_pack_kernel   one wavefront per scene: PtIsInFrame per reference point, GetNearestDistance, PlanWapionts
+//                                 (snap to the nearest edge point over the frames, re-query), fast path / merge per
+//                                 reference point, padding, needReplan, early exit, GetRefStates
+//   mpc_solve_kernel              Solve + refill of the reference path (mpc_solve.hip)
+#include "kd_grid.h"
+#include "mpc_handle.h"
+
+using namespace amk;
+
+namespace {
+
+struct FrameSet {  // kernel argument: where every frame's indices live
+    GridPtrs obs[AMK_MAX_FRAMES], edge[AMK_MAX_FRAMES];
+    const int *size_obs[AMK_MAX_FRAMES], *size_edge[AMK_MAX_FRAMES];
+    int n;
+};
+
+struct FrameBufs {  // per-frame raw query results, frame-major
+    float *knn_pts;   // [F][S][N][K][3]
+    double *knn_d2;   // [F][S][N][K]
+    float *edge_pt;   // [F][S][3]
+    double *edge_d2;  // [F][S]
+};
+
+__global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n_scenes, const double *__restrict__ ref_path,
+                                                              int N, int K, FrameBufs fb, const int *__restrict__ done) {
+    __shared__ GridWaveLds wl[4];
+    const int f = blockIdx.y;
+    const int nq = N + 1;
+    const int bps = (nq + 3) / 4;
+    const int xcd = blockIdx.x & 7;
+    const int j = blockIdx.x >> 3;
+    const int s = (j / bps) * 8 + xcd;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (j % bps) * 4 + w;
+    if (s >= n_scenes || q >= nq || done[s]) return;
+    const bool is_edge = q == N;
+    const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
+    const int k = is_edge ? 1 : K;
+    double ld;
+    int li, lpos;
+    const GridScene gs = is_edge ? fs.edge[f].scene(s) : fs.obs[f].scene(s);
+    grid_knn(gs, qp[0], qp[1], qp[2], k, ld, li, lpos, &wl[w]);
+    if (lane < k) {
+        const bool ok = li != kNoIndex;
+        const float4 rec = gs.pt[lpos];
+        if (is_edge) {
+            const size_t o = (size_t)f * n_scenes + s;
+            fb.edge_d2[o] = ok ? ld : DBL_MAX;
+            fb.edge_pt[3 * o + 0] = ok ? rec.x : 0.f;
+            fb.edge_pt[3 * o + 1] = ok ? rec.y : 0.f;
+            fb.edge_pt[3 * o + 2] = ok ? rec.z : 0.f;
+        } else {
+            const size_t row = ((size_t)f * n_scenes + s) * N + q;
+            fb.knn_d2[row * K + lane] = ok ? ld : DBL_MAX;
+            float *o = fb.knn_pts + (row * K + lane) * 3;
+            o[0] = ok ? rec.x : 0.f;
+            o[1] = ok ? rec.y : 0.f;
+            o[2] = ok ? rec.z : 0.f;
+        }
+    }
+}
+
+// PtIsInFrame (FrameKDMap.cpp:215-231): Twc rigid, its inverse is [R' | -R' t]
+__device__ __forceinline__ bool pt_in_frame(const double *__restrict__ T, const amk_frame_camera &cam, double px, double py,
+                                            double pz) {
+    const double dx = px - T[3], dy = py - T[7], dz = pz - T[11];
+    const double x = T[0] * dx + T[4] * dy + T[8] * dz;
+    const double y = T[1] * dx + T[5] * dy + T[9] * dz;
+    const double z = T[2] * dx + T[6] * dy + T[10] * dz;
+    if (z > cam.depth_max || z < 0) return false;
+    const double u = cam.fx * x / z + cam.cx;
+    const double v = cam.fy * y / z + cam.cy;
+    if (u < 0 || u >= cam.width || v < 0 || v >= cam.height) return false;
+    return true;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(v, off);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+constexpr int kMaxCandPerLane = (AMK_MAX_FRAMES * AMK_MAX_K + 63) / 64;
+
+__global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
+    FrameSet fs, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
+    int max_iter, double speed, double T, double safety_distance, const double *__restrict__ state_quad,
+    const double *__restrict__ pos_x, double *__restrict__ ref_path, float *__restrict__ knn_pts,
+    double *__restrict__ knn_d2, double *__restrict__ ref_states, int *__restrict__ done, int *__restrict__ flags) {
+    const int s = blockIdx.x, lane = threadIdx.x;
+    if (done[s]) return;
+    const int F = fs.n;
+    __shared__ GridWaveLds wl;
+    __shared__ int cntq[AMK_MAX_HORIZON];
+    double *rp = ref_path + (size_t)s * N * SD;
+    const double *Ts = Twc ? Twc + (size_t)s * 16 : nullptr;
+    auto in_frame = [&](double x, double y, double z) { return Ts ? pt_in_frame(Ts, cam, x, y, z) : true; };
+    // ---- PlanWapionts (:259-281) for reference point 0
+    const double p0x = rp[0], p0y = rp[1], p0z = rp[2];
+    double d2n = DBL_MAX;  // GetNearestDistance: 1-NN per frame exists iff the frame holds more than one point
+    for (int f = 0; f < F; ++f)
+        if (fs.size_obs[f][s] > 1) d2n = fmin(d2n, fb.knn_d2[(((size_t)f * S + s) * N) * K]);
+    int is_safety = 1;
+    if (!(sqrt(d2n) > safety_distance)) {
+        // QueryNearest(p1, 1, ..., queryEdge = true): fast path iff the current edge cloud holds >= 1 point and p1 is in frame
+        double best = DBL_MAX;
+        int bf = -1;
+        if (fs.size_edge[0][s] >= 1 && in_frame(p0x, p0y, p0z)) {
+            if (fs.size_edge[0][s] > 1 && fb.edge_d2[s] < DBL_MAX) { best = fb.edge_d2[s]; bf = 0; }
+        } else {
+            for (int f = 0; f < F; ++f) {  // k' = min(1, size_f): a result iff size_f > 1; ties keep the earlier frame
+                const double d = fb.edge_d2[(size_t)f * S + s];
+                if (fs.size_edge[f][s] > 1 && d < best) { best = d; bf = f; }
+            }
+        }
+        if (bf < 0) {
+            is_safety = 0;
+        } else {
+            const float *ep = fb.edge_pt + 3 * ((size_t)bf * S + s);
+            const double ex = (double)ep[0], ey = (double)ep[1], ez = (double)ep[2];
+            for (int f = 0; f < F; ++f) {  // the snapped point is what ProcessWaypoints queries next (:210-215)
+                double gld;
+                int gli, glpos;
+                const GridScene gs = fs.obs[f].scene(s);
+                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl);
+                if (lane < K) {
+                    const bool ok = gli != kNoIndex;
+                    const float4 rec = gs.pt[glpos];
+                    const size_t row = ((size_t)f * S + s) * N;
+                    fb.knn_d2[row * K + lane] = ok ? gld : DBL_MAX;
+                    float *o = fb.knn_pts + (row * K + lane) * 3;
+                    o[0] = ok ? rec.x : 0.f; o[1] = ok ? rec.y : 0.f; o[2] = ok ? rec.z : 0.f;
+                }
+                __syncthreads();
+            }
+            if (lane == 0) { rp[0] = ex; rp[1] = ey; rp[2] = ez; }
+        }
+    }
+    if (lane == 0) flags[4 * s + 0] = is_safety;
+    __threadfence_block();
+    __syncthreads();
+    // ---- ProcessWaypoints' queries (:204-215): fast path or merge over the frames, per reference point
+    for (int i = 0; i < N; ++i) {
+        const double qx = rp[i * SD], qy = rp[i * SD + 1], qz = rp[i * SD + 2];
+        const size_t orow = ((size_t)s * N + i) * K;
+        if (fs.size_obs[0][s] >= K && in_frame(qx, qy, qz)) {  // QueryNearestWithCurFrame (:254-275, 339-345)
+            const int cnt = fs.size_obs[0][s] > K ? K : 0;      // kd_tree_two.h:119-124
+            if (lane < K) {
+                const size_t irow = ((size_t)s * N + i) * K + lane;  // frame 0
+                knn_d2[orow + lane] = fb.knn_d2[irow];
+                for (int c = 0; c < 3; ++c) knn_pts[(orow + lane) * 3 + c] = fb.knn_pts[irow * 3 + c];
+            }
+            if (lane == 0) cntq[i] = cnt;
+            continue;
+        }
+        // QueryNearestThreadWorker over mVecQueryVector (:276-321) + sort (:371): candidate c = f * K + j
+        unsigned long long key[kMaxCandPerLane];
+        const int ncand = F * K;
+#pragma unroll
+        for (int r = 0; r < kMaxCandPerLane; ++r) {
+            const int c = lane + 64 * r;
+            key[r] = ~0ull;
+            if (c < ncand) {
+                const int f = c / K, jj = c - f * K;
+                if (fs.size_obs[f][s] > K) {  // k' = min(K, size_f) results exist iff size_f > k'
+                    const double d = fb.knn_d2[(((size_t)f * S + s) * N + i) * K + jj];
+                    if (d < DBL_MAX) key[r] = (unsigned long long)__double_as_longlong(d);  // d >= 0: order-preserving
+                }
+            }
+        }
+        int cnt = 0;
+        for (int m = 0; m < K; ++m) {  // K rounds of "smallest remaining (distance, candidate id)"
+            unsigned long long loc = ~0ull;
+#pragma unroll
+            for (int r = 0; r < kMaxCandPerLane; ++r) loc = key[r] < loc ? key[r] : loc;
+            const unsigned long long best = wave_min_u64(loc);
+            if (best == ~0ull) break;
+            int myc = 0x7fffffff;  // lowest candidate id holding `best`
+#pragma unroll
+            for (int r = kMaxCandPerLane - 1; r >= 0; --r)
+                if (key[r] == best) myc = lane + 64 * r;
+            int win = myc;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) win = min(win, __shfl_xor(win, off));
+            if (myc == win) {
+                const int f = win / K, jj = win - f * K;
+                const size_t irow = (((size_t)f * S + s) * N + i) * K + jj;
+                knn_d2[orow + m] = __longlong_as_double((long long)best);
+                for (int c = 0; c < 3; ++c) knn_pts[(orow + m) * 3 + c] = fb.knn_pts[irow * 3 + c];
+#pragma unroll
+                for (int r = 0; r < kMaxCandPerLane; ++r)
+                    if (lane + 64 * r == win) key[r] = ~0ull;
+            }
+            ++cnt;
+        }
+        if (lane == 0) cntq[i] = cnt;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- padding, needReplan (:216-231), early exit (:333-335), GetRefStates (:236-257)
+    bool need = false;
+    if (lane < N) need = (cntq[lane] == 0) || (sqrt(knn_d2[((size_t)s * N + lane) * K]) <= safety_distance);
+    const bool need_replan = __ballot(need) != 0ull;
+    if (!need_replan && iter > 0 && is_safety) {
+        if (lane == 0) done[s] = 1;
+        return;
+    }
+    double *P = ref_states + (size_t)s * nref;
+    const double *sq = state_quad + ((size_t)s * max_iter + iter) * SD;
+    if (lane < SD) P[lane] = sq[lane];
+    for (int e = lane; e < SD * N; e += 64) P[SD + e] = rp[e];
+    for (int e = lane; e < 3 * K * N; e += 64) {
+        const int i = e / (3 * K), jj = (e / 3) % K;
+        P[SD + SD * N + e] = (jj < cntq[i]) ? (double)knn_pts[(size_t)s * N * K * 3 + e] : 10000.0;
+    }
+    if (lane < SD) {
+        const double *last = rp + (N - 1) * SD;
+        double v = last[lane];
+        if (lane == 0) {
+            double dX = speed * T - fmax(0., last[0] - pos_x[s]);
+            dX = fmax(0., dX);
+            v += dX;
+        }
+        if (lane == 1) v = 0.;
+        P[SD + SD * N + 3 * K * N + lane] = v;
+    }
+}
+
+__global__ void step_frames_begin_kernel(int S, int *__restrict__ done, int *__restrict__ flags, double *__restrict__ u) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= S) return;
+    done[s] = 0;
+    flags[4 * s + 0] = 1;
+    flags[4 * s + 1] = 0;
+    flags[4 * s + 2] = -1;
+    flags[4 * s + 3] = 0;
+    u[4 * s + 0] = u[4 * s + 1] = u[4 * s + 2] = u[4 * s + 3] = 0.0;
+}
+
+}  // namespace
+
+extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edge, int n_frames, const double *d_Twc,
+                                     const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm,
+                                     const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
+                                     double *d_x0array, int *d_flags, void *stream_) {
+    if (!obstacle || !edge || !mpc || !prm || !d_state_quad || !d_pos_x || !d_ref_path || !d_u || !d_flags || n_frames < 1)
+        return AMK_ERR_INVALID_ARG;
+    if (d_Twc && !cam) return AMK_ERR_INVALID_ARG;
+    if (n_frames > AMK_MAX_FRAMES) return AMK_ERR_UNSUPPORTED;
+    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
+    const int S = mpc->S, N = mpc->N, K = mpc->K, F = n_frames;
+    FrameSet fs;
+    fs.n = F;
+    for (int f = 0; f < F; ++f) {
+        if (!obstacle[f] || !edge[f] || obstacle[f]->n_scenes != S || edge[f]->n_scenes != S) return AMK_ERR_INVALID_ARG;
+        if (obstacle[f]->mode != 0 || edge[f]->mode != 0) return AMK_ERR_UNSUPPORTED;  // bucketed indices only
+        fs.obs[f] = GridPtrs{obstacle[f]->gpt.p, obstacle[f]->cell_start.p, obstacle[f]->gparams.p, obstacle[f]->cap};
+        fs.edge[f] = GridPtrs{edge[f]->gpt.p, edge[f]->cell_start.p, edge[f]->gparams.p, edge[f]->cap};
+        fs.size_obs[f] = obstacle[f]->size.p;
+        fs.size_edge[f] = edge[f]->size.p;
+    }
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!mpc->done.p) {
+        AMK_HIP(mpc->knn_pts.alloc((size_t)S * N * K * 3));
+        AMK_HIP(mpc->knn_d2.alloc((size_t)S * N * K));
+        AMK_HIP(mpc->edge_pt.alloc((size_t)S * 3));
+        AMK_HIP(mpc->edge_d2.alloc(S));
+        AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
+        AMK_HIP(mpc->done.alloc(S));
+    }
+    if (mpc->mf_frames < F) {
+        AMK_HIP(mpc->mf_knn_pts.alloc((size_t)F * S * N * K * 3));
+        AMK_HIP(mpc->mf_knn_d2.alloc((size_t)F * S * N * K));
+        AMK_HIP(mpc->mf_edge_pt.alloc((size_t)F * S * 3));
+        AMK_HIP(mpc->mf_edge_d2.alloc((size_t)F * S));
+        mpc->mf_frames = F;
+    }
+    const FrameBufs fb{mpc->mf_knn_pts.p, mpc->mf_knn_d2.p, mpc->mf_edge_pt.p, mpc->mf_edge_d2.p};
+    amk_frame_camera c{};
+    if (cam) c = *cam;
+    hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
+    const int S8 = (S + 7) / 8 * 8;
+    for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
+        hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path, N, K,
+                           fb, mpc->done.p);
+        hipLaunchKernelGGL(step_merge_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, fs, fb, S, d_Twc, c, N, K, mpc->nref,
+                           iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
+                           d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
+        AMK_HIP(hipGetLastError());
+        int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
+        if (st != AMK_OK) return st;
+    }
+    return AMK_OK;
+}

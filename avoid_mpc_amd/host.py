@@ -228,6 +228,27 @@ def step_batch(kd_obstacle, kd_edge, mpc, prm, state_quad, pos_x, ref_path, stre
     return out
 
 
+def step_batch_frames(kd_obstacle_frames, kd_edge_frames, mpc, prm, state_quad, pos_x, ref_path, Twc=None, cam=None,
+                      stream=None, out=None):
+    """amk_step_batch_frames: the control step over a multi-frame map.  kd_*_frames: lists of KdBatch, index 0 = current
+    frame; Twc float64 [S, 4, 4] (or None); cam: capi.FrameCamera."""
+    S, N = mpc.S, mpc.N
+    F = len(kd_obstacle_frames)
+    assert F == len(kd_edge_frames) and F >= 1
+    dev = ref_path.device
+    if out is None:
+        out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
+                   x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
+                   flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
+    sp = capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0)
+    oa = (C.c_void_p * F)(*[k.h for k in kd_obstacle_frames]); ea = (C.c_void_p * F)(*[k.h for k in kd_edge_frames])
+    capi.check(capi.load().amk_step_batch_frames(oa, ea, F, capi.dptr(Twc), C.byref(cam) if cam is not None else None, mpc.h,
+                                                 C.byref(sp), capi.dptr(state_quad), capi.dptr(pos_x), capi.dptr(ref_path),
+                                                 capi.dptr(out["u"]), capi.dptr(out["x0array"]), capi.dptr(out["flags"]),
+                                                 capi.stream_ptr(stream)), "amk_step_batch_frames")
+    return out
+
+
 def depth_params(pixel2meter=1.0, depth_min=0.1, depth_max=100.0, resize_scale=10.0, fx=320.0, fy=320.0, cx=320.0,
                  cy=240.0, Tbc=None):
     """amk_depth_params with the defaults of AM/config/mpc_parameters.yaml:59-66."""

@@ -62,6 +62,7 @@ def _cpu_scene(args):
     from tests import _oracle
     prm = synth.MpcParams(T=T, K=K)
     t_ref = None
+    t_begin = time.time()
     if use_ref:   # FrameKDMap::AddVertex's two InitializeNew calls on the reference's nanoflann (reference flags)
         t0 = time.perf_counter()
         ko, ke = _oracle.kd_ref(cloud, strict=False), _oracle.kd_ref(edge, strict=False)
@@ -74,7 +75,7 @@ def _cpu_scene(args):
     r = _oracle.step_oracle(kd, ke, mpc, prm, sq, posx, ref.copy())
     t2 = time.perf_counter()
     kd.close(); ke.close(); mpc.close()
-    return r["u"], r["flags"], t1 - t0, t2 - t1, t_ref
+    return r["u"], r["flags"], t1 - t0, t2 - t1, t_ref, t_begin, time.time()
 
 
 def cpu_baseline_and_check(scenes, T, K, gpu_u, gpu_flags):
@@ -101,14 +102,22 @@ def cpu_baseline_and_check(scenes, T, K, gpu_u, gpu_flags):
     wall = time.perf_counter() - t0
     build = np.array([(r[4] if use_ref else r[2]) for r in res]); step = np.array([r[3] for r in res])
     busy = float((build + step).sum())
-    value = workers / (busy / len(res))     # `workers` cores each running scenes back to back (startup excluded)
+    span = max(r[6] for r in res) - min(r[5] for r in res)   # first scene started .. last scene finished (no startup)
+    value = len(res) / span
+    quota = None
+    try:
+        quota = open("/sys/fs/cgroup/cpu.max").read().strip()
+    except Exception:
+        pass
     base = {"value": round(value, 2), "unit": "MPC steps/s", "cores": workers, "kind": "port",
-            "sample": f"the {len(res)} scenes of one in-flight slot of the timed workload, one per core at a time on "
-                      f"{workers} processes ({busy:.1f} s of CPU work, {wall:.1f} s wall incl. process startup); KD builds "
+            "sample": f"the {len(res)} scenes of one in-flight slot of the timed workload, one per process at a time on "
+                      f"{workers} processes; value = scenes / (last finish - first start) = {len(res)} / {span:.2f} s "
+                      f"({busy:.1f} s of summed per-scene time, {wall:.1f} s wall incl. process startup); KD builds "
                       + ("on the reference's own nanoflann compiled in place with the reference's flags (oracle/_ref), "
                          if use_ref else "on the oracle's restatement of nanoflann, ")
                       + "queries / step logic / interior-point solve on the oracle's restatement (CasADi + IPOPT are absent)",
-            "kd_build_kind": "reference" if use_ref else "port",
+            "kd_build_kind": "reference" if use_ref else "port", "span_s": round(span, 3), "cgroup_cpu_max": quota,
+            "if_every_core_ran_at_single_process_speed": round(workers / (lone_build + lone_step), 1),
             "all_core_ms_per_step_per_core": round(1e3 * busy / len(res), 3),
             "all_core_kd_build_ms": round(1e3 * float(build.mean()), 3),
             "single_process_ms_per_step": round(1e3 * (lone_build + lone_step), 3),

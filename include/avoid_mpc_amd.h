@@ -218,6 +218,26 @@ int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_
                    const double *d_state_quad, const double *d_pos_x, double *d_ref_path,
                    double *d_u, double *d_x0array, int *d_flags, void *stream);
 
+/* The same control step over a MULTI-FRAME map: mVecQueryVector = [current frame, keyframes ...] (FrameKDMap.cpp:64-74).
+ * Every query follows FrameKDMap::QueryNearest (:322-376): the current frame alone when it holds >= k points and the query
+ * projects into the current image (PtIsInFrame, :215-231), otherwise the k' = min(k, size_f) nearest of every frame merged by
+ * squared distance; GetNearestDistance (:400-427) is the minimum over the frames.  obstacle[f] / edge[f]: the dual KD indices of
+ * frame f, f = 0 the current frame; n_frames <= AMK_MAX_FRAMES; every handle holds the same number of scenes as `mpc`.
+ *   d_Twc [S][16]  mCurFrame.Twc (world <- camera, row-major) per scene; NULL: every query counts as inside the current frame
+ *   cam            camera model of PtIsInFrame: intrinsics ALREADY divided by the resize scale (:21-24), depth_max, and the
+ *                  size of the down-scaled image (mParamWidth / mParamHeight, :106-107)
+ * Remaining arguments as amk_step_batch.  With n_frames = 1 and d_Twc = NULL the results equal amk_step_batch's.            */
+#define AMK_MAX_FRAMES 16
+typedef struct amk_frame_camera {
+    double fx, fy, cx, cy;
+    double depth_max;
+    int width, height;
+} amk_frame_camera;
+int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edge, int n_frames, const double *d_Twc,
+                          const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *params,
+                          const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
+                          double *d_x0array, int *d_flags, void *stream);
+
 /* Same with host buffers (stages through device memory, synchronises); what a single-robot host
  * (S = 1) calls once per control period.                                                         */
 int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *params,

@@ -170,3 +170,143 @@ int stepo_run(void *kd_obs, void *kd_edge, void *mpc, int K, double speed, doubl
     free(obst);
     return 0;
 }
+
+/* ---------------------------------------------------------------- multi-frame map ------------------------------------
+ * FrameKDMap with keyframes: mVecQueryVector = [cur, keyframes...] (AM/src/FrameKDMap.cpp:64-74).  Restated:
+ *   pt_is_in_frame        PtIsInFrame                                     FrameKDMap.cpp:215-231
+ *   mapf_query            QueryNearest (+WithCurFrame, ThreadWorker)      :254-376
+ *   mapf_nearest_distance GetNearestDistance (+worker)                    :378-427
+ *   stepo_run_frames      TASK branch of Step on that map                 AvoidanceStateMachine.cpp:322-355
+ * cam[7] = {fx, fy, cx, cy (already divided by the resize scale, :21-24), depth_max, width, height}; Twc row-major 4x4
+ * (NULL: every point counts as inside the current frame).  The reference sorts the merged candidates with std::sort on
+ * the squared distance alone (:371, FrameKDMap.h:52-54: equal distances in unspecified order); here ties keep the
+ * earlier frame / earlier neighbour -- the rule of the product. */
+static int pt_is_in_frame(const double *p, const double *T, const double *cam) {
+    if (!T) return 1;
+    /* Twc.inverse() * p for a rigid Twc: R'(p - t) */
+    const double dx = p[0] - T[3], dy = p[1] - T[7], dz = p[2] - T[11];
+    const double x = T[0] * dx + T[4] * dy + T[8] * dz;
+    const double y = T[1] * dx + T[5] * dy + T[9] * dz;
+    const double z = T[2] * dx + T[6] * dy + T[10] * dz;
+    if (z > cam[4] || z < 0) return 0;
+    const double u = cam[0] * x / z + cam[2];
+    const double v = cam[1] * y / z + cam[3];
+    if (u < 0 || u >= cam[5] || v < 0 || v >= cam[6]) return 0;
+    return 1;
+}
+
+typedef struct { double pt[3], d; } ptd;
+
+static int mapf_query(void **kds, int F, const double *p, int k, const double *Twc, const double *cam, double pts[][3],
+                      double *d2) {
+    int idx[MAXK];
+    double dd[MAXK];
+    float pf[MAXK * 3];
+    if (kds[0]) {
+        const int first = kdo_size(kds[0]);
+        if (first >= k && pt_is_in_frame(p, Twc, cam)) { /* fast path :339-345 */
+            int cnt = kdo_search(kds[0], p[0], p[1], p[2], k, idx, dd, pf);
+            for (int i = 0; i < cnt; ++i) {
+                pts[i][0] = pf[3 * i]; pts[i][1] = pf[3 * i + 1]; pts[i][2] = pf[3 * i + 2];
+                d2[i] = dd[i];
+            }
+            return cnt;
+        }
+    }
+    ptd all[64 * MAXK];
+    int n = 0;
+    for (int f = 0; f < F; ++f) { /* one worker per frame in the reference, :347-364 */
+        if (!kds[f]) continue;
+        const int size = kdo_size(kds[f]);
+        const int kq = k < size ? k : size; /* :298 */
+        int cnt = kdo_search(kds[f], p[0], p[1], p[2], kq, idx, dd, pf);
+        for (int j = 0; j < cnt; ++j) {
+            all[n].pt[0] = pf[3 * j]; all[n].pt[1] = pf[3 * j + 1]; all[n].pt[2] = pf[3 * j + 2];
+            all[n].d = dd[j];
+            ++n;
+        }
+    }
+    /* stable insertion sort on the distance (:371) */
+    for (int i = 1; i < n; ++i) {
+        ptd t = all[i];
+        int j = i - 1;
+        while (j >= 0 && all[j].d > t.d) { all[j + 1] = all[j]; --j; }
+        all[j + 1] = t;
+    }
+    int cnt = n < k ? n : k; /* :372-375 */
+    for (int i = 0; i < cnt; ++i) {
+        pts[i][0] = all[i].pt[0]; pts[i][1] = all[i].pt[1]; pts[i][2] = all[i].pt[2];
+        d2[i] = all[i].d;
+    }
+    return cnt;
+}
+
+static double mapf_nearest_distance(void **kds, int F, const double *p) {
+    double nearest = DBL_MAX;
+    for (int f = 0; f < F; ++f)
+        if (kds[f] && kdo_size(kds[f]) > 0) { /* :385-387 */
+            int idx[1];
+            double dd[1];
+            float pf[3];
+            int cnt = kdo_search(kds[f], p[0], p[1], p[2], 1, idx, dd, pf);
+            if (cnt > 0 && dd[0] < nearest) nearest = dd[0];
+        }
+    return sqrt(nearest);
+}
+
+int stepo_run_frames(void **kd_obs, void **kd_edge, int F, const double *Twc, const double *cam, void *mpc, int K,
+                     double speed, double T, double safety_distance, int mpc_max_iter, const double *state_quad,
+                     double pos_x, double *ref_path, double *u, double *x0array, int *flags) {
+    const int N = mpco_horizon(mpc);
+    const int nref = 20 + 10 * N + 3 * K * N;
+    double *ref_states = (double *)malloc(sizeof(double) * nref);
+    double *x0 = (double *)calloc((size_t)14 * N, sizeof(double));
+    double *obst = (double *)malloc(sizeof(double) * 3 * K * N);
+    int is_safety = 1, solves = 0, status = -1, iters = 0;
+    memset(u, 0, sizeof(double) * 4);
+    for (int iter = 0; iter < mpc_max_iter; ++iter) {
+        const double *sq = state_quad + 10 * iter;
+        is_safety = 1;
+        {
+            double *p1 = ref_path;
+            double nd = mapf_nearest_distance(kd_obs, F, p1);
+            if (!(nd > safety_distance)) {
+                double ep[1][3], ed[1];
+                int cnt = mapf_query(kd_edge, F, p1, 1, Twc, cam, ep, ed);
+                if (cnt == 0) is_safety = 0;
+                else { p1[0] = ep[0][0]; p1[1] = ep[0][1]; p1[2] = ep[0][2]; }
+            }
+        }
+        int need_replan = 0;
+        for (int i = 0; i < N; ++i) {
+            double pts[MAXK][3], d2[MAXK];
+            int cnt = mapf_query(kd_obs, F, ref_path + 10 * i, K, Twc, cam, pts, d2);
+            for (int j = 0; j < K; ++j) {
+                double *o = obst + 3 * (K * i + j);
+                if (j < cnt) { o[0] = pts[j][0]; o[1] = pts[j][1]; o[2] = pts[j][2]; }
+                else { o[0] = o[1] = o[2] = 10000; }
+            }
+            if (cnt == 0 || sqrt(d2[0]) <= safety_distance) need_replan = 1;
+        }
+        if (!need_replan && iter > 0 && is_safety) break;
+        memcpy(ref_states, sq, sizeof(double) * 10);
+        memcpy(ref_states + 10, ref_path, sizeof(double) * 10 * N);
+        memcpy(ref_states + 10 + 10 * N, obst, sizeof(double) * 3 * K * N);
+        {
+            double *tg = ref_states + 10 + 10 * N + 3 * K * N;
+            memcpy(tg, ref_path + 10 * (N - 1), sizeof(double) * 10);
+            double dX = speed * T - fmax(0., tg[0] - pos_x);
+            dX = fmax(0., dX);
+            tg[0] += dX;
+            tg[1] = 0.;
+        }
+        status = mpco_Solve(mpc, ref_states, u, x0, iter == 0);
+        iters += mpco_last_info(mpc)[1];
+        ++solves;
+        for (int i = 0; i < N; ++i) memcpy(ref_path + 10 * i, x0 + 14 * i, sizeof(double) * 10);
+    }
+    if (x0array) memcpy(x0array, x0, sizeof(double) * 14 * N);
+    if (flags) { flags[0] = is_safety; flags[1] = solves; flags[2] = status; flags[3] = iters; }
+    free(ref_states); free(x0); free(obst);
+    return 0;
+}

@@ -266,6 +266,27 @@ def step_oracle(kd_obs, kd_edge, mpc, prm, state_quad, pos_x, ref_path, want_log
     return dict(u=u, x0array=x0, flags=flags, ref_log=log)
 
 
+def step_oracle_frames(kd_obs_frames, kd_edge_frames, mpc, prm, state_quad, pos_x, ref_path, Twc=None, cam=None):
+    """The control step on a multi-frame map (oracle/step_oracle.c stepo_run_frames).  kd_*_frames: lists of KdHandle, index 0
+    = current frame; Twc 4x4 or None; cam = (fx, fy, cx, cy, depth_max, width, height).  ref_path is updated in place."""
+    lib = load_oracle()
+    lib.stepo_run_frames.restype = C.c_int
+    lib.stepo_run_frames.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_int, _f64p, C.c_double, _f64p, _f64p, _f64p, _i32p]
+    F = len(kd_obs_frames)
+    oa = (C.c_void_p * F)(*[k.h for k in kd_obs_frames]); ea = (C.c_void_p * F)(*[k.h for k in kd_edge_frames])
+    N, K = mpc.N, mpc.K
+    u = np.zeros(4); x0 = np.zeros((N, 14)); flags = np.zeros(4, np.int32)
+    T = np.ascontiguousarray(Twc, np.float64).reshape(-1) if Twc is not None else None
+    cm = np.ascontiguousarray(cam, np.float64) if cam is not None else None
+    sq = np.ascontiguousarray(state_quad, np.float64)
+    lib.stepo_run_frames(oa, ea, F, T.ctypes.data_as(C.c_void_p) if T is not None else None,
+                         cm.ctypes.data_as(C.c_void_p) if cm is not None else None, mpc.h, K, prm.speed, prm.T,
+                         prm.safety_distance, prm.max_iter, sq.reshape(-1), float(pos_x), ref_path.reshape(-1), u,
+                         x0.reshape(-1), flags)
+    return dict(u=u, x0array=x0, flags=flags)
+
+
 # ---- depth image -> cloud (oracle/depth_oracle.c) ------------------------------------------------
 class DepthoParams(C.Structure):
     _fields_ = [("pixel2meter", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),

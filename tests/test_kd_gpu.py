@@ -213,7 +213,8 @@ def test_tie_flags_mark_every_query_whose_indices_may_differ_from_nanoflann(torc
     rng = np.random.default_rng(5)
     clouds = {"random": rng.uniform(-5, 5, (4000, 3)).astype(np.float32)}
     u, v = np.meshgrid(np.arange(64), np.arange(48))
-    depth = (rng.integers(20, 200, (48, 64)) * (100.0 / 200.0)).astype(np.float64)        # byte * (max - min) / 200
+    # byte * (max - min) / 200 with walls at two quantised depths: the points of a wall form a regular lattice
+    depth = np.where(((u // 8 + v // 8) % 2) == 0, 40, 60) * (100.0 / 200.0)
     clouds["quantised"] = np.stack([(u - 32.0) * depth / 32.0, (v - 24.0) * depth / 32.0, depth], -1).reshape(-1, 3).astype(np.float32)
     for name, c in clouds.items():
         t = _oracle.kd_oracle(c)
@@ -239,4 +240,6 @@ def test_tie_flags_mark_every_query_whose_indices_may_differ_from_nanoflann(torc
             print(f"{name} k={k}: flagged {int(fl.sum())}/48, index lists differing from nanoflann {differ}, sets differing {sets_differ}")
             if name == "random":
                 assert fl.sum() == 0 and differ == 0
+            elif k > 1:
+                assert fl.sum() > 0          # the lattice really produces exact ties
             kd.close()

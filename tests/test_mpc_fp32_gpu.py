@@ -68,7 +68,7 @@ def test_fp32_tolerance_against_the_converged_cpu_trajectory(torch_cuda):
     prm = synth.MpcParams(T=1.0, K=8)
     lo = np.array([-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot])
     hi = np.array([prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot])
-    assert np.all(np.isfinite(w32)) and np.all(u32 > lo) and np.all(u32 < hi)   # strictly interior
+    assert np.all(np.isfinite(w32)) and np.all(u32 >= lo) and np.all(u32 <= hi)   # inside the box (fp32 rounds onto it)
     assert np.mean(du <= 1e-2) >= 0.85 and np.median(du) <= 2e-3
     assert abs(rep["dJ_rel_median"]) <= 1e-5
 

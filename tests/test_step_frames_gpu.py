@@ -1,0 +1,71 @@
+"""GPU: the control step over a MULTI-FRAME map (amk_step_batch_frames: current frame + keyframes, PtIsInFrame fast path,
+per-frame k' = min(k, size) merge, minimum distance over the frames; AM/src/FrameKDMap.cpp:215-231,254-427) against the
+oracle's restatement (oracle/step_oracle.c stepo_run_frames).  The frames are slices of one synthetic cloud as a camera
+moving along +x would have seen them, so part of every reference path lies outside the current frustum and obstacles
+behind the camera are remembered only by the keyframes."""
+import numpy as np
+import pytest
+
+from tests import _oracle
+from avoid_mpc_amd import synth
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-6
+
+
+def _frames(sc, n_frames):
+    """frame 0 (current) sees x in [6, 30), keyframes saw [0, 8), [3, 12) ...: overlapping slices."""
+    c, e = sc["cloud"], sc["edge"]
+    spans = [(6.0, 30.0), (0.0, 8.0), (3.0, 12.0), (-1.0, 1.0)][:n_frames]
+    return ([c[(c[:, 0] >= a) & (c[:, 0] < b)] for a, b in spans], [e[(e[:, 0] >= a) & (e[:, 0] < b)] for a, b in spans])
+
+
+@pytest.mark.parametrize("n_frames,with_camera", [(1, False), (3, True), (4, True)])
+def test_multi_frame_step_matches_oracle(n_frames, with_camera):
+    import torch
+    from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import KdBatch, MpcBatch, step_batch, step_batch_frames
+    prm = synth.MpcParams(T=0.66, K=8)
+    S = 12
+    scenes = [synth.make_scene(20000, 900 + i, prm) for i in range(S)]
+    N = prm.N
+    # camera 2 m behind the start, looking along +x (camera z = world x, camera x = -world y, camera y = -world z)
+    Twc = np.array([[0, 0, 1, -2.0], [-1, 0, 0, 0.0], [0, -1, 0, 1.5], [0, 0, 0, 1.0]])
+    cam = (32.0, 32.0, 32.0, 24.0, 6.0, 64, 48)      # depth_max 6 m: the far end of the reference path is out of range
+    kd_o, kd_e, fr = [], [], []
+    for f in range(n_frames):
+        cl = [_frames(sc, n_frames)[0][f] for sc in scenes]; ed = [_frames(sc, n_frames)[1][f] for sc in scenes]
+        fr.append((cl, ed))
+        for lst, out in ((cl, kd_o), (ed, kd_e)):
+            nmax = max(max(len(x) for x in lst), 1)
+            buf = np.zeros((S, nmax, 3), np.float32); cnt = np.zeros(S, np.int32)
+            for s, x in enumerate(lst):
+                buf[s, :len(x)] = x; cnt[s] = len(x)
+            kd = KdBatch(S, nmax); kd.build(torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda()); out.append(kd)
+    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
+    sq = np.stack([_oracle.scene_state_quads(sc, prm) for sc in scenes])
+    ref = torch.from_numpy(np.stack([sc["ref_path"] for sc in scenes])).cuda()
+    pos_x = torch.from_numpy(np.array([sc["pos"][0] for sc in scenes])).cuda()
+    Tw = torch.from_numpy(np.repeat(Twc[None], S, 0).copy()).cuda() if with_camera else None
+    fc = capi.FrameCamera(*cam) if with_camera else None
+    out = step_batch_frames(kd_o, kd_e, mpc, prm, torch.from_numpy(sq).cuda(), pos_x, ref, Twc=Tw, cam=fc)
+    torch.cuda.synchronize()
+    u, x0, flags, rp = out["u"].cpu().numpy(), out["x0array"].cpu().numpy(), out["flags"].cpu().numpy(), ref.cpu().numpy()
+    worst = 0.0
+    for s, sc in enumerate(scenes):
+        ko = [_oracle.kd_oracle(fr[f][0][s]) for f in range(n_frames)]
+        ke = [_oracle.kd_oracle(fr[f][1][s]) for f in range(n_frames)]
+        m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)
+        r_ref = sc["ref_path"].copy()
+        r = _oracle.step_oracle_frames(ko, ke, m, prm, sq[s], sc["pos"][0], r_ref, Twc if with_camera else None,
+                                       cam if with_camera else None)
+        assert np.array_equal(flags[s], r["flags"]), (s, flags[s], r["flags"])
+        worst = max(worst, np.abs(u[s] - r["u"]).max(), np.abs(x0[s] - r["x0array"]).max(), np.abs(rp[s] - r_ref).max())
+    print(f"frames {n_frames}: worst |gpu - oracle| = {worst:.3e}; solves {flags[:, 1].tolist()}")
+    assert worst <= TOL
+    if n_frames == 1:   # one frame, no camera: identical to amk_step_batch
+        mpc1 = MpcBatch(prm.T, prm.dt, prm.K, S); mpc1.configure(prm)
+        ref1 = torch.from_numpy(np.stack([sc["ref_path"] for sc in scenes])).cuda()
+        o1 = step_batch(kd_o[0], kd_e[0], mpc1, prm, torch.from_numpy(sq).cuda(), pos_x, ref1)
+        torch.cuda.synchronize()
+        assert torch.equal(o1["u"], out["u"]) and torch.equal(o1["flags"], out["flags"]) and torch.equal(ref1, ref)
