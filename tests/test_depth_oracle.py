@@ -104,3 +104,33 @@ def test_range_gates_and_interpolation_with_holes():
     assert len(cloud) == 0                         # 1/100 -> float 0.01 < 1e-2 in double? (float(0.01) = 0.00999999977)
     empty, _ = _oracle.depth_oracle(np.zeros((20, 20), np.uint16), prm, np.eye(4))
     assert len(empty) == 0
+
+
+def test_downscaled_inverse_depth_equals_torch_bilinear_interpolate():
+    """Independent pin of the cv::resize restatement (SURVEY.md section 8 f2; VERDICT r1 item 8):
+    torch.nn.functional.interpolate(mode="bilinear", align_corners=False) implements the same half-pixel rule as
+    cv::resize's INTER_LINEAR (source coordinate (d + 0.5) * scale - 0.5, clamped at the borders).  The two differ
+    only in where they round (torch forms the four-tap sum in a different order): <= 2 ulp of the float32 inverse depth
+    when the size ratio is an integer (the reference's scale 10, mpc_parameters.yaml:63).  For a non-integer ratio
+    torch evaluates the source coordinate in float32 where OpenCV (and the oracle) use double before the cast: the tap
+    weights then differ by ~1e-5 and so does the result (bounded here at 1e-4 relative)."""
+    import torch
+    rng = np.random.default_rng(12)
+    for (rows, cols, s, dtype) in ((480, 640, 10.0, np.float32), (120, 160, 4.0, np.uint16), (96, 130, 3.0, np.float32)):
+        depth, p2m = scene(rng, rows, cols, dtype)
+        prm = dict(YAML, resize_scale=s, pixel2meter=p2m)
+        _, small = _oracle.depth_oracle(depth, prm, np.eye(4))
+        d = (depth.astype(np.float32).astype(np.float64) * p2m).astype(np.float32)
+        bad = (d.astype(np.float64) < prm["depth_min"]) | (d.astype(np.float64) > prm["depth_max"])
+        with np.errstate(divide="ignore"):
+            inv = np.where(bad, np.float32(0), (1.0 / d.astype(np.float64)).astype(np.float32)).astype(np.float32)
+        H, W = int(rows / s), int(cols / s)
+        t = torch.nn.functional.interpolate(torch.from_numpy(inv)[None, None], size=(H, W), mode="bilinear",
+                                            align_corners=False)[0, 0].numpy()
+        assert small.shape == t.shape
+        ulp = np.spacing(np.maximum(np.abs(small), np.abs(t)).astype(np.float32))
+        diff = np.abs(small.astype(np.float64) - t.astype(np.float64))
+        if cols / s == int(cols / s) and rows / s == int(rows / s):
+            assert np.all(diff <= 2.0 * ulp + 1e-12), float((diff / np.maximum(ulp, 1e-30)).max())
+        else:
+            assert np.all(diff <= 1e-4 * np.maximum(np.abs(t), 1e-3))
