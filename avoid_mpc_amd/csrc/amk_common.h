@@ -91,7 +91,14 @@ struct amk_kd {
     int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
     amk::DevBuf<unsigned char> flags; // [S][cap] keyframe sweep: 1 = outlier
     amk::DevBuf<int> sweep_cnt;       // [S][2]   {outliers, rebuilt}
-    // staging for the *_host conveniences
+    // staging for the *_host conveniences: a private stream and one pinned host block, so that a single-query
+    // SearchForNearest costs one small H2D copy, one launch, one D2H copy and a wait on THIS stream only (a device-wide
+    // synchronisation would stall every other stream of the process: a ROS node calls this ~100 times per control period)
+    hipStream_t hstream = nullptr;
+    void *hpin = nullptr;
+    size_t hpin_bytes = 0;
+    amk::DevBuf<unsigned char> stage_out;
+    int async_pending = 0;  // a stream-ordered build / sweep was enqueued since the last synchronisation
     amk::DevBuf<float> stage_xyz;
     amk::DevBuf<int> stage_counts;
     amk::DevBuf<double> stage_q, stage_d2;

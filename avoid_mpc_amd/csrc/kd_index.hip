@@ -6,15 +6,16 @@
 //   amk_kd_search  <- KDTreeTwo::SearchForNearest   AM/include/kd_tree_two.h:108-133
 //                     (+ nanoflann findNeighbors    AM/include/nanoflann_two.hpp:1563-1586)
 //
-// Design: the reference asks <= 3*(N+2) ~ 100 queries of a freshly built tree per
-// depth frame.  On a GPU the cheapest exact "index" for that query count is the cloud itself in a
-// scan-friendly layout: build = one streaming pass (NaN-x filter, order-preserving compaction,
-// AoS -> SoA, NaN padding), search = one wavefront per (scene, query group) streaming the SoA cloud
-// with coalesced 16-byte loads, a wave-uniform k-th-best threshold held in scalar registers, a
-// ballot to find the (rare) lanes that beat it and a shuffle-based insertion into a sorted top-k
-// list that lives in lanes 0..k-1.  Only *results* must equal the reference's;
-// the tree shape is free.
+// Design: only the RESULTS of a search must equal the reference's, the
+// tree shape is free.  build = one launch, one 512-thread block per scene, reading the caller's AoS cloud directly:
+// sampled bounding box, histogram pass (which also applies the NaN-x filter by ballot/popcount), scan, scatter of one
+// 16-byte record (x, y, z, cloud index) per point into a bucketed grid (kd_grid.h).  search = one wavefront per
+// (scene, query) walking Chebyshev rings of grid cells with nanoflann's branch-and-bound stop rule.  The streaming scan
+// of index-ordered SoA planes (kd_device.h; the first correct path) is kept as a cross-check (amk__kd_set_mode) and
+// makes its planes on demand.
 #include "kd_grid.h"
+
+#include <cstring>
 
 namespace amk {
 thread_local int g_last_hip_error = 0;
@@ -446,6 +447,7 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
     hipLaunchKernelGGL(amk::kd_grid_build_kernel, dim3(S), dim3(amk::kGridBuildThreads), 0, stream, keyframe->x.p,
                        keyframe->y.p, keyframe->z.p, keyframe->cap, keyframe->size.p, keyframe->bbox.p, keyframe->gpt.p,
                        keyframe->cell_start.p, keyframe->gparams.p);
+    keyframe->async_pending = 1;
     AMK_HIP(hipGetLastError());
     return AMK_OK;
 }
@@ -549,6 +551,8 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
 }
 
 int amk_kd_destroy(amk_kd *kd) {
+    if (kd && kd->hpin) (void)hipHostFree(kd->hpin);
+    if (kd && kd->hstream) (void)hipStreamDestroy(kd->hstream);
     if (!kd) return AMK_ERR_INVALID_ARG;
     delete kd;
     return AMK_OK;
@@ -563,6 +567,7 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
                            point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p, kd->cap / kWave + 2,
                            kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p);
         kd->soa_valid = 0;
+        kd->async_pending = 1;
     }
     AMK_HIP(hipGetLastError());
     return AMK_OK;
@@ -624,7 +629,16 @@ int amk_kd_build_host(amk_kd *kd, const float *h_xyz, int point_stride, long lon
     if (scene_stride < min_stride && kd->n_scenes > 1) return AMK_ERR_INVALID_ARG;
     const size_t tot = (size_t)(kd->n_scenes - 1) * scene_stride + (size_t)min_stride;
     if (kd->stage_xyz.n < tot) AMK_HIP(kd->stage_xyz.alloc(tot > 0 ? tot : 1));
-    if (tot) AMK_HIP(hipMemcpy(kd->stage_xyz.p, h_xyz, tot * sizeof(float), hipMemcpyHostToDevice));
+    if (h_counts) {  // only the points every scene holds (the caller's buffer need not extend to the capacity)
+        for (int s = 0; s < kd->n_scenes; ++s) {
+            if (h_counts[s] < 0 || h_counts[s] > kd->max_points) return AMK_ERR_INVALID_ARG;
+            const size_t nf = (size_t)h_counts[s] * point_stride;
+            if (nf) AMK_HIP(hipMemcpy(kd->stage_xyz.p + (size_t)s * scene_stride, h_xyz + (size_t)s * scene_stride,
+                                      nf * sizeof(float), hipMemcpyHostToDevice));
+        }
+    } else if (tot) {
+        AMK_HIP(hipMemcpy(kd->stage_xyz.p, h_xyz, tot * sizeof(float), hipMemcpyHostToDevice));
+    }
     const int *d_counts = nullptr;
     if (h_counts) {
         if (kd->stage_counts.n < (size_t)kd->n_scenes) AMK_HIP(kd->stage_counts.alloc(kd->n_scenes));
@@ -634,6 +648,7 @@ int amk_kd_build_host(amk_kd *kd, const float *h_xyz, int point_stride, long lon
     int st = amk_kd_build(kd, kd->stage_xyz.p, point_stride, scene_stride, d_counts, nullptr);
     if (st != AMK_OK) return st;
     AMK_HIP(hipDeviceSynchronize());
+    kd->async_pending = 0;
     return AMK_OK;
 }
 
@@ -642,20 +657,36 @@ int amk_kd_search_host(amk_kd *kd, const double *h_queries, int n_queries, int k
     if (!kd || !h_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
     if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
     const size_t rows = (size_t)kd->n_scenes * n_queries;
-    if (kd->stage_q.n < rows * 3) AMK_HIP(kd->stage_q.alloc(rows * 3));
-    if (kd->stage_idx.n < rows * k) AMK_HIP(kd->stage_idx.alloc(rows * k));
-    if (kd->stage_d2.n < rows * k) AMK_HIP(kd->stage_d2.alloc(rows * k));
-    if (kd->stage_pts.n < rows * k * 3) AMK_HIP(kd->stage_pts.alloc(rows * k * 3));
-    if (kd->stage_cnt.n < rows) AMK_HIP(kd->stage_cnt.alloc(rows));
-    AMK_HIP(hipMemcpy(kd->stage_q.p, h_queries, rows * 3 * sizeof(double), hipMemcpyHostToDevice));
-    int st = amk_kd_search(kd, kd->stage_q.p, n_queries, k, kd->stage_idx.p, kd->stage_d2.p, kd->stage_pts.p,
-                           kd->stage_cnt.p, nullptr);
+    // one device block and one pinned host block: [queries | sqdist | indices | counts | pts]
+    const size_t o_q = 0, o_d2 = o_q + rows * 3 * sizeof(double), o_idx = o_d2 + rows * k * sizeof(double),
+                 o_cnt = o_idx + rows * k * sizeof(int), o_pts = o_cnt + rows * sizeof(int),
+                 total = o_pts + rows * k * 3 * sizeof(float);
+    if (!kd->hstream) AMK_HIP(hipStreamCreateWithFlags(&kd->hstream, hipStreamNonBlocking));
+    if (kd->stage_out.n < total) AMK_HIP(kd->stage_out.alloc(total));
+    if (kd->hpin_bytes < total) {
+        if (kd->hpin) (void)hipHostFree(kd->hpin);
+        kd->hpin = nullptr;
+        kd->hpin_bytes = 0;
+        AMK_HIP(hipHostMalloc(&kd->hpin, total, hipHostMallocDefault));
+        kd->hpin_bytes = total;
+    }
+    if (kd->async_pending) {  // a build / sweep enqueued on some other stream: order behind it once
+        AMK_HIP(hipDeviceSynchronize());
+        kd->async_pending = 0;
+    }
+    unsigned char *hp = static_cast<unsigned char *>(kd->hpin), *dp = kd->stage_out.p;
+    memcpy(hp + o_q, h_queries, rows * 3 * sizeof(double));
+    AMK_HIP(hipMemcpyAsync(dp + o_q, hp + o_q, rows * 3 * sizeof(double), hipMemcpyHostToDevice, kd->hstream));
+    int st = amk_kd_search(kd, reinterpret_cast<const double *>(dp + o_q), n_queries, k, reinterpret_cast<int *>(dp + o_idx),
+                           reinterpret_cast<double *>(dp + o_d2), reinterpret_cast<float *>(dp + o_pts),
+                           reinterpret_cast<int *>(dp + o_cnt), kd->hstream);
     if (st != AMK_OK) return st;
-    AMK_HIP(hipDeviceSynchronize());
-    if (h_indices) AMK_HIP(hipMemcpy(h_indices, kd->stage_idx.p, rows * k * sizeof(int), hipMemcpyDeviceToHost));
-    if (h_sqdist) AMK_HIP(hipMemcpy(h_sqdist, kd->stage_d2.p, rows * k * sizeof(double), hipMemcpyDeviceToHost));
-    if (h_pts) AMK_HIP(hipMemcpy(h_pts, kd->stage_pts.p, rows * k * 3 * sizeof(float), hipMemcpyDeviceToHost));
-    if (h_counts) AMK_HIP(hipMemcpy(h_counts, kd->stage_cnt.p, rows * sizeof(int), hipMemcpyDeviceToHost));
+    AMK_HIP(hipMemcpyAsync(hp + o_d2, dp + o_d2, total - o_d2, hipMemcpyDeviceToHost, kd->hstream));
+    AMK_HIP(hipStreamSynchronize(kd->hstream));
+    if (h_indices) memcpy(h_indices, hp + o_idx, rows * k * sizeof(int));
+    if (h_sqdist) memcpy(h_sqdist, hp + o_d2, rows * k * sizeof(double));
+    if (h_pts) memcpy(h_pts, hp + o_pts, rows * k * 3 * sizeof(float));
+    if (h_counts) memcpy(h_counts, hp + o_cnt, rows * sizeof(int));
     return AMK_OK;
 }
 

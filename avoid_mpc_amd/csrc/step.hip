@@ -4,11 +4,13 @@
 // round trip between the dual-KD-tree queries, the packing of P and the solves.
 //
 // Per outer iteration (<= mpc_max_iter):
-//   step_scan_kernel<2>  N K-NN queries at the reference points against the obstacle cloud     (:204-215)
-//   step_scan_kernel<1>  1-NN of reference point 0 against the edge cloud                      (:270)
+//   step_knn_grid_kernel   one launch for both trees: the N K-NN queries at the reference points in the obstacle index
+//                          (:204-215) and the 1-NN of reference point 0 in the edge index (:270), through the bucketed
+//                          indices (step_scan_kernel<5> / <1>: the same through the streaming-scan cross-check path)
 //   step_plan_pack_kernel  PlanWapionts: nearest-obstacle test, snap to the edge point, re-query (:259-281), then
 //                          ProcessWaypoints padding/needReplan, early exit, GetRefStates      (:216-257,333-335)
-//   mpc_solve_kernel     Solve + refill of the reference path                                  (:337-342)
+//   mpc_solve_kernel       Solve + refill of the reference path                                (:337-342)
+// The multi-frame map (keyframes, PtIsInFrame fast path, per-frame merge) is step_frames.hip.
 #include "kd_grid.h"
 #include "mpc_handle.h"
 

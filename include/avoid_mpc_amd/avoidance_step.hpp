@@ -15,6 +15,7 @@ namespace avoid_mpc_amd {
 struct OdomState {  // what the callbacks store (AvoidanceStateMachine.cpp:118-152)
     double pos[3] = {0, 0, 0}, vel[3] = {0, 0, 0}, acc[3] = {0, 0, 0};
     double yaw = 0;
+    double stamp = 0;  // mTimePos: time stamp of the odometry message (seconds)
 };
 
 class AvoidanceTaskStep {
@@ -56,16 +57,20 @@ public:
         l[0] = goalx; l[2] = mHeight; l[4] = mSpeed;
     }
 
-    // One TASK step against the current frame of `map`.  iterTime: assumed duration of one re-plan pass
-    // (the reference measures it with ros::Time::now(), :329,343; the device loop has no host round
-    // trip, so it is a model -- default: decay).  Returns isSafety; u = last solve's control.
+    // One TASK step against the current frame of `map`.  now: ros::Time::now() at the start of the step -- the state is
+    // extrapolated over the AGE of the odometry plus the compute latency, dt = now + decay - mTimePos (:183-184,329-330);
+    // pass now = o.stamp for fresh odometry.  iterTime: assumed duration of one re-plan pass (the reference measures it
+    // with ros::Time::now(), :329,343; the device loop has no host round trip, so it is a model -- default: decay).
+    // Single-frame map only (mVecQueryVector = [cur]): with keyframes in the map use the reference-shaped
+    // FrameKDMap::QueryNearest path or amk_step_batch_frames.  Returns isSafety; u = last solve's control.
     bool Step(FrameKDMap &map, const OdomState &o, std::vector<double> &u, std::vector<std::vector<double>> &x0Array,
-              double iterTime = -1.0) {
+              double iterTime = -1.0, double now = -1.0) {
         const auto &fr = map.CurFrame();
         if (!fr.pointCloud || !fr.edgeCloud) throw std::runtime_error("AvoidanceTaskStep::Step: no frame in the map");
         if (iterTime < 0) iterTime = mDecay;
         std::vector<double> sq((size_t)mMaxIter * 10);
-        for (int i = 0; i < mMaxIter; ++i) CurStateQuad(o, mDecay + i * iterTime, &sq[10 * i]);
+        const double age = now >= 0 ? now - o.stamp : 0.0;
+        for (int i = 0; i < mMaxIter; ++i) CurStateQuad(o, age + mDecay + i * iterTime, &sq[10 * i]);
         amk_step_params p;
         p.speed = mSpeed; p.safety_distance = mSafety; p.mpc_max_iter = mMaxIter; p.reserved = 0;
         u.assign(4, 0.0);

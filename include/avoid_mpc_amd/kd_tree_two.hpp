@@ -87,6 +87,25 @@ public:
             indices.push_back(idx[i]);
         }
     }
+    // Several SearchForNearest calls in ONE device round trip (the reference issues them one at a time: N per re-plan
+    // pass in ProcessWaypoints, AvoidanceStateMachine.cpp:210-215; each single call costs a launch + two small copies,
+    // tens of microseconds -- see INTEGRATION.md).  queries: q[3*i + {0,1,2}], nq <= AMK_MAX_QUERIES.  Results of query i:
+    // out_indices[i], out_sqdist[i] (same contents as `indices` / `squared_distances` after SearchForNearest(q_i, n)).
+    void SearchForNearestBatch(const double *queries, int nq, int n, std::vector<std::vector<int>> &out_indices,
+                               std::vector<std::vector<num_t>> &out_sqdist) {
+        out_indices.assign(nq, {});
+        out_sqdist.assign(nq, {});
+        if (cloud.pts.size() == 0 || n <= 0 || nq <= 0) return;
+        if (n > AMK_MAX_K || nq > AMK_MAX_QUERIES) throw std::runtime_error("KDTreeTwo::SearchForNearestBatch: too many");
+        std::vector<int> idx((size_t)nq * n), cnt(nq);
+        std::vector<double> d2((size_t)nq * n);
+        amk_throw(amk_kd_search_host(kd_, queries, nq, n, idx.data(), d2.data(), nullptr, cnt.data()), "amk_kd_search_host");
+        for (int i = 0; i < nq; ++i)
+            for (int j = 0; j < cnt[i]; ++j) {
+                out_indices[i].push_back(idx[(size_t)i * n + j]);
+                out_sqdist[i].push_back((num_t)d2[(size_t)i * n + j]);
+            }
+    }
     PointCloudTwo<num_t> const &GetPointCloud() { return cloud; }
     std::vector<int> const &GetColors() { return colors; }
     amk_kd *handle() { return kd_; }  // for batched / fused use through the C ABI
@@ -110,9 +129,8 @@ private:
             amk_throw(amk_kd_create(1, capacity_, &kd_), "amk_kd_create");
         }
         static_assert(sizeof(PointXYZ) == 16, "PointXYZ must be 16 bytes (pcl layout)");
-        std::vector<PointXYZ> staged(cloud.pts);
-        staged.resize(capacity_);
-        amk_throw(amk_kd_build_host(kd_, reinterpret_cast<const float *>(staged.data()), 4, 4LL * capacity_, &n),
+        static const PointXYZ none(0, 0, 0);  // (a valid address for an empty cloud; only n points are read)
+        amk_throw(amk_kd_build_host(kd_, reinterpret_cast<const float *>(n ? cloud.pts.data() : &none), 4, 4LL * capacity_, &n),
                   "amk_kd_build_host");
     }
     PointCloudTwo<num_t> cloud;

@@ -59,6 +59,16 @@ int main(int argc, char **argv) {
         wr(o, tree.squared_distances.data(), c);
         for (int j = 0; j < c; ++j) { float p[3] = {tree.closest_pts[j].x, tree.closest_pts[j].y, tree.closest_pts[j].z}; wr(o, p, 3); }
     }
+    {   // 1b. the same queries in one device round trip: identical to the one-at-a-time results
+        std::vector<std::vector<int>> bi; std::vector<std::vector<double>> bd;
+        tree.SearchForNearestBatch(qs.data(), nq, K, bi, bd);
+        int same = 1;
+        for (int i = 0; i < nq; ++i) {
+            tree.SearchForNearest(qs[3 * i], qs[3 * i + 1], qs[3 * i + 2], K);
+            if (bi[i] != tree.indices || bd[i] != tree.squared_distances) same = 0;
+        }
+        wr(o, &same, 1);
+    }
     // 2. FrameKDMap front end, as AvoidanceStateMachine.cpp:214,264,270 does
     FrameKDMap map;
     map.AddVertex(cloud, edge);

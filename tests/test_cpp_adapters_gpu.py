@@ -54,6 +54,7 @@ def test_adapters_match_oracle(tmp_path):
         assert c == len(ia)
         assert np.array_equal(take(np.int32, c), ia) and np.array_equal(take(np.float64, c), da)
         assert np.array_equal(take(np.float32, 3 * c).reshape(-1, 3), pa)
+    assert int(take(np.int32, 1)[0]) == 1                            # 1b. SearchForNearestBatch == one at a time
     for q in qs:                                                     # 2. FrameKDMap
         c = int(take(np.int32, 1)[0]); d2 = take(np.float64, c); nd = take(np.float64, 1)[0]
         ce = int(take(np.int32, 1)[0]); ed2 = take(np.float64, ce)
