@@ -19,3 +19,11 @@ rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_AC
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_WAVES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $OUT/pmc_sq_b -o b -- python bench.py --steps 8 --warmup 2 --streams 1 --no-cpu-baseline --no-parity --steady-steps 0 > /dev/null 2>> $OUT/bench.err
 find $OUT -name "*.csv" -o -name "*.db" | head -40
 tail -3 $OUT/bench.err
+# 5. the collective path on one GPU: bench.py under torch.distributed.run with one rank (RCCL all_gather per step)
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 256 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_torchrun_1rank.json 2>> $OUT/bench.err
+# 6. other BASELINE sizes and launch shapes (not the headline)
+python bench.py --points 200000 --T 1.0 --steps 64 --warmup 4 --streams 8 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_c5size.json 2>> $OUT/bench.err
+python bench.py --points 5000 --T 0.33 --K 3 --steps 512 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_c1size.json 2>> $OUT/bench.err
+python bench.py --steps 64 --warmup 4 --scenes 1 --streams 1 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_single_robot.json 2>> $OUT/bench.err
+python bench.py --steps 32 --warmup 4 --scenes 2048 --streams 1 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_s2048_streams1.json 2>> $OUT/bench.err
+ls $OUT
