@@ -20,7 +20,7 @@ AMK_MPC_DEFAULT_MAX_ITER = 40
 SYMBOLS = [
     "amk_version", "amk_status_string", "amk_last_hip_error", "amk_device_count",
     "amk_kd_create", "amk_kd_destroy", "amk_kd_build", "amk_kd_sizes", "amk_kd_search",
-    "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_keyframe_sweep",
+    "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_set_tie_order", "amk_kd_keyframe_sweep",
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
@@ -89,6 +89,7 @@ def load():
         "amk_kd_sizes": (i, [vp, vp, vp]),
         "amk_kd_search": (i, [vp, vp, i, i, vp, vp, vp, vp, vp]),
         "amk_kd_tie_flags": (i, [vp, vp, i, i, i, vp, vp]),
+        "amk_kd_set_tie_order": (i, [vp, i]),
         "amk_kd_keyframe_sweep": (i, [vp, vp, d, i, vp, vp, vp]),
         "amk_kd_keyframe_sweep_host": (i, [vp, vp, d, i, vp, vp]),
         "amk_kd_points_host": (i, [vp, vp, vp]),

@@ -89,6 +89,12 @@ struct amk_kd {
     amk::DevBuf<int> cell_start;     // [S][kGridMaxCells + 2]
     amk::DevBuf<double> gparams;     // [S][8]
     int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
+    // opt-in "nanoflann tie order" (amk_kd_set_tie_order, kd_exact.h): the reference's own tree, built beside the bucketed index
+    int tie_order = 0;
+    int ex_max_nodes = 0;
+    amk::DevBuf<unsigned> ex_vind, ex_left, ex_right, ex_sa, ex_sb;
+    amk::DevBuf<int> ex_feat, ex_child, ex_nn;
+    amk::DevBuf<double> ex_low, ex_high, ex_nbbox, ex_root;
     amk::DevBuf<unsigned char> flags; // [S][cap] keyframe sweep: 1 = outlier
     amk::DevBuf<int> sweep_cnt;       // [S][2]   {outliers, rebuilt}
     // staging for the *_host conveniences: a private stream and one pinned host block, so that a single-query

@@ -13,7 +13,7 @@
 // (scene, query) walking Chebyshev rings of grid cells with nanoflann's branch-and-bound stop rule.  The streaming scan
 // of index-ordered SoA planes (kd_device.h; the first correct path) is kept as a cross-check (amk__kd_set_mode) and
 // makes its planes on demand.
-#include "kd_grid.h"
+#include "kd_exact.h"
 
 #include <cstring>
 
@@ -300,6 +300,68 @@ __global__ __launch_bounds__(256) void kd_tie_flags_kernel(amk::GridPtrs gpt, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// opt-in nanoflann tie order (kd_exact.h): the reference's own tree beside the bucketed index
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(amk::kExactThreads) void kd_exact_build_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes) {
+    const int s = blockIdx.x;
+    amk::exact_build_scene(ep.scene(s), sizes[s]);
+}
+
+// one THREAD per (scene, query): nanoflann's own traversal.  Overwrites the outputs of the bucketed search (launched
+// before it on the same stream) wherever the tree is available; a scene whose tree is not (node capacity or traversal
+// depth exceeded on pathological data) keeps the bucketed index's answer.
+__global__ __launch_bounds__(64) void kd_exact_search_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes, int n_scenes,
+                                                             const double *__restrict__ queries, int n_queries, int k,
+                                                             int *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                             float *__restrict__ out_pts, int *__restrict__ out_cnt) {
+    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (row >= (size_t)n_scenes * n_queries) return;
+    const int s = (int)(row / n_queries);
+    const amk::ExactTree T = ep.scene(s);
+    const double *qp = queries + row * 3;
+    double rd[AMK_MAX_K];
+    int ri[AMK_MAX_K];
+    const int size = sizes[s];
+    const int got = amk::exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    if (got < 0) return;
+    const int cnt = size < k ? size : (size > k ? k : 0);  // kd_tree_two.h:119-124
+    if (out_cnt) out_cnt[row] = cnt;
+    for (int j = 0; j < k; ++j) {
+        const bool ok = j < cnt && j < got;
+        const int idx = ok ? ri[j] : -1;
+        if (out_idx) out_idx[row * k + j] = idx;
+        if (out_d2) out_d2[row * k + j] = ok ? rd[j] : DBL_MAX;
+        if (out_pts) {
+            float *o = out_pts + (row * k + j) * 3;
+            o[0] = ok ? T.x[idx] : 0.f;
+            o[1] = ok ? T.y[idx] : 0.f;
+            o[2] = ok ? T.z[idx] : 0.f;
+        }
+    }
+}
+
+static amk::ExactPtrs exact_ptrs(amk_kd *kd) { return amk_exact_ptrs(kd); }
+
+// builds the reference's tree of every scene from the index-ordered planes (made on demand from the bucket records)
+static int exact_build(amk_kd *kd, hipStream_t stream) {
+    const size_t S = kd->n_scenes;
+    if (!kd->ex_vind.p) {
+        kd->ex_max_nodes = kd->cap / 2 + 64;  // ~0.29 nodes per point with 10-point leaves; more = pathological data
+        const size_t pc = S * (size_t)kd->cap, nc = S * (size_t)kd->ex_max_nodes;
+        AMK_HIP(kd->ex_vind.alloc(pc)); AMK_HIP(kd->ex_sa.alloc(pc)); AMK_HIP(kd->ex_sb.alloc(pc));
+        AMK_HIP(kd->ex_left.alloc(nc)); AMK_HIP(kd->ex_right.alloc(nc)); AMK_HIP(kd->ex_feat.alloc(nc));
+        AMK_HIP(kd->ex_child.alloc(nc)); AMK_HIP(kd->ex_low.alloc(nc)); AMK_HIP(kd->ex_high.alloc(nc));
+        AMK_HIP(kd->ex_nbbox.alloc(nc * 6)); AMK_HIP(kd->ex_root.alloc(S * 6)); AMK_HIP(kd->ex_nn.alloc(S));
+    }
+    const int st = ensure_soa(kd, stream);
+    if (st != AMK_OK) return st;
+    hipLaunchKernelGGL(kd_exact_build_kernel, dim3(kd->n_scenes), dim3(amk::kExactThreads), 0, stream, exact_ptrs(kd),
+                       kd->size.p);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // keyframe sweep (FrameKDMap::KeyframeThreadWorker, AM/src/FrameKDMap.cpp:462-485)
 // ------------------------------------------------------------------------------------------------
 // one thread per keyframe point: outlier iff its nearest neighbour in the current frame is farther than th
@@ -449,6 +511,7 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
                        keyframe->cell_start.p, keyframe->gparams.p);
     keyframe->async_pending = 1;
     AMK_HIP(hipGetLastError());
+    if (keyframe->tie_order) return exact_build(keyframe, stream);  // (the planes are valid: the sweep compacted them)
     return AMK_OK;
 }
 
@@ -570,6 +633,22 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
         kd->async_pending = 1;
     }
     AMK_HIP(hipGetLastError());
+    if (kd->tie_order) return exact_build(kd, (hipStream_t)stream);
+    return AMK_OK;
+}
+
+// internal (tests): number of nodes of every scene's reference-shaped tree (-1: not available), after synchronising
+int amk__kd_exact_nodes(amk_kd *kd, int *h_nodes) {
+    if (!kd || !h_nodes || !kd->ex_nn.p) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h_nodes, kd->ex_nn.p, sizeof(int) * kd->n_scenes, hipMemcpyDeviceToHost));
+    return AMK_OK;
+}
+
+int amk_kd_set_tie_order(amk_kd *kd, int mode) {
+    if (!kd) return AMK_ERR_INVALID_ARG;
+    if (mode != AMK_TIES_LOWEST_INDEX && mode != AMK_TIES_NANOFLANN) return AMK_ERR_UNSUPPORTED;
+    kd->tie_order = mode;
     return AMK_OK;
 }
 
@@ -590,6 +669,13 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
         hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p,
                            kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts);
         AMK_HIP(hipGetLastError());
+        if (kd->tie_order && kd->ex_vind.p) {  // nanoflann's own traversal where its tree is available
+            const size_t rows = (size_t)kd->n_scenes * n_queries;
+            hipLaunchKernelGGL(kd_exact_search_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+                               exact_ptrs(kd), kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts,
+                               d_counts);
+            AMK_HIP(hipGetLastError());
+        }
         return AMK_OK;
     }
     {   // the streaming scan reads the index-ordered planes

@@ -11,7 +11,7 @@
 //                          ProcessWaypoints padding/needReplan, early exit, GetRefStates      (:216-257,333-335)
 //   mpc_solve_kernel       Solve + refill of the reference path                                (:337-342)
 // The multi-frame map (keyframes, PtIsInFrame fast path, per-frame merge) is step_frames.hip.
-#include "kd_grid.h"
+#include "kd_exact.h"
 #include "mpc_handle.h"
 
 using namespace amk;
@@ -121,8 +121,45 @@ __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridP
     }
 }
 
+// Handles in AMK_TIES_NANOFLANN mode: the same raw results by nanoflann's own traversal of its own tree (kd_exact.h), one
+// THREAD per (scene, query), overwriting what step_knn_grid_kernel wrote wherever the tree is available.  With exact ties
+// (quantised edge clouds) this is what keeps the snapped edge point and the neighbour SET equal to the reference's.
+__global__ __launch_bounds__(64) void step_knn_exact_kernel(ExactPtrs eobs, ExactPtrs eedge, int use_obs, int use_edge,
+                                                            int n_scenes, const double *__restrict__ ref_path, int N, int K,
+                                                            float *__restrict__ knn_pts, double *__restrict__ knn_d2,
+                                                            float *__restrict__ edge_pt, double *__restrict__ edge_d2,
+                                                            const int *__restrict__ done) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int nq = N + 1;
+    if (t >= n_scenes * nq) return;
+    const int s = t / nq, q = t - s * nq;
+    if (done[s]) return;
+    const bool is_edge = q == N;
+    if (is_edge ? !use_edge : !use_obs) return;
+    const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
+    const ExactTree T = is_edge ? eedge.scene(s) : eobs.scene(s);
+    const int k = is_edge ? 1 : K;
+    double rd[AMK_MAX_K];
+    int ri[AMK_MAX_K];
+    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    if (got < 0) return;
+    for (int j = 0; j < k; ++j) {
+        const bool ok = j < got;
+        const float px = ok ? T.x[ri[j]] : 0.f, py = ok ? T.y[ri[j]] : 0.f, pz = ok ? T.z[ri[j]] : 0.f;
+        if (is_edge) {
+            edge_d2[s] = ok ? rd[j] : DBL_MAX;
+            edge_pt[3 * s + 0] = px; edge_pt[3 * s + 1] = py; edge_pt[3 * s + 2] = pz;
+        } else {
+            const size_t row = (size_t)s * N + q;
+            knn_d2[row * K + j] = ok ? rd[j] : DBL_MAX;
+            float *o = knn_pts + (row * K + j) * 3;
+            o[0] = px; o[1] = py; o[2] = pz;
+        }
+    }
+}
+
 // PlanWapionts (:259-281) for reference point 0; called by the one wavefront that owns scene s.
-__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid,
+__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, ExactPtrs eobs, int use_exact,
                                                           const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
@@ -177,6 +214,27 @@ __device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid,
                 o[0] = ok ? nx : 0.f;
                 o[1] = ok ? ny : 0.f;
                 o[2] = ok ? nz : 0.f;
+            }
+            if (use_exact) {  // AMK_TIES_NANOFLANN: the re-query by the reference's own traversal (lane 0), as above
+                __shared__ double xr[AMK_MAX_K];
+                __shared__ int xi[AMK_MAX_K], xgot;
+                const ExactTree T = eobs.scene(s);
+                if (lane == 0) {
+                    double rd[AMK_MAX_K];
+                    int ri[AMK_MAX_K];
+                    const int got = exact_knn_thread(T, ex, ey, ez, K, rd, ri);
+                    xgot = got;
+                    for (int j = 0; j < K && j < got; ++j) { xr[j] = rd[j]; xi[j] = ri[j]; }
+                }
+                __syncthreads();
+                if (xgot >= 0 && lane < K) {
+                    const bool ok = lane < xgot;
+                    knn_d2[(size_t)s * N * K + lane] = ok ? xr[lane] : DBL_MAX;
+                    float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
+                    o[0] = ok ? T.x[xi[lane]] : 0.f;
+                    o[1] = ok ? T.y[xi[lane]] : 0.f;
+                    o[2] = ok ? T.z[xi[lane]] : 0.f;
+                }
             }
             if (lane == 0) {
                 p1[0] = ex;
@@ -236,7 +294,7 @@ __device__ __forceinline__ void pack_scene(int s, const int *__restrict__ sizes_
 // PlanWapionts, then ProcessWaypoints' bookkeeping + GetRefStates, for scene s = blockIdx.x (one wavefront): the
 // second half reads what the first one wrote for this scene only (snapped point, its neighbours, isSafety).
 __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
-    GridPtrs gpt, int use_grid, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+    GridPtrs gpt, int use_grid, ExactPtrs eobs, int use_exact, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
     int cap, const int *__restrict__ sizes_obs, const float *__restrict__ pmax_obs, const int *__restrict__ sizes_edge,
     int N, int K, int nref, int iter, int max_iter, double speed, double T, double safety_distance,
     const double *__restrict__ state_quad, const double *__restrict__ pos_x, double *__restrict__ ref_path,
@@ -245,7 +303,7 @@ __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
     int *__restrict__ flags) {
     const int s = blockIdx.x;
     if (done[s]) return;
-    plan_scene(s, gpt, use_grid, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
+    plan_scene(s, gpt, use_grid, eobs, use_exact, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
                knn_d2, edge_pt, edge_d2, flags);
     __threadfence_block();
     __syncthreads();
@@ -286,12 +344,19 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     }
     const GridPtrs gobs{obstacle->gpt.p, obstacle->cell_start.p, obstacle->gparams.p, obstacle->cap};
     const GridPtrs gedge{edge->gpt.p, edge->cell_start.p, edge->gparams.p, edge->cap};
+    // handles in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build)
+    const int ex_obs = use_grid && obstacle->tie_order && obstacle->ex_vind.p, ex_edge = use_grid && edge->tie_order && edge->ex_vind.p;
+    const ExactPtrs eobs = ex_obs ? amk_exact_ptrs(obstacle) : ExactPtrs{}, eedge = ex_edge ? amk_exact_ptrs(edge) : ExactPtrs{};
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         if (use_grid) {
             TimedLaunch tl(KC_SCAN_OBS, stream);
             hipLaunchKernelGGL(step_knn_grid_kernel, dim3(S8 * ((N + 4) / 4)), dim3(256), 0, stream, gobs, gedge, S,
                                d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
                                mpc->done.p);
+            if (ex_obs || ex_edge)
+                hipLaunchKernelGGL(step_knn_exact_kernel, dim3((S * (N + 1) + 63) / 64), dim3(64), 0, stream, eobs, eedge, ex_obs,
+                                   ex_edge, S, d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p,
+                                   mpc->edge_d2.p, mpc->done.p);
         } else {
         { TimedLaunch tl(KC_SCAN_OBS, stream);
         hipLaunchKernelGGL(step_scan_kernel<5>, dim3(S8 * bps), dim3(wpb * kWave), scan_lds_bytes<5>(wpb), stream,
@@ -303,7 +368,7 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         }
         { TimedLaunch tl(KC_PLAN, stream);
-        hipLaunchKernelGGL(step_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, obstacle->x.p,
+        hipLaunchKernelGGL(step_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, eobs, ex_obs, obstacle->x.p,
                            obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
                            K, mpc->nref, iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
                            d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,

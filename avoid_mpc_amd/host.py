@@ -37,6 +37,10 @@ class KdBatch:
 
     __del__ = close
 
+    def set_tie_order(self, mode):
+        """capi.AMK_TIES_LOWEST_INDEX (default) or capi.AMK_TIES_NANOFLANN; takes effect at the next build."""
+        capi.check(self.lib.amk_kd_set_tie_order(self.h, int(mode)), "amk_kd_set_tie_order")
+
     def build(self, xyz, counts=None, stream=None):
         """InitializeNew: xyz float32 device tensor [S, max_points, 3|4]; counts int32 [S] or None."""
         assert xyz.dtype == torch.float32 and xyz.dim() == 3 and xyz.shape[0] == self.S

@@ -88,6 +88,19 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
 int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int n_queries, int k, int *d_tie_flags,
                      void *stream);
 
+/* Tie ORDER.  AMK_TIES_LOWEST_INDEX (default): equal squared distances order by cloud index.  AMK_TIES_NANOFLANN: the
+ * handle also builds the reference's own tree (divideTree / middleSplit_ / planeSplit, leaf size 10: nanoflann_two.hpp:
+ * 1055-1106,1197-1294, kd_tree_two.h:68) at every amk_kd_build / keyframe rebuild and amk_kd_search answers by nanoflann's
+ * own traversal (searchLevel + KNNResultSet, :1729-1793,219-246): index lists identical to the reference's on ANY cloud,
+ * ties included.  Costs milliseconds per build (level-synchronous, one wavefront per tree node) where the bucketed index
+ * takes a fraction of one: meant for the reference's real frame sizes (<= 3072 points, quantised edge clouds), set it
+ * before amk_kd_build.  amk_step_batch honours it (queries and the edge snap then go through nanoflann's traversal too);
+ * amk_step_batch_frames uses the bucketed indices.  A scene whose tree would exceed the node capacity
+ * (cap / 2 + 64) or a traversal depth of 60 -- pathological data -- keeps the bucketed index's answer.              */
+#define AMK_TIES_LOWEST_INDEX 0
+#define AMK_TIES_NANOFLANN 1
+int amk_kd_set_tie_order(amk_kd *kd, int mode);
+
 /* Keyframe sweep of FrameKDMap::KeyframeThreadWorker (AM/src/FrameKDMap.cpp:462-485), for every scene:
  * for each point of `keyframe` the nearest-neighbour distance in `current` (SearchForNearest(pt, 1));
  * points with sqrt(d2) > th_dist are outliers (a point gets no result, hence is no outlier, when `current`

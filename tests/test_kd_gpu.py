@@ -243,3 +243,58 @@ def test_tie_flags_mark_every_query_whose_indices_may_differ_from_nanoflann(torc
             elif k > 1:
                 assert fl.sum() > 0          # the lattice really produces exact ties
             kd.close()
+
+
+def test_nanoflann_tie_order_mode(torch_cuda, oracle):
+    """amk_kd_set_tie_order(AMK_TIES_NANOFLANN): the handle builds the reference's own tree on the device and answers by
+    nanoflann's own traversal -- index lists (not only distances) identical to the reference on tie-heavy clouds:
+    integer lattice, triplicated points, a quantised two-wall depth lattice, a planar cloud, plus random / tiny / NaN-x
+    clouds; node counts equal the oracle's tree (the oracle is pinned to the reference header, tests/test_kd_oracle.py,
+    and the reference itself is consulted directly when oracle/_ref is present)."""
+    import ctypes as C
+    torch = torch_cuda
+    from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import KdBatch
+    lib = capi.load()
+    rng = np.random.default_rng(8)
+    g = np.stack(np.meshgrid(np.arange(10), np.arange(10), np.arange(10), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    u, v = np.meshgrid(np.arange(64), np.arange(48))
+    depth = np.where(((u // 8 + v // 8) % 2) == 0, 40, 60) * (100.0 / 200.0)
+    lattice = np.stack([(u - 32.0) * depth / 32.0, (v - 24.0) * depth / 32.0, depth], -1).reshape(-1, 3).astype(np.float32)
+    dup = np.repeat(rng.uniform(-1, 1, (300, 3)).astype(np.float32), 3, axis=0)
+    planar = rng.uniform(-3, 3, (2000, 3)).astype(np.float32); planar[:, 2] = 1.0
+    nanx = rng.uniform(-2, 2, (700, 3)).astype(np.float32); nanx[::7, 0] = np.nan
+    clouds = dict(grid=g, lattice=lattice, dup=dup, planar=planar, random=rng.uniform(-5, 5, (5000, 3)).astype(np.float32),
+                  tiny=rng.uniform(-1, 1, (7, 3)).astype(np.float32), nanx=nanx, eleven=rng.uniform(-1, 1, (11, 3)).astype(np.float32))
+    differ_default = 0
+    for name, c in clouds.items():
+        t = _oracle.kd_oracle(c)
+        tr = _oracle.kd_ref(c)
+        pts = c[~np.isnan(c[:, 0])]
+        qs = np.concatenate([pts[rng.integers(0, len(pts), 24)].astype(np.float64),
+                             pts[rng.integers(0, len(pts), 24)].astype(np.float64) + 0.5,
+                             rng.uniform(-6, 6, (16, 3))])
+        kd = KdBatch(1, len(c))
+        assert lib.amk_kd_set_tie_order(kd.h, 1) == 0 and lib.amk_kd_set_tie_order(kd.h, 7) == capi.AMK_ERR_UNSUPPORTED
+        kd.build(torch.from_numpy(c[None].copy()).cuda())
+        nn = np.zeros(1, np.int32)
+        assert lib.amk__kd_exact_nodes(kd.h, nn.ctypes.data_as(C.c_void_p)) == 0
+        lib_o = _oracle.load_oracle(); lib_o.kdo_num_nodes.restype = C.c_int; lib_o.kdo_num_nodes.argtypes = [C.c_void_p]
+        assert nn[0] == lib_o.kdo_num_nodes(t.h), (name, nn[0], lib_o.kdo_num_nodes(t.h))
+        for k in (1, 3, 8, 10):
+            r = kd.search(torch.from_numpy(qs[None].copy()).cuda(), k)
+            torch.cuda.synchronize()
+            idx, d2, cnt = (r[n].cpu().numpy()[0] for n in ("indices", "sqdist", "counts"))
+            pt = r["pts"].cpu().numpy()[0]
+            for i, q in enumerate(qs):
+                ia, da, pa = t.search(q, k)                       # KDTreeTwo::SearchForNearest semantics, traversal tie order
+                assert cnt[i] == len(ia), (name, k, i)
+                assert np.array_equal(idx[i][:cnt[i]], ia), (name, k, i, idx[i], ia)
+                assert np.array_equal(d2[i][:cnt[i]].view(np.int64), da.view(np.int64))
+                assert np.array_equal(pt[i][:cnt[i]], pa)
+                if tr is not None:
+                    ir = tr.search(q, k)[0]
+                    assert np.array_equal(idx[i][:cnt[i]], ir), (name, k, i)
+                differ_default += not np.array_equal(t.bruteforce(q, k)[0][:len(ia)], ia)
+        kd.close()
+    assert differ_default > 50     # the default (lowest-index) policy does differ on these clouds: the mode matters

@@ -20,7 +20,7 @@ def torch_cuda():
     return torch
 
 
-def run_both(torch, scenes, prm, n_steps=1):
+def run_both(torch, scenes, prm, n_steps=1, tie_order=0):
     """scenes: list of dict(cloud, edge, pos, vel, acc, yaw, ref_path).  Returns (gpu, cpu) lists of
     per-step results."""
     from avoid_mpc_amd.host import KdBatch, MpcBatch, step_batch
@@ -33,6 +33,7 @@ def run_both(torch, scenes, prm, n_steps=1):
         cl[s, :len(sc["cloud"])] = sc["cloud"]; cn[s] = len(sc["cloud"])
         ed[s, :len(sc["edge"])] = sc["edge"]; en[s] = len(sc["edge"])
     kd_o, kd_e = KdBatch(S, nmax), KdBatch(S, emax)
+    kd_o.set_tie_order(tie_order); kd_e.set_tie_order(tie_order)
     kd_o.build(torch.from_numpy(cl).cuda(), torch.from_numpy(cn).cuda())
     kd_e.build(torch.from_numpy(ed).cuda(), torch.from_numpy(en).cuda())
     mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
@@ -93,6 +94,45 @@ def test_step_matches_oracle(cfg, n, scenes, torch_cuda):
     gpu, cpu = run_both(torch_cuda, scenes, prm, n_steps=2)    # second step: warm start carried over
     w = compare(gpu, cpu)
     print(f"{cfg}: worst |gpu - oracle| = {w:.3e}; solves/step = {[r['flags'][1] for r in cpu[0]]}")
+
+
+def test_reference_default_problem_size(torch_cuda):
+    """The reference's own default configuration (AM/config/mpc_parameters.yaml:1-2,5,59-63): 640x480 depth / 10 ->
+    <= 3072 points per frame, N = 30 (T = 1.0, dt = 0.033), K = 3 -- BASELINE's configs are scale-ups of this."""
+    prm = synth.MpcParams(T=1.0, K=3)
+    scenes = [synth.make_scene(3072, 700 + i, prm) for i in range(16)]
+    gpu, cpu = run_both(torch_cuda, scenes, prm, n_steps=3)    # three control periods, warm start carried over
+    w = compare(gpu, cpu)
+    print(f"yaml default size: worst |gpu - oracle| = {w:.3e}; solves/step = {[r['flags'][1] for r in cpu[0]]}")
+
+
+def test_step_in_nanoflann_tie_order_on_quantised_clouds(torch_cuda):
+    """Clouds and reference paths on a 0.25 m / 0.125 m lattice: equal squared distances everywhere (the K-th neighbour of a
+    reference point and the nearest edge point are regularly tied), so WHICH point nanoflann keeps decides the problem the
+    solver sees.  With amk_kd_set_tie_order(AMK_TIES_NANOFLANN) on both handles the fused step -- first queries, the edge
+    snap and its re-query -- follows the reference's traversal and matches the oracle's step (which searches the oracle's
+    nanoflann-shaped tree) to the usual tolerance; the default lowest-index policy picks other members of the ties."""
+    prm = synth.MpcParams(T=1.0, K=3)
+    scenes = []
+    for i in range(16):
+        sc = synth.make_scene(3072, 1500 + i, prm)
+        sc["cloud"] = (np.round(sc["cloud"] * 4) / 4).astype(np.float32)
+        sc["edge"] = (np.round(sc["edge"] * 4) / 4).astype(np.float32)
+        sc["ref_path"] = sc["ref_path"].copy(); sc["ref_path"][:, :3] = np.round(sc["ref_path"][:, :3] * 8) / 8
+        if i % 2:   # reference point 0 within the safety distance of an obstacle -> snap to a (tied) nearest edge point
+            sc["cloud"] = np.concatenate([sc["cloud"], (sc["ref_path"][0, :3] + [0.125, 0, 0])[None].astype(np.float32)])
+            e0 = sc["ref_path"][0, :3]
+            ring = np.float32([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]]) * 0.5 + e0
+            sc["edge"] = np.concatenate([sc["edge"], ring.astype(np.float32)])
+        scenes.append(sc)
+    gpu, cpu = run_both(torch_cuda, scenes, prm, n_steps=2, tie_order=1)
+    w = compare(gpu, cpu)
+    gpu0, _ = run_both(torch_cuda, scenes, prm, n_steps=1, tie_order=0)
+    differ = sum(np.abs(gpu0[0]["u"][s] - cpu[0][s]["u"]).max() > 1e-6 or
+                 np.abs(gpu0[0]["ref_path"][s] - cpu[0][s]["ref_path"]).max() > 0 for s in range(len(scenes)))
+    print(f"quantised clouds, nanoflann tie order: worst |gpu - oracle| = {w:.3e}; "
+          f"default tie policy differs from the reference on {differ}/{len(scenes)} scenes")
+    assert differ >= 1      # the mode is what makes these scenes agree
 
 
 def test_full_batch_c3_and_a_c4_shard(torch_cuda):
