@@ -1,6 +1,7 @@
 // Host-side handle of a batch of ObstacleAvoidanceMPC objects (AM/include/HighLvlMpc.h:4-33) and the
 // device workspace of the fused control step.  Shared by mpc_solve.hip and step.hip.
 #pragma once
+#include <vector>
 #include "mpc_device.h"
 
 struct amk_mpc {
@@ -31,6 +32,8 @@ struct amk_mpc {
     int mf_frames = 0;
     amk::DevBuf<float> mf_knn_pts, mf_edge_pt;    // [F][S][N][K][3], [F][S][3]
     amk::DevBuf<double> mf_knn_d2, mf_edge_d2;    // [F][S][N][K],    [F][S]
+    amk::DevBuf<char> mf_exact;                   // step_frames.hip: FrameExact, when a frame is in AMK_TIES_NANOFLANN mode
+    std::vector<char> mf_exact_host;
     // staging for amk_step_batch_host
     amk::DevBuf<double> sh_sq, sh_posx, sh_ref, sh_u, sh_x0;
     amk::DevBuf<int> sh_flags;

@@ -17,7 +17,9 @@
 //                                 (snap to the nearest edge point over the frames, re-query), fast path / merge per
 //                                 reference point, padding, needReplan, early exit, GetRefStates
 //   mpc_solve_kernel              Solve + refill of the reference path (mpc_solve.hip)
-#include "kd_grid.h"
+// Frames whose handles are in AMK_TIES_NANOFLANN mode are queried by nanoflann's own traversal of its own tree
+// (kd_exact.h): step_knn_frames_exact_kernel overwrites the raw results, the snap re-query follows suit.
+#include "kd_exact.h"
 #include "mpc_handle.h"
 
 using namespace amk;
@@ -35,6 +37,11 @@ struct FrameBufs {  // per-frame raw query results, frame-major
     double *knn_d2;   // [F][S][N][K]
     float *edge_pt;   // [F][S][3]
     double *edge_d2;  // [F][S]
+};
+
+struct FrameExact {  // lives in device memory (too large for the kernel argument segment next to FrameSet)
+    ExactPtrs obs[AMK_MAX_FRAMES], edge[AMK_MAX_FRAMES];
+    int use_obs[AMK_MAX_FRAMES], use_edge[AMK_MAX_FRAMES];
 };
 
 __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n_scenes, const double *__restrict__ ref_path,
@@ -76,6 +83,41 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     }
 }
 
+// one THREAD per (frame, scene, query): the same raw results by the reference's traversal, where the frame has its tree
+__global__ __launch_bounds__(64) void step_knn_frames_exact_kernel(const FrameExact *__restrict__ fe, int n_scenes,
+                                                                   const double *__restrict__ ref_path, int N, int K,
+                                                                   FrameBufs fb, const int *__restrict__ done) {
+    const int f = blockIdx.y;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int nq = N + 1;
+    if (t >= n_scenes * nq) return;
+    const int s = t / nq, q = t - s * nq;
+    if (done[s]) return;
+    const bool is_edge = q == N;
+    if (is_edge ? !fe->use_edge[f] : !fe->use_obs[f]) return;
+    const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
+    const ExactTree T = is_edge ? fe->edge[f].scene(s) : fe->obs[f].scene(s);
+    const int k = is_edge ? 1 : K;
+    double rd[AMK_MAX_K];
+    int ri[AMK_MAX_K];
+    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    if (got < 0) return;
+    for (int j = 0; j < k; ++j) {
+        const bool ok = j < got;
+        const float px = ok ? T.x[ri[j]] : 0.f, py = ok ? T.y[ri[j]] : 0.f, pz = ok ? T.z[ri[j]] : 0.f;
+        if (is_edge) {
+            const size_t o = (size_t)f * n_scenes + s;
+            fb.edge_d2[o] = ok ? rd[j] : DBL_MAX;
+            fb.edge_pt[3 * o + 0] = px; fb.edge_pt[3 * o + 1] = py; fb.edge_pt[3 * o + 2] = pz;
+        } else {
+            const size_t row = ((size_t)f * n_scenes + s) * N + q;
+            fb.knn_d2[row * K + j] = ok ? rd[j] : DBL_MAX;
+            float *o = fb.knn_pts + (row * K + j) * 3;
+            o[0] = px; o[1] = py; o[2] = pz;
+        }
+    }
+}
+
 // PtIsInFrame (FrameKDMap.cpp:215-231): Twc rigid, its inverse is [R' | -R' t]
 __device__ __forceinline__ bool pt_in_frame(const double *__restrict__ T, const amk_frame_camera &cam, double px, double py,
                                             double pz) {
@@ -102,7 +144,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 constexpr int kMaxCandPerLane = (AMK_MAX_FRAMES * AMK_MAX_K + 63) / 64;
 
 __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
-    FrameSet fs, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
+    FrameSet fs, const FrameExact *__restrict__ fe, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
     int max_iter, double speed, double T, double safety_distance, const double *__restrict__ state_quad,
     const double *__restrict__ pos_x, double *__restrict__ ref_path, float *__restrict__ knn_pts,
     double *__restrict__ knn_d2, double *__restrict__ ref_states, int *__restrict__ done, int *__restrict__ flags) {
@@ -151,6 +193,27 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
                     o[0] = ok ? rec.x : 0.f; o[1] = ok ? rec.y : 0.f; o[2] = ok ? rec.z : 0.f;
                 }
                 __syncthreads();
+                if (fe && fe->use_obs[f]) {  // AMK_TIES_NANOFLANN frame: the re-query by the reference's traversal (lane 0)
+                    __shared__ double xr[AMK_MAX_K];
+                    __shared__ int xi[AMK_MAX_K], xgot;
+                    const ExactTree T = fe->obs[f].scene(s);
+                    if (lane == 0) {
+                        double rd[AMK_MAX_K];
+                        int ri[AMK_MAX_K];
+                        const int got = exact_knn_thread(T, ex, ey, ez, K, rd, ri);
+                        xgot = got;
+                        for (int j = 0; j < K && j < got; ++j) { xr[j] = rd[j]; xi[j] = ri[j]; }
+                    }
+                    __syncthreads();
+                    if (xgot >= 0 && lane < K) {
+                        const bool ok = lane < xgot;
+                        const size_t row = ((size_t)f * S + s) * N;
+                        fb.knn_d2[row * K + lane] = ok ? xr[lane] : DBL_MAX;
+                        float *o = fb.knn_pts + (row * K + lane) * 3;
+                        o[0] = ok ? T.x[xi[lane]] : 0.f; o[1] = ok ? T.y[xi[lane]] : 0.f; o[2] = ok ? T.z[xi[lane]] : 0.f;
+                    }
+                    __syncthreads();
+                }
             }
             if (lane == 0) { rp[0] = ex; rp[1] = ey; rp[2] = ez; }
         }
@@ -295,6 +358,25 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         mpc->mf_frames = F;
     }
     const FrameBufs fb{mpc->mf_knn_pts.p, mpc->mf_knn_d2.p, mpc->mf_edge_pt.p, mpc->mf_edge_d2.p};
+    // frames in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build / amk_kd_push_keyframe)
+    bool any_exact = false;
+    FrameExact *fe_dev = nullptr;
+    {
+        mpc->mf_exact_host.assign(sizeof(FrameExact), 0);
+        FrameExact *h = reinterpret_cast<FrameExact *>(mpc->mf_exact_host.data());
+        for (int f = 0; f < F; ++f) {
+            h->use_obs[f] = obstacle[f]->tie_order && obstacle[f]->ex_vind.p;
+            h->use_edge[f] = edge[f]->tie_order && edge[f]->ex_vind.p;
+            if (h->use_obs[f]) h->obs[f] = amk_exact_ptrs(obstacle[f]);
+            if (h->use_edge[f]) h->edge[f] = amk_exact_ptrs(edge[f]);
+            any_exact |= h->use_obs[f] || h->use_edge[f];
+        }
+        if (any_exact) {
+            if (!mpc->mf_exact.p) AMK_HIP(mpc->mf_exact.alloc(sizeof(FrameExact)));
+            AMK_HIP(hipMemcpyAsync(mpc->mf_exact.p, h, sizeof(FrameExact), hipMemcpyHostToDevice, stream));
+            fe_dev = reinterpret_cast<FrameExact *>(mpc->mf_exact.p);
+        }
+    }
     amk_frame_camera c{};
     if (cam) c = *cam;
     hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
@@ -302,7 +384,10 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path, N, K,
                            fb, mpc->done.p);
-        hipLaunchKernelGGL(step_merge_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, fs, fb, S, d_Twc, c, N, K, mpc->nref,
+        if (any_exact)
+            hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 63) / 64, F), dim3(64), 0, stream, fe_dev, S,
+                               d_ref_path, N, K, fb, mpc->done.p);
+        hipLaunchKernelGGL(step_merge_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
                            iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
         AMK_HIP(hipGetLastError());

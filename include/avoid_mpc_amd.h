@@ -94,8 +94,8 @@ int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int 
  * own traversal (searchLevel + KNNResultSet, :1729-1793,219-246): index lists identical to the reference's on ANY cloud,
  * ties included.  Costs milliseconds per build (level-synchronous, one wavefront per tree node) where the bucketed index
  * takes a fraction of one: meant for the reference's real frame sizes (<= 3072 points, quantised edge clouds), set it
- * before amk_kd_build.  amk_step_batch honours it (queries and the edge snap then go through nanoflann's traversal too);
- * amk_step_batch_frames uses the bucketed indices.  A scene whose tree would exceed the node capacity
+ * before amk_kd_build.  amk_step_batch and amk_step_batch_frames honour it (queries and the edge snap's
+ * re-query then go through nanoflann's traversal too).  A scene whose tree would exceed the node capacity
  * (cap / 2 + 64) or a traversal depth of 60 -- pathological data -- keeps the bucketed index's answer.              */
 #define AMK_TIES_LOWEST_INDEX 0
 #define AMK_TIES_NANOFLANN 1

@@ -57,6 +57,13 @@ public:
     template <class CloudPtr>
     void AddToKDTree(CloudPtr const &xyz_cloud_new) { Initialize(xyz_cloud_new, false); }
     void Clear() { cloud.pts.clear(); }
+    // Not in the reference: true -> later (re)builds also construct nanoflann's own tree on the device and searches
+    // follow its traversal, so that `indices` equal the reference's on clouds with equal squared distances too
+    // (amk_kd_set_tie_order, AMK_TIES_NANOFLANN); default: equal distances ordered by index.
+    void SetNanoflannTieOrder(bool on) {
+        tie_order_ = on ? AMK_TIES_NANOFLANN : AMK_TIES_LOWEST_INDEX;
+        if (kd_) amk_throw(amk_kd_set_tie_order(kd_, tie_order_), "amk_kd_set_tie_order");
+    }
 
     template <class CloudPtr>
     void Initialize(CloudPtr const &xyz_cloud_new, bool clear) {  // kd_tree_two.h:88-106
@@ -127,6 +134,7 @@ private:
             kd_ = nullptr;
             capacity_ = n > 1024 ? n + n / 2 : 1024;
             amk_throw(amk_kd_create(1, capacity_, &kd_), "amk_kd_create");
+            amk_throw(amk_kd_set_tie_order(kd_, tie_order_), "amk_kd_set_tie_order");
         }
         static_assert(sizeof(PointXYZ) == 16, "PointXYZ must be 16 bytes (pcl layout)");
         static const PointXYZ none(0, 0, 0);  // (a valid address for an empty cloud; only n points are read)
@@ -136,6 +144,7 @@ private:
     PointCloudTwo<num_t> cloud;
     amk_kd *kd_ = nullptr;
     int capacity_ = 0;
+    int tie_order_ = AMK_TIES_LOWEST_INDEX;
 };
 
 }  // namespace avoid_mpc_amd

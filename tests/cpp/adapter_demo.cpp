@@ -4,6 +4,7 @@
 //   adapter_demo <in.bin> <out.bin>
 // in.bin : int32 n, ne, N, K, max_iter, nq ; double params[6+25+4+4+5] ; float cloud[n*3], edge[ne*3] ;
 //          double odom[10] (pos vel acc yaw) ; double ref_path[N*10] ; double queries[nq*3]
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -68,6 +69,21 @@ int main(int argc, char **argv) {
             if (bi[i] != tree.indices || bd[i] != tree.squared_distances) same = 0;
         }
         wr(o, &same, 1);
+    }
+    {   // 1c. SetNanoflannTieOrder: cloud and queries on a lattice (equal distances are the rule); indices as the reference's
+        auto qc = std::make_shared<Cloud>();
+        for (int i = 0; i < n; ++i)
+            qc->points.emplace_back(std::round(cl[3 * i] * 4) / 4, std::round(cl[3 * i + 1] * 4) / 4, std::round(cl[3 * i + 2] * 4) / 4);
+        KDTreeTwo<double> lat;
+        lat.SetNanoflannTieOrder(true);
+        lat.InitializeNew(qc);
+        for (int i = 0; i < nq; ++i) {
+            lat.SearchForNearest(std::round(qs[3 * i] * 8) / 8, std::round(qs[3 * i + 1] * 8) / 8, std::round(qs[3 * i + 2] * 8) / 8, K);
+            int c = (int)lat.indices.size();
+            wr(o, &c, 1);
+            wr(o, lat.indices.data(), c);
+            wr(o, lat.squared_distances.data(), c);
+        }
     }
     // 2. FrameKDMap front end, as AvoidanceStateMachine.cpp:214,264,270 does
     FrameKDMap map;

@@ -55,6 +55,15 @@ def test_adapters_match_oracle(tmp_path):
         assert np.array_equal(take(np.int32, c), ia) and np.array_equal(take(np.float64, c), da)
         assert np.array_equal(take(np.float32, 3 * c).reshape(-1, 3), pa)
     assert int(take(np.int32, 1)[0]) == 1                            # 1b. SearchForNearestBatch == one at a time
+    lat = _oracle.kd_oracle((np.round(sc["cloud"] * 4) / 4).astype(np.float32))   # 1c. nanoflann tie order on a lattice
+    tied = 0
+    for q in qs:
+        c = int(take(np.int32, 1)[0])
+        ia, da, _ = lat.search(np.round(q * 8) / 8, K)
+        assert c == len(ia)
+        assert np.array_equal(take(np.int32, c), ia) and np.array_equal(take(np.float64, c), da)
+        tied += len(np.unique(lat.search(np.round(q * 8) / 8, K + 1)[1])) < K + 1
+    assert tied >= 4                                                 # these queries do have equidistant neighbours
     for q in qs:                                                     # 2. FrameKDMap
         c = int(take(np.int32, 1)[0]); d2 = take(np.float64, c); nd = take(np.float64, 1)[0]
         ce = int(take(np.int32, 1)[0]); ed2 = take(np.float64, ce)

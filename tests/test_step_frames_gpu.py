@@ -20,14 +20,23 @@ def _frames(sc, n_frames):
     return ([c[(c[:, 0] >= a) & (c[:, 0] < b)] for a, b in spans], [e[(e[:, 0] >= a) & (e[:, 0] < b)] for a, b in spans])
 
 
-@pytest.mark.parametrize("n_frames,with_camera", [(1, False), (3, True), (4, True)])
-def test_multi_frame_step_matches_oracle(n_frames, with_camera):
+@pytest.mark.parametrize("n_frames,with_camera,quantised", [(1, False, False), (3, True, False), (4, True, False),
+                                                            (3, True, True)])
+def test_multi_frame_step_matches_oracle(n_frames, with_camera, quantised):
+    """quantised: clouds on a 0.25 m lattice and reference paths on a 0.125 m lattice (equal squared distances are the
+    rule), every frame's handles in AMK_TIES_NANOFLANN mode -- the per-frame results then follow the reference's traversal
+    and the step still matches the oracle, whose per-frame trees are nanoflann-shaped."""
     import torch
     from avoid_mpc_amd import capi
     from avoid_mpc_amd.host import KdBatch, MpcBatch, step_batch, step_batch_frames
     prm = synth.MpcParams(T=0.66, K=8)
     S = 12
     scenes = [synth.make_scene(20000, 900 + i, prm) for i in range(S)]
+    if quantised:
+        for sc in scenes:
+            sc["cloud"] = (np.round(sc["cloud"] * 4) / 4).astype(np.float32)
+            sc["edge"] = (np.round(sc["edge"] * 4) / 4).astype(np.float32)
+            sc["ref_path"] = sc["ref_path"].copy(); sc["ref_path"][:, :3] = np.round(sc["ref_path"][:, :3] * 8) / 8
     N = prm.N
     # camera 2 m behind the start, looking along +x (camera z = world x, camera x = -world y, camera y = -world z)
     Twc = np.array([[0, 0, 1, -2.0], [-1, 0, 0, 0.0], [0, -1, 0, 1.5], [0, 0, 0, 1.0]])
@@ -41,7 +50,7 @@ def test_multi_frame_step_matches_oracle(n_frames, with_camera):
             buf = np.zeros((S, nmax, 3), np.float32); cnt = np.zeros(S, np.int32)
             for s, x in enumerate(lst):
                 buf[s, :len(x)] = x; cnt[s] = len(x)
-            kd = KdBatch(S, nmax); kd.build(torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda()); out.append(kd)
+            kd = KdBatch(S, nmax); kd.set_tie_order(1 if quantised else 0); kd.build(torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda()); out.append(kd)
     mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
     sq = np.stack([_oracle.scene_state_quads(sc, prm) for sc in scenes])
     ref = torch.from_numpy(np.stack([sc["ref_path"] for sc in scenes])).cuda()
