@@ -26,7 +26,7 @@ namespace amk {
 
 constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
 constexpr int kExactThreads = 256;  // 4 wavefronts per scene
-constexpr int kExactMaxDepth = 60;  // traversal stack; deeper trees (pathological data) fall back to the bucketed index
+constexpr int kExactMaxDepth = 48;  // traversal stack (one frame per level); deeper trees fall back to the bucketed index
 
 struct ExactTree {  // one scene
     const float *x, *y, *z;  // index-ordered planes of the NaN-x-filtered cloud
@@ -238,10 +238,24 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree &T, int n) {
     if (tid == 0) *T.n_nodes = overflow ? -1 : n_nodes_lds;
 }
 
+// The traversal's stack: one frame per tree level -- either "the other child of this node is still to be considered"
+// (kind 0: node, cut dimension, cut distance, mindist at the node) or, once that child has been entered, "restore
+// dists[idx]" (kind 1, same slot).  Storage is the caller's: private arrays for the thread-per-query kernels (scratch
+// memory), LDS for the single-lane re-query inside the plan kernels.
+struct ExactStack {
+    int *node, *ik;  // ik = idx | kind << 2
+    double *a, *b;   // a: cut distance (kind 0) / saved dists[idx] (kind 1); b: mindist at the node
+};
+struct ExactStackStorage {  // kExactMaxDepth frames
+    int node[kExactMaxDepth], ik[kExactMaxDepth];
+    double a[kExactMaxDepth], b[kExactMaxDepth];
+    __device__ __forceinline__ ExactStack view() { return ExactStack{node, ik, a, b}; }
+};
+
 // findNeighbors for one query by ONE thread, exactly nanoflann's traversal.  rd / ri: the KNNResultSet arrays (k
 // entries).  Returns the number of results (min(k, size)), or -1 when the tree is deeper than the stack (fallback).
 __device__ __forceinline__ int exact_knn_thread(const ExactTree &T, double qx, double qy, double qz, int k, double *rd,
-                                                int *ri) {
+                                                int *ri, const ExactStack st) {
     const int nn = *T.n_nodes;
     if (nn <= 0) return nn < 0 ? -1 : 0;
     const double q[3] = {qx, qy, qz};
@@ -255,23 +269,22 @@ __device__ __forceinline__ int exact_knn_thread(const ExactTree &T, double qx, d
         if (q[d] < blo) { dists[d] = (q[d] - blo) * (q[d] - blo); mind += dists[d]; }
         if (q[d] > bhi) { dists[d] = (q[d] - bhi) * (q[d] - bhi); mind += dists[d]; }
     }
-    // explicit stack of the recursion of searchLevel (:1729-1793): a frame is either "the other child of a node is
-    // still to be considered" (kind 0) or "restore dists[idx]" (kind 1)
-    int st_node[2 * kExactMaxDepth], st_idx[2 * kExactMaxDepth];
-    unsigned char st_kind[2 * kExactMaxDepth];
-    double st_a[2 * kExactMaxDepth], st_b[2 * kExactMaxDepth];
-    int sp = 0, node = 0;
+    auto set_dist = [&](int idx, double v) {  // dists[] stays in registers: no dynamic indexing
+        dists[0] = idx == 0 ? v : dists[0];
+        dists[1] = idx == 1 ? v : dists[1];
+        dists[2] = idx == 2 ? v : dists[2];
+    };
+    int sp = 0, node = 0;  // explicit stack of the recursion of searchLevel (:1729-1793)
     for (;;) {
-        while (T.feat[node] >= 0) {  // descend along the best children
-            const int idx = T.feat[node];
-            const double val = q[idx];
+        for (int idx = T.feat[node]; idx >= 0; idx = T.feat[node]) {  // descend along the best children
+            const double val = idx == 0 ? qx : (idx == 1 ? qy : qz);
             const double diff1 = val - T.low[node], diff2 = val - T.high[node];
             int best, other;
             double cut;
             if ((diff1 + diff2) < 0) { best = T.child[node]; other = best + 1; cut = diff2 * diff2; }
             else { other = T.child[node]; best = other + 1; cut = diff1 * diff1; }
-            if (sp >= 2 * kExactMaxDepth - 2) return -1;
-            st_kind[sp] = 0; st_node[sp] = other; st_idx[sp] = idx; st_a[sp] = cut; st_b[sp] = mind;
+            if (sp >= kExactMaxDepth) return -1;
+            st.node[sp] = other; st.ik[sp] = idx; st.a[sp] = cut; st.b[sp] = mind;
             ++sp;
             node = best;
         }
@@ -298,21 +311,19 @@ __device__ __forceinline__ int exact_knn_thread(const ExactTree &T, double qx, d
         bool go = false;
         while (sp > 0) {  // unwind
             --sp;
-            if (st_kind[sp] == 1) { dists[st_idx[sp]] = st_a[sp]; continue; }
-            const int idx = st_idx[sp];
-            const double cut = st_a[sp], dst = dists[idx];
-            const double m2 = st_b[sp] + cut - dst;
-            dists[idx] = cut;
+            const int ik = st.ik[sp], idx = ik & 3;
+            if (ik >> 2) { set_dist(idx, st.a[sp]); continue; }  // kind 1: dists[idx] = dst (:1791)
+            const double cut = st.a[sp], dst = idx == 0 ? dists[0] : (idx == 1 ? dists[1] : dists[2]);
+            const double m2 = st.b[sp] + cut - dst;
             if (m2 * 1.0f <= rd[k - 1]) {  // (epsError = 1 + eps, eps = 0: :1572,1780)
-                const int other = st_node[sp];
-                st_kind[sp] = 1; st_a[sp] = dst;  // dists[idx] = dst once the other child returns (:1791)
+                set_dist(idx, cut);
+                node = st.node[sp];
+                st.ik[sp] = idx | 4; st.a[sp] = dst;  // restore once the other child returns
                 ++sp;
-                node = other;
                 mind = m2;
                 go = true;
                 break;
             }
-            dists[idx] = dst;
         }
         if (!go) break;
     }

@@ -322,7 +322,8 @@ __global__ __launch_bounds__(64) void kd_exact_search_kernel(amk::ExactPtrs ep, 
     double rd[AMK_MAX_K];
     int ri[AMK_MAX_K];
     const int size = sizes[s];
-    const int got = amk::exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    amk::ExactStackStorage stack;
+    const int got = amk::exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
     if (got < 0) return;
     const int cnt = size < k ? size : (size > k ? k : 0);  // kd_tree_two.h:119-124
     if (out_cnt) out_cnt[row] = cnt;

@@ -141,7 +141,8 @@ __global__ __launch_bounds__(64) void step_knn_exact_kernel(ExactPtrs eobs, Exac
     const int k = is_edge ? 1 : K;
     double rd[AMK_MAX_K];
     int ri[AMK_MAX_K];
-    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    ExactStackStorage stack;
+    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
     if (got < 0) return;
     for (int j = 0; j < k; ++j) {
         const bool ok = j < got;
@@ -159,7 +160,8 @@ __global__ __launch_bounds__(64) void step_knn_exact_kernel(ExactPtrs eobs, Exac
 }
 
 // PlanWapionts (:259-281) for reference point 0; called by the one wavefront that owns scene s.
-__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, ExactPtrs eobs, int use_exact,
+template <bool EXACT>
+__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, ExactPtrs eobs,
                                                           const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
@@ -215,17 +217,12 @@ __device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, Ex
                 o[1] = ok ? ny : 0.f;
                 o[2] = ok ? nz : 0.f;
             }
-            if (use_exact) {  // AMK_TIES_NANOFLANN: the re-query by the reference's own traversal (lane 0), as above
+            if (EXACT) {  // AMK_TIES_NANOFLANN: the re-query by the reference's own traversal (lane 0), as above
                 __shared__ double xr[AMK_MAX_K];
                 __shared__ int xi[AMK_MAX_K], xgot;
+                __shared__ ExactStackStorage xstack;  // LDS, not scratch: one lane walks the tree
                 const ExactTree T = eobs.scene(s);
-                if (lane == 0) {
-                    double rd[AMK_MAX_K];
-                    int ri[AMK_MAX_K];
-                    const int got = exact_knn_thread(T, ex, ey, ez, K, rd, ri);
-                    xgot = got;
-                    for (int j = 0; j < K && j < got; ++j) { xr[j] = rd[j]; xi[j] = ri[j]; }
-                }
+                if (lane == 0) xgot = exact_knn_thread(T, ex, ey, ez, K, xr, xi, xstack.view());
                 __syncthreads();
                 if (xgot >= 0 && lane < K) {
                     const bool ok = lane < xgot;
@@ -293,8 +290,12 @@ __device__ __forceinline__ void pack_scene(int s, const int *__restrict__ sizes_
 
 // PlanWapionts, then ProcessWaypoints' bookkeeping + GetRefStates, for scene s = blockIdx.x (one wavefront): the
 // second half reads what the first one wrote for this scene only (snapped point, its neighbours, isSafety).
+// EXACT (obstacle handle in AMK_TIES_NANOFLANN mode) is a template parameter, not a flag: the traversal's stack lives in
+// scratch memory, and a kernel that MAY use scratch makes every hardware queue reserve it (with 32 queues in flight the
+// default path ran out of resources when the two shared one kernel).
+template <bool EXACT>
 __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
-    GridPtrs gpt, int use_grid, ExactPtrs eobs, int use_exact, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+    GridPtrs gpt, int use_grid, ExactPtrs eobs, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
     int cap, const int *__restrict__ sizes_obs, const float *__restrict__ pmax_obs, const int *__restrict__ sizes_edge,
     int N, int K, int nref, int iter, int max_iter, double speed, double T, double safety_distance,
     const double *__restrict__ state_quad, const double *__restrict__ pos_x, double *__restrict__ ref_path,
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
     int *__restrict__ flags) {
     const int s = blockIdx.x;
     if (done[s]) return;
-    plan_scene(s, gpt, use_grid, eobs, use_exact, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
+    plan_scene<EXACT>(s, gpt, use_grid, eobs, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
                knn_d2, edge_pt, edge_d2, flags);
     __threadfence_block();
     __syncthreads();
@@ -368,7 +369,8 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         }
         { TimedLaunch tl(KC_PLAN, stream);
-        hipLaunchKernelGGL(step_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, gobs, use_grid, eobs, ex_obs, obstacle->x.p,
+        hipLaunchKernelGGL(ex_obs ? step_plan_pack_kernel<true> : step_plan_pack_kernel<false>, dim3(S), dim3(kWave), 0, stream,
+                           gobs, use_grid, eobs, obstacle->x.p,
                            obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
                            K, mpc->nref, iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
                            d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,

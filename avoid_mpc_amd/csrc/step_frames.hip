@@ -100,7 +100,8 @@ __global__ __launch_bounds__(64) void step_knn_frames_exact_kernel(const FrameEx
     const int k = is_edge ? 1 : K;
     double rd[AMK_MAX_K];
     int ri[AMK_MAX_K];
-    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri);
+    ExactStackStorage stack;
+    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
     if (got < 0) return;
     for (int j = 0; j < k; ++j) {
         const bool ok = j < got;
@@ -143,6 +144,8 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 
 constexpr int kMaxCandPerLane = (AMK_MAX_FRAMES * AMK_MAX_K + 63) / 64;
 
+// EXACT (some frame in AMK_TIES_NANOFLANN mode): a template parameter so that the default kernel needs no scratch memory
+template <bool EXACT>
 __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     FrameSet fs, const FrameExact *__restrict__ fe, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
     int max_iter, double speed, double T, double safety_distance, const double *__restrict__ state_quad,
@@ -193,17 +196,12 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
                     o[0] = ok ? rec.x : 0.f; o[1] = ok ? rec.y : 0.f; o[2] = ok ? rec.z : 0.f;
                 }
                 __syncthreads();
-                if (fe && fe->use_obs[f]) {  // AMK_TIES_NANOFLANN frame: the re-query by the reference's traversal (lane 0)
+                if (EXACT && fe->use_obs[f]) {  // AMK_TIES_NANOFLANN frame: the re-query by the reference's traversal (lane 0)
                     __shared__ double xr[AMK_MAX_K];
                     __shared__ int xi[AMK_MAX_K], xgot;
+                    __shared__ ExactStackStorage xstack;  // LDS, not scratch: one lane walks the tree
                     const ExactTree T = fe->obs[f].scene(s);
-                    if (lane == 0) {
-                        double rd[AMK_MAX_K];
-                        int ri[AMK_MAX_K];
-                        const int got = exact_knn_thread(T, ex, ey, ez, K, rd, ri);
-                        xgot = got;
-                        for (int j = 0; j < K && j < got; ++j) { xr[j] = rd[j]; xi[j] = ri[j]; }
-                    }
+                    if (lane == 0) xgot = exact_knn_thread(T, ex, ey, ez, K, xr, xi, xstack.view());
                     __syncthreads();
                     if (xgot >= 0 && lane < K) {
                         const bool ok = lane < xgot;
@@ -387,7 +385,8 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         if (any_exact)
             hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 63) / 64, F), dim3(64), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);
-        hipLaunchKernelGGL(step_merge_plan_pack_kernel, dim3(S), dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
+        hipLaunchKernelGGL(any_exact ? step_merge_plan_pack_kernel<true> : step_merge_plan_pack_kernel<false>, dim3(S),
+                           dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
                            iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
         AMK_HIP(hipGetLastError());

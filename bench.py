@@ -191,6 +191,8 @@ def main():
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
     ap.add_argument("--ipm-max-iter", type=int, default=None, help="iteration cap of the solve (default: the library's)")
+    ap.add_argument("--tie-order", type=int, default=0, choices=(0, 1),
+                    help="1: amk_kd_set_tie_order(AMK_TIES_NANOFLANN) on both indices (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--steady-steps", type=int, default=1024,
@@ -247,6 +249,7 @@ def main():
             self.posx = torch.from_numpy(posx).to(dev)
             self.stream = torch.cuda.Stream(device=dev)
             self.kd_o, self.kd_e = KdBatch(S, n), KdBatch(S, ne)
+            self.kd_o.set_tie_order(args.tie_order); self.kd_e.set_tie_order(args.tie_order)
             self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm); self.mpc.set_precision(args.precision)
             if args.ipm_max_iter is not None:
                 self.mpc.set_solver_options(1e-4, args.ipm_max_iter)
@@ -370,6 +373,7 @@ def main():
                        "ipm_tol": 1e-4, "solves_per_step": round(solves, 3), "ipm_iters_per_step": round(ipm_iters, 2),
                        "streams_in_flight": nslots, "distinct_frames_bytes": int(nslots * S * 12 * (n + ne)),
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
+                       "tie_order": "nanoflann" if args.tie_order else "lowest index",
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
                        "parallelism": (f"scenes sharded over {world} GPU(s); RCCL all_gather of u" if collective
                                        else "single GPU, no process group")},

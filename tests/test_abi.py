@@ -55,3 +55,22 @@ def test_product_never_touches_the_oracle():
             if re.search(r"liboracle|kdo_|mpco_", txt):
                 bad.append(f)
     assert bad == []
+
+
+def test_default_path_kernels_use_no_scratch_memory(lib):
+    """A kernel that may touch scratch makes every hardware queue reserve it; with the bench's 20 streams / 32 queues a
+    scratch-using kernel on the default path exhausted the runtime's resources (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Only
+    the thread-per-query kernels of the opt-in nanoflann tie-order mode may use scratch (their traversal stack); the solve
+    must also stay within 256 VGPRs (2 waves per SIMD).  Read from the compiler's own resource report, written next to
+    the library by the build."""
+    import json
+    table = json.load(open(amk_build.RES))
+    assert len(table) >= 30
+    allowed = ("kd_exact_search_kernel", "step_knn_exact_kernel", "step_knn_frames_exact_kernel")
+    for name, r in table.items():
+        if not any(a in name for a in allowed):
+            assert r["scratch_bytes_per_lane"] == 0, (name, r)
+        else:
+            assert r["scratch_bytes_per_lane"] <= 2048, (name, r)
+    solve = [r for n, r in table.items() if "mpc_solve_kernel" in n]
+    assert solve and all(r["vgprs"] <= 256 for r in solve)
