@@ -25,7 +25,10 @@ constexpr int kGridMaxCells = 8192;
 #define AMK_BUILD_THREADS 512
 #endif
 constexpr int kGridBuildThreads = AMK_BUILD_THREADS;
-constexpr int kGridUnroll = 4;
+#ifndef AMK_GRID_UNROLL
+#define AMK_GRID_UNROLL 4
+#endif
+constexpr int kGridUnroll = AMK_GRID_UNROLL;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz
 
 // ------------------------------------------------------------------------------------------------
@@ -246,8 +249,16 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
                 idx = src.group_base((i < nvis ? i : i0) >> 6) + __popcll(m & ((1ull << lane) - 1ull));
             }
             if (keep) {
+#if defined(AMK_BUILD_DIAG) && AMK_BUILD_DIAG == 1   // experiments: everything but the record store
+                const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+                if (pos == 0x7fffffff) gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
+#elif defined(AMK_BUILD_DIAG) && AMK_BUILD_DIAG == 2  // experiments: records stored in input order (coalesced)
+                const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+                gpt4[pos >= 0 ? i : 0] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
+#else
                 const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
                 gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));  // one 16-byte store per point
+#endif
             }
         }
     }

@@ -42,9 +42,11 @@ constexpr int PRM_GAIN = 29;    // gains[4]  (parsed but unused by the dynamics,
 constexpr int PRM_RADIUS = 33;  // drone radius
 constexpr int PRM_LB = 34;      // control lower bounds[4]
 constexpr int PRM_UB = 38;      // control upper bounds[4]
-constexpr int PRM_A = 42;       // A[10][10] row-major
-constexpr int PRM_B = 142;      // B[10][4]
-constexpr int PRM_C = 182;      // c[10]
+constexpr int PRM_C = 42;       // c[10]
+constexpr int PRM_LDS_LEN = 52; // what the solve keeps in its scratchpad: everything above (A, B are read from global
+                                // memory into registers by the sweeps that need them: 140 doubles of LDS per scene)
+constexpr int PRM_A = 52;       // A[10][10] row-major
+constexpr int PRM_B = 152;      // B[10][4]
 constexpr int PRM_LEN = 192;
 
 struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the tests carries the same defaults
@@ -64,31 +66,34 @@ struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the t
 };
 
 // LDS carve-up for one scene (offsets in doubles).  All per-scene state of the solve lives here.
-constexpr int KK_ROW = 12;              // gains row: 10 feedback entries, the feed-forward term, one pad (16-byte rows)
-constexpr int KK_STAGE = 4 * KK_ROW;
+// The feedback gains of the Riccati sweep (4 x 10 + feed-forward per stage) live in a global, L2-resident scratch, not
+// in LDS: written once by the backward sweep, read once by the forward roll, 7.7 KB of the former 26.3 KB per scene --
+// with them in LDS a CU held 6 scenes, without them 8 (two per SIMD).  Layout [k][a][16]: row a of K_k in lane 16 a + j.
+constexpr int GAIN_ROW = 16;
+constexpr int GAIN_STAGE = 4 * GAIN_ROW;
 
 struct LdsMap {
     int prm, xinit, target, cy, sy;
     int X, U, zl, zu, dX, dU, dzl, dzu, Xt, Ut;
     int q, r, rb, Rb, gU, H6, rotQ;
-    int P, p, lam, M, Hm, G, Atp, Atl, qu, Y, Z, D, Kk, red;
+    int P, p, lam, M, Hm, G, Atp, Atl, qu, Y, Z, D, red;
     int total;
-    __host__ __device__ explicit LdsMap(int N) {
+    __host__ __device__ explicit LdsMap(int N, int prm_len = PRM_LDS_LEN) {
         int o = 0;
         auto take = [&](int n) { int b = o; o += (n + 1) & ~1; return b; };
-        prm = take(PRM_LEN); xinit = take(SD); target = take(SD); cy = take(N); sy = take(N);
+        prm = take(prm_len); xinit = take(SD); target = take(SD); cy = take(N); sy = take(N);
         X = take((N + 1) * SD); U = take(N * UD); zl = take(N * UD); zu = take(N * UD);
         dX = take((N + 1) * SD); dU = take(N * UD);
         q = take((N + 1) * SD); r = take(N * UD); rb = take(N * UD); Rb = take(N * UD); gU = take(N * UD);
-        // (the dual steps and the line-search trial point alias the gains, below)
         H6 = take(N * 21); rotQ = take(N * 6);
         P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
         Atp = take(SD); Atl = take(SD); qu = take(UD); Y = 0; Z = 0; D = 0;
-        Kk = take(N * KK_STAGE); red = take(16);
-        // buffers with disjoint lifetimes share storage: the gains are dead once the forward roll has run; the dual
-        // steps and the line-search trial point are born after it.  (Not on q / r: the first trial point is evaluated
-        // WITH derivatives, into q, r, H6, so that an accepted full step needs no second evaluation.)
-        Xt = Kk; Ut = Xt + (N + 1) * SD; dzl = Ut + N * UD; dzu = dzl + N * UD;
+        Xt = take((N + 1) * SD); Ut = take(N * UD); red = take(16);
+        // buffers with disjoint lifetimes share storage: the barrier-shifted control gradient / Hessian (rb, Rb) are
+        // dead once the backward sweep has run; the dual steps are born after the forward roll and consumed by the
+        // update that follows the line search.  (Not on q / r: the first trial point is evaluated WITH derivatives,
+        // into q, r, H6, so that an accepted full step needs no second evaluation.)
+        dzl = rb; dzu = Rb;
         total = o;
     }
 };

@@ -395,17 +395,19 @@ __device__ __forceinline__ void update_term_multipliers(real *sm, const LdsMap &
 // Reduced gradient gU_k = r_k + B' lam_{k+1} by the adjoint sweep lam_k = q_k + A' lam_{k+1}, lam_N = q_N (oracle
 // eval_iterate).  Lane i < 10 owns lam[i], lanes 10..13 own gU[a]; column i of A / a of B has <= 3 non-zero rows
 // (rows_of_A / rows_of_B), read from a double-buffered copy of lam_{k+1} in LDS: one barrier per stage.
-__device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N) {
-    const int lane = threadIdx.x;
-    const real *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
+__device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N, const double *prm_g) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));  // the lane's coefficients are re-derived per sweep: hoisted out of the iteration loop
+                                    // they would be live across the objective evaluation, which sets the register peak
+    const double *A = prm_g + PRM_A, *B = prm_g + PRM_B;  // three coefficients per lane, L2-resident
     int rows[3] = {0, 0, 0};
     real cf[3] = {RL(0.0), RL(0.0), RL(0.0)};
     if (lane < SD) {
         const int nr = rows_of_A(lane, rows);
-        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? A[rows[t] * SD + lane] : RL(0.0);
+        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? (real)A[rows[t] * SD + lane] : RL(0.0);
     } else if (lane < SD + UD) {
         const int nr = rows_of_B(lane - SD, rows);
-        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? B[rows[t] * UD + (lane - SD)] : RL(0.0);
+        for (int t = 0; t < 3; ++t) cf[t] = t < nr ? (real)B[rows[t] * UD + (lane - SD)] : RL(0.0);
     }
     real *buf0 = sm + L.lam, *buf1 = sm + L.Atl;
     if (lane < SD) buf0[lane] = sm[L.q + N * SD + lane];
@@ -453,13 +455,14 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
 }
 
 // Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
-// control block is not positive definite.  Gains go to L.Kk ([k][a*KK_ROW + j], column 10 = feed-forward).
+// control block is not positive definite.  Gains go to the scene's global scratch ([k][a][GAIN_ROW], column 10 =
+// feed-forward): stores that nothing in the sweep waits for.
 //
 // A stage is two LDS rounds.  Both are straight-line code (every lane runs the same instructions on its own
 // host-built indices) so that the loads of a round are all in flight before the first dependent fp64 op: this
 // sweep is a chain of dependent fp64 operations (32 cycles each here) and LDS round trips, nothing else.
 __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, const double *plan_coef,
-                                                 const int *plan_meta, int N, real delta) {
+                                                 const int *plan_meta, int N, real delta, double *gains) {
     const int lane = threadIdx.x;
     // the lane's plan is (re)loaded per sweep -- L2-resident words -- instead of being held for the whole
     // solve: it is dead weight (~90 VGPRs) during the objective evaluation, which sets the register peak
@@ -535,8 +538,9 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
             const real base = (fma(lp.bdelta, delta, lp.bconst) + b0) + (b1 + b2);
             const real val = fma(-t, rd, fma(-gi[3], u3, base));
             if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward)
-                real *kk = sm + L.Kk + k * KK_STAGE + R.gain_col;
-                kk[0] = -u0 * rd; kk[KK_ROW] = -u1 * rd; kk[2 * KK_ROW] = -u2 * rd; kk[3 * KK_ROW] = -u3;
+                double *kk = gains + k * GAIN_STAGE + R.gain_col;
+                kk[0] = (double)(-u0 * rd); kk[GAIN_ROW] = (double)(-u1 * rd);
+                kk[2 * GAIN_ROW] = (double)(-u2 * rd); kk[3 * GAIN_ROW] = (double)(-u3);
             }
             if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
                 sm[R.out1] = val;
@@ -550,44 +554,57 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
 }
 
 // forward roll of the Newton step: dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k.
-// Lane i < 10 owns dX[i], lane a < 4 owns dU[a]; a stage is two LDS broadcasts (dX_k to every lane, then dU_k).
-// The v_readlane version of the same exchange cost 56 VALU issue slots per stage -- more than its arithmetic.
-__device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N) {
-    const int lane = threadIdx.x;
-    const real *A = sm + L.prm + PRM_A, *B = sm + L.prm + PRM_B;
-    real arow[SD], brow[UD];  // row `lane` of A and B (lanes >= 10 idle)
-    const int row = lane < SD ? lane : 0;
+// Lane 16 a + j (j < 11) holds K_k[a][j] (j = 10: the feed-forward term) -- one coalesced global load per stage,
+// prefetched kFwdPrefetch stages ahead -- multiplies it with dX_k[j] from LDS, and a DPP row reduction leaves dU_k[a] in
+// every lane of row a.  State i is owned by a spare lane of the row of ITS control (p_a, v_a, a_a in row a; yaw in row 3:
+// B couples a state to that control only, cols_of_A_row / rows_of_B), so dX_{k+1}[i] needs no second exchange: a stage
+// is ONE LDS round trip (the previous version: two, plus 11 LDS reads of the gains per lane).
+constexpr int kFwdPrefetch = 5;  // divides the baked horizons 10, 20, 30
+__device__ __forceinline__ int cols_of_A_row(int i, int c[3]) {  // transpose view of rows_of_A
+    if (i < 3) { c[0] = i; c[1] = 4 + i; c[2] = 7 + i; return 3; }   // p_a <- p_a, v_a, a_a
+    if (i == 3) { c[0] = 3; return 1; }                              // yaw
+    if (i < 7) { c[0] = i; c[1] = i + 3; return 2; }                 // v_a <- v_a, a_a
+    c[0] = i; return 1;                                              // a_a
+}
+__device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N, const double *prm_g,
+                                                const double *gains) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));  // as in adjoint_sweep: nothing of the lane's role may be hoisted out of the iteration loop
+    const int a = lane >> 4, j = lane & 15;
+    const double *A = prm_g + PRM_A, *B = prm_g + PRM_B;
+    int own = -1;  // the state this lane produces
+    if (a < 3 && j >= 11 && j <= 13) own = j == 11 ? a : (j == 12 ? 4 + a : 7 + a);
+    if (a == 3 && j == 11) own = 3;
+    int cols[3] = {0, 0, 0};
+    real ac[3] = {RL(0.0), RL(0.0), RL(0.0)}, bc = RL(0.0);
+    if (own >= 0) {
+        const int nc = cols_of_A_row(own, cols);
+        for (int t = 0; t < 3; ++t) ac[t] = t < nc ? (real)A[own * SD + cols[t]] : RL(0.0);
+        bc = (real)B[own * UD + a];
+    }
+    const bool gain_lane = j <= SD;
+    real kv[kFwdPrefetch];
 #pragma unroll
-    for (int j = 0; j < SD; ++j) arow[j] = A[row * SD + j];
-#pragma unroll
-    for (int j = 0; j < UD; ++j) brow[j] = B[row * UD + j];
-    const int a = lane < UD ? lane : 0;
+    for (int u = 0; u < kFwdPrefetch; ++u) kv[u] = (u < N && gain_lane) ? (real)gains[u * GAIN_STAGE + lane] : RL(0.0);
     if (lane < SD) sm[L.dX + lane] = RL(0.0);
     __syncthreads();
+    const int xsrc = j < SD ? j : 0;
 #pragma unroll 1
-    for (int k = 0; k < N; ++k) {
-        const real *kk = sm + L.Kk + k * KK_STAGE + a * KK_ROW;
-        const real *xk = sm + L.dX + k * SD;
-        real krow[SD + 1], xs[SD];
+    for (int k0 = 0; k0 < N; k0 += kFwdPrefetch) {
 #pragma unroll
-        for (int j = 0; j <= SD; ++j) krow[j] = kk[j];
-#pragma unroll
-        for (int j = 0; j < SD; ++j) xs[j] = xk[j];
-        // partial sums: four short dependent chains instead of one of ten
-        real d0 = fma(krow[0], xs[0], krow[SD]), d1 = krow[1] * xs[1], d2 = krow[2] * xs[2], d3 = krow[3] * xs[3];
-        d0 = fma(krow[4], xs[4], d0); d1 = fma(krow[5], xs[5], d1); d2 = fma(krow[6], xs[6], d2);
-        d3 = fma(krow[7], xs[7], d3); d0 = fma(krow[8], xs[8], d0); d1 = fma(krow[9], xs[9], d1);
-        const real du = (d0 + d1) + (d2 + d3);
-        if (lane < UD) sm[L.dU + k * UD + lane] = du;
-        real a0 = arow[0] * xs[0], a1 = arow[1] * xs[1], a2 = arow[2] * xs[2], a3 = arow[3] * xs[3];
-        a0 = fma(arow[4], xs[4], a0); a1 = fma(arow[5], xs[5], a1); a2 = fma(arow[6], xs[6], a2);
-        a3 = fma(arow[7], xs[7], a3); a0 = fma(arow[8], xs[8], a0); a1 = fma(arow[9], xs[9], a1);
-        __syncthreads();
-        const real *uk = sm + L.dU + k * UD;
-        a2 = fma(brow[0], uk[0], a2); a3 = fma(brow[1], uk[1], a3);
-        a0 = fma(brow[2], uk[2], a0); a1 = fma(brow[3], uk[3], a1);
-        if (lane < SD) sm[L.dX + (k + 1) * SD + lane] = (a0 + a1) + (a2 + a3);
-        __syncthreads();
+        for (int u = 0; u < kFwdPrefetch; ++u) {
+            const int k = k0 + u;
+            if (k >= N) break;
+            const real g = kv[u];
+            kv[u] = (k + kFwdPrefetch < N && gain_lane) ? (real)gains[(k + kFwdPrefetch) * GAIN_STAGE + lane] : RL(0.0);
+            const real *xk = sm + L.dX + k * SD;
+            const real xj = xk[xsrc], x0 = xk[cols[0]], x1 = xk[cols[1]], x2 = xk[cols[2]];
+            const real du = row_reduce<OpSum>(g * (j < SD ? xj : RL(1.0)));  // lanes j > 10 hold g = 0
+            const real ax = fma(ac[2], x2, ac[0] * x0) + ac[1] * x1;
+            if (j == 0) sm[L.dU + k * UD + a] = du;
+            if (own >= 0) sm[L.dX + (k + 1) * SD + own] = fma(bc, du, ax);
+            __syncthreads();
+        }
     }
 }
 
@@ -628,11 +645,11 @@ __device__ __forceinline__ real next_mu(real mu, real mu_min, real kappa_mu) {
 __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
                             const double *x_init, const double *target, const SceneIO &io, const double *w0,
                             double *w_out, int *info, const double *plan_coef, const int *plan_meta, double *ybuf,
-                            double *trace = nullptr) {
+                            double *gains, double *trace = nullptr) {
     const int lane = threadIdx.x;
     const real o_tol = (real)opt.tol, o_mu_init = (real)opt.mu_init, o_bound_push = (real)opt.bound_push, o_bound_frac = (real)opt.bound_frac, o_kappa_mu = (real)opt.kappa_mu, o_tau_min = (real)opt.tau_min, o_eta_phi = (real)opt.eta_phi, o_s_max = (real)opt.s_max, o_kappa_sigma = (real)opt.kappa_sigma;
     const real o_kappa_eps = (real)opt.kappa_eps, o_maj = (real)opt.maj;
-    for (int e = lane; e < PRM_LEN; e += 64) sm[L.prm + e] = (real)prm_g[e];
+    for (int e = lane; e < PRM_LDS_LEN; e += 64) sm[L.prm + e] = (real)prm_g[e];
     if (lane < SD) {
         sm[L.xinit + lane] = (real)x_init[lane];
         sm[L.target + lane] = (real)target[lane];
@@ -669,14 +686,20 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         *reinterpret_cast<double2 *>(ybuf + (size_t)e * 2) = make_double2(-1.0, -1.0);
     __syncthreads();
     {  // rollout X_{k+1} = A X_k + B U_k + c
-        const real *A = prm + PRM_A, *B = prm + PRM_B, *c = prm + PRM_C;
+        const real *c = prm + PRM_C;
+        const int row = lane < SD ? lane : 0;
+        real arow[SD], brow[UD];  // row `lane` of A and B
+#pragma unroll
+        for (int j = 0; j < SD; ++j) arow[j] = (real)prm_g[PRM_A + row * SD + j];
+#pragma unroll
+        for (int j = 0; j < UD; ++j) brow[j] = (real)prm_g[PRM_B + row * UD + j];
         for (int k = 0; k < N; ++k) {
             if (lane < SD) {
                 real a = RL(0.0);
 #pragma unroll
-                for (int j = 0; j < SD; ++j) a += A[lane * SD + j] * sm[L.X + k * SD + j];
+                for (int j = 0; j < SD; ++j) a += arow[j] * sm[L.X + k * SD + j];
 #pragma unroll
-                for (int j = 0; j < UD; ++j) a += B[lane * UD + j] * sm[L.U + k * UD + j];
+                for (int j = 0; j < UD; ++j) a += brow[j] * sm[L.U + k * UD + j];
                 sm[L.X + (k + 1) * SD + lane] = a + c[lane];
             }
             __syncthreads();
@@ -691,7 +714,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
                                      : evaluate<true>(sm, L, io, N, K, sm + L.X, sm + L.U, mu, o_kappa_sigma,
                                                       o_maj * mu / o_mu_init, ybuf, acc, tclk);
         __syncthreads();
-        adjoint_sweep(sm, L, N);
+        adjoint_sweep(sm, L, N, prm_g);
         return J + box_errors(sm, L, nvar, mu, o_s_max, acc, err);
     };
     // starting barrier parameter: the duals start on the central path of whatever mu is chosen, so mu_init is lowered
@@ -739,20 +762,20 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         __syncthreads();
         real delta = RL(0.0);
         int reg_now = 0;
-        bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
+        bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta, gains);
         while (!ok) {
             __syncthreads();
             if (delta == RL(0.0)) delta = (delta_last == RL(0.0)) ? RL(1.0) : fmax(RL(1e-20), delta_last / RL(3.0));
             else delta *= (delta_last == RL(0.0)) ? RL(100.0) : RL(8.0);
             ++reg_now;
             if (delta > (AMK_REAL_F32 ? RL(1e30) : RL(1e40))) break;
-            ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta);
+            ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta, gains);
         }
         if (!ok) { status = 2; break; }
         n_reg += reg_now;
         if (delta > RL(0.0)) delta_last = delta;
         const long long t2 = AMK_CLK();
-        riccati_forward(sm, L, N);
+        riccati_forward(sm, L, N, prm_g, gains);
         const long long t3 = AMK_CLK();
         // dual steps, fraction to the boundary, directional derivative: control box ...
         real a_pr = RL(1.0), a_du = RL(1.0), dphi = RL(0.0);

@@ -36,7 +36,7 @@ __global__ __launch_bounds__(64) void mpc_eval_kernel(int Nrt, int K, int nref, 
     double *sm = reinterpret_cast<double *>(sm_raw);
     const int s = blockIdx.x, lane = threadIdx.x;
     const int N = NT > 0 ? NT : Nrt;
-    const LdsMap L(N);
+    const LdsMap L(N, PRM_LEN);
     const double *P = ref_states + (size_t)s * nref;
     const double *w = w_all + (size_t)s * nx;
     SceneIO io;

@@ -78,6 +78,15 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
     for (int i = 0; i < SD; ++i)
         if (i != 3 && B[i * UD + 3] != 0.0) yaw_free = false;
     if (!yaw_free) return AMK_ERR_UNSUPPORTED;  // the control block is inverted as blkdiag(3x3, 1x1) (riccati_backward)
+    // the sweeps assume the chain structure p_a <- v_a <- a_a <- u_a, yaw <- u_3 (rows_of_A / rows_of_B / cols_of_A_row)
+    auto axis = [](int i) { return i < 3 ? i : (i == 3 ? 3 : (i < 7 ? i - 4 : i - 7)); };
+    auto level = [](int i) { return i < 3 ? 0 : (i == 3 ? 0 : (i < 7 ? 1 : 2)); };
+    for (int i = 0; i < SD; ++i) {
+        for (int j = 0; j < SD; ++j)
+            if (A[i * SD + j] != 0.0 && (axis(i) != axis(j) || level(j) < level(i))) return AMK_ERR_UNSUPPORTED;
+        for (int a = 0; a < UD; ++a)
+            if (B[i * UD + a] != 0.0 && axis(i) != a) return AMK_ERR_UNSUPPORTED;
+    }
     auto zeroP = [&](int l, int mm) { return (l == 3) != (mm == 3); };
     const int ZERO = L.red + 10, DUMMY = L.red + 8;  // a cell that always holds 0.0 / a write-only cell
     struct Item { std::vector<std::pair<int, double>> t; int out, ks, aux, aux_ks; double dflag; };
@@ -231,7 +240,8 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
                                                   double *__restrict__ x0array, int *__restrict__ info, double *trace,
                                                   const int *__restrict__ done, double *__restrict__ ref_path,
                                                   int *__restrict__ step_flags, const double *__restrict__ plan_coef,
-                                                  const int *__restrict__ plan_meta, double *__restrict__ ybuf) {
+                                                  const int *__restrict__ plan_meta, double *__restrict__ ybuf,
+                                                  double *__restrict__ gains) {
     using namespace amk32;  // solve_scene / sm_status / sm_iters overload on the scratchpad type
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     R *sm = reinterpret_cast<R *>(sm_raw);
@@ -246,7 +256,7 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     const double *target = P + SD + SD * N + 3 * K * N;
     double *w = w0 + (size_t)s * nx;
     solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, plan_coef, plan_meta,
-                ybuf + (size_t)s * N * (K > 0 ? K : 1) * 2, s == 0 ? trace : nullptr);
+                ybuf + (size_t)s * N * (K > 0 ? K : 1) * 2, gains + (size_t)s * N * GAIN_STAGE, s == 0 ? trace : nullptr);
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
@@ -269,8 +279,8 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
         const double *__restrict__ ref_states, double *__restrict__ w0, double *__restrict__ u_out,                      \
         double *__restrict__ x0array, int *__restrict__ info, double *trace, const int *__restrict__ done,               \
         double *__restrict__ ref_path, int *__restrict__ step_flags, const double *__restrict__ plan_coef,               \
-        const int *__restrict__ plan_meta, double *__restrict__ ybuf
-#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta, ybuf
+        const int *__restrict__ plan_meta, double *__restrict__ ybuf, double *__restrict__ gains
+#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta, ybuf, gains
 
 template <int NT>
 __global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(AMK_SOLVE_ARGS) {
@@ -288,7 +298,7 @@ int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_
 #define AMK_LAUNCH_SOLVE(KERNEL, NT, LDS)                                                                            \
     hipLaunchKernelGGL(KERNEL<NT>, dim3(m->S), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
                        d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, d_step_flags,         \
-                       m->plan_coef.p, m->plan_meta.p, m->ybuf.p)
+                       m->plan_coef.p, m->plan_meta.p, m->ybuf.p, m->gains.p)
     if (m->precision == 32) {  // fp32 arithmetic, half the scratchpad
         const size_t lds = m->lds_bytes / 2;
         switch (m->N) {
@@ -373,6 +383,8 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
         (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2)) != hipSuccess ||
         (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = m->ybuf.alloc((size_t)n_scenes * N * (m->K > 0 ? m->K : 1) * 2)) != hipSuccess ||
+        (e = m->gains.alloc((size_t)n_scenes * N * GAIN_STAGE)) != hipSuccess ||
+        (e = hipMemset(m->gains.p, 0, sizeof(double) * (size_t)n_scenes * N * GAIN_STAGE)) != hipSuccess ||
         (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
         (e = hipFuncSetAttribute(N == 10   ? (const void *)mpc_solve_kernel<10>
                                  : N == 20 ? (const void *)mpc_solve_kernel<20>

@@ -261,6 +261,9 @@ def main():
 
     slots = [Slot(i) for i in range(nslots)]
     step_no = [0]
+    # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
+    # value is then NOT the metric (the JSON line says so)
+    DIAG_SKIP = os.environ.get("AMK_BENCH_SKIP", "")
 
     def one_step():
         sl = slots[step_no[0] % nslots]
@@ -268,9 +271,11 @@ def main():
         with torch.cuda.stream(sl.stream):
             sl.ref.copy_(sl.ref0, non_blocking=True)  # fresh frame: mRefPath after GetInitPath
             sl.mpc.reset_warm_start(sl.stream)        # zero warm start (HighLvlMpc.cpp:26-27,35)
-            sl.kd_o.build(sl.clouds, stream=sl.stream)   # FrameKDMap::AddVertex: obstacle index ...
-            sl.kd_e.build(sl.edges, stream=sl.stream)    # ... and edge index (FrameKDMap.cpp:44-47)
-            step_batch(sl.kd_o, sl.kd_e, sl.mpc, prm, sl.sq, sl.posx, sl.ref, stream=sl.stream, out=sl.out)
+            if DIAG_SKIP != "build" or step_no[0] <= nslots:
+                sl.kd_o.build(sl.clouds, stream=sl.stream)   # FrameKDMap::AddVertex: obstacle index ...
+                sl.kd_e.build(sl.edges, stream=sl.stream)    # ... and edge index (FrameKDMap.cpp:44-47)
+            if DIAG_SKIP != "step":
+                step_batch(sl.kd_o, sl.kd_e, sl.mpc, prm, sl.sq, sl.posx, sl.ref, stream=sl.stream, out=sl.out)
             if collective:
                 shard.gather_controls(sl.out["u"], out=sl.u_all)   # the one exchange step: controls to every rank
 
@@ -336,11 +341,11 @@ def main():
         total_scenes = S * world * args.steps
         value = total_scenes / dt
         solve_launches = max(cnt[5], 1)
-        solve_ms = ms[5] / solve_launches
+        solve_ms = ms[5] / solve_launches or 1e-9
         alg_launch = solve_alg_bytes(N, prm.K) * S
         achieved = alg_launch / (solve_ms * 1e-3) / 1e9
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
-        build_ms = ms[7] / max(cnt[7], 1)
+        build_ms = ms[7] / max(cnt[7], 1) or 1e-9
         build_alg = 28 * S * (n + ne) // 2       # 12 B read + 16 B written per point; mean of the obstacle and the edge launch
         traffic, build_traffic, traffic_src, issue = None, None, None, None
         tpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
@@ -362,6 +367,7 @@ def main():
             "metric": f"MPC steps/sec ({n // 1000}k-pt cloud, N={N}, {prm.K} obstacle constraints)",
             "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+            **({"INVALID_diagnostic_run": "AMK_BENCH_SKIP=" + DIAG_SKIP} if DIAG_SKIP else {}),
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "value_steady_state": round(steady, 1) if steady else None,
             "value_steady_state_steps": args.steady_steps if steady else None,
