@@ -5,7 +5,7 @@
 // Only the *results* of a search must equal the reference's (exact k nearest, ascending), so the tree
 // shape is free.  On a GPU a pointer tree with 10-point leaves is the wrong shape:
 // the build here is a counting sort of the points into the cells of a uniform grid (bucket-contiguous
-// reordered SoA copy, ~8 points per cell, <= 8192 cells), the search one wavefront per query that
+// records, ~64 points per cell, <= 1024 cells), the search one wavefront per query that
 // visits the cells in growing Chebyshev rings around the query's cell -- 64 lanes evaluate 64 bucket
 // points at a time -- and stops as soon as the k-th best squared distance is below the squared distance
 // to everything not yet visited.  That is the same branch-and-bound argument as nanoflann's
@@ -15,7 +15,20 @@
 
 namespace amk {
 
-constexpr int kGridMaxCells = 8192;
+#ifndef AMK_GRID_MAX_CELLS
+#define AMK_GRID_MAX_CELLS 1024
+#endif
+constexpr int kGridMaxCells = AMK_GRID_MAX_CELLS;
+#ifndef AMK_GRID_PPC
+#define AMK_GRID_PPC 64
+#endif
+// Resolution: ~64 points per cell, <= 1024 cells (round 1: ~8 per cell, <= 8192).  The build's scatter keeps one open
+// output line per cell; 256 scenes x 8192 cells x 128 B is 8x the L2, so every 16-byte record left L2 on its own (write
+// traffic 2x the records), while 256 x <= 1024 lines mostly stay until they are full.  The search pays with longer
+// candidate lists (a cell is one coalesced run of records: cheap) -- measured with 20 steps in flight
+// (tools/experiments/cells_sens.sh): 50k-point clouds 385 -> 402 k steps/s, 200k-point clouds 125 -> 137 k, 5k / 3k-point
+// clouds unchanged; the histogram shrinks from 32 KB to 4 KB of LDS per block.
+constexpr int kGridPointsPerCell = AMK_GRID_PPC;  // target occupancy of a cell
 // 512, not 1024: a 1024-thread workgroup needs four wave slots on every SIMD of one CU at the same moment, and the
 // dispatcher holds everything behind it until a CU qualifies -- measured: 1024-thread builds do not overlap with
 // the solves (or the searches) of other streams AT ALL (time = sum), 512/256-thread builds overlap almost fully
@@ -93,7 +106,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
     __shared__ double geo[kGridParamDoubles];
 
     // 1. bounding box of the finite points: reduced by the compaction kernel (bbox[s][6] = min xyz, max xyz)
-    // 2. grid geometry: ~8 points per cell, <= kGridMaxCells cells, cubic cells of edge h
+    // 2. grid geometry: ~kGridPointsPerCell points per cell, <= kGridMaxCells cells, cubic cells of edge h
     if (tid == 0) {
         double lo[3], hi[3], ext[3], emax = 0.0;
         for (int a = 0; a < 3; ++a) {
@@ -106,7 +119,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
         const double efloor = fmax(emax * 1e-6, 1e-30);
         double vol = 1.0;
         for (int a = 0; a < 3; ++a) vol *= fmax(ext[a], efloor);
-        double target = fmin(fmax((double)(Src::kFilter ? nvis : n) / 8.0, 1.0), (double)kGridMaxCells);
+        double target = fmin(fmax((double)(Src::kFilter ? nvis : n) / (double)kGridPointsPerCell, 1.0), (double)kGridMaxCells);
         double h = cbrt(vol / target);
         if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
         int g[3];
