@@ -39,7 +39,7 @@ constexpr int kGridPointsPerCell = AMK_GRID_PPC;  // target occupancy of a cell
 #endif
 constexpr int kGridBuildThreads = AMK_BUILD_THREADS;
 #ifndef AMK_GRID_UNROLL
-#define AMK_GRID_UNROLL 4
+#define AMK_GRID_UNROLL 8
 #endif
 constexpr int kGridUnroll = AMK_GRID_UNROLL;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz
