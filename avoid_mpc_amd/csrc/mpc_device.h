@@ -19,6 +19,7 @@
 // work is 64-lane fp64 VALU with LDS as the per-scene scratchpad.
 #pragma once
 #include "amk_common.h"
+#include "fast_math.h"
 
 namespace amk {
 

@@ -36,12 +36,27 @@ __device__ __forceinline__ real fast_rcp(real x) {
 #if AMK_REAL_F32
     real r = __builtin_amdgcn_rcpf(x);
     r = fma(fma(-x, r, 1.0f), r, r);
-#else
-    real r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-#endif
     return r;
+#else
+    return amk::rcp_f64(x);  // one cubic correction: a dependent operation less than two Newton steps
+#endif
+}
+
+// exp / log of the collision terms and barrier sums: the short-chain versions of fast_math.h in fp64, the library's
+// (hardware-assisted) ones in fp32
+__device__ __forceinline__ real real_exp(real x) {
+#if AMK_REAL_F32
+    return exp(x);
+#else
+    return amk::fast_exp(x);
+#endif
+}
+__device__ __forceinline__ real real_log(real x) {
+#if AMK_REAL_F32
+    return log(x);
+#else
+    return amk::fast_log(x);
+#endif
 }
 
 struct OpSum { __device__ __forceinline__ static real f(real a, real b) { return a + b; } };
@@ -114,8 +129,8 @@ __device__ __forceinline__ real collide_term(const real p[3], const real v[3], c
     const real d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
     const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
     const real x = -RL(32.0) * (rho - radius);
-    const real ex = exp(x);
-    const real g = log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
+    const real ex = real_exp(x);
+    const real g = real_log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
     const real c = lam * g;
     if (!(c > RL(0.0))) {              // dormant: c == 0 exactly, the term and all its derivatives vanish
         if (MODE == 2) { y1 = -RL(1.0); y2 = -RL(1.0); }
@@ -127,7 +142,7 @@ __device__ __forceinline__ real collide_term(const real p[3], const real v[3], c
     real w1, w2;
     slacks(s, mu, w1, w2);
     const real t = RL(0.5) * (w1 + w2);
-    if (MODE == 0) return c * (t - mu * log(w1 * w2));
+    if (MODE == 0) return c * (t - mu * real_log(w1 * w2));
     const real sg = ex * fast_rcp(RL(1.0) + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
     const real gp = -RL(32.0) * sg;
     const real tv[3] = {v[0] - s * n[0], v[1] - s * n[1], v[2] - s * n[2]};
@@ -152,7 +167,7 @@ __device__ __forceinline__ real collide_term(const real p[3], const real v[3], c
     const real gpp = RL(1024.0) * sg * (RL(1.0) - sg);
     const real sig = a1 - a2;
     const real bs = mu * (iw1 - iw2);  // d/ds of the barrier form; its d/dt vanishes at the optimal t
-    const real Psi = t - mu * log(w1 * w2);
+    const real Psi = t - mu * real_log(w1 * w2);
     const real lgp = lam * gp;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -624,7 +639,7 @@ __device__ __forceinline__ real box_errors(const real *sm, const LdsMap &L, int 
         ed = fmax(ed, fabs(sm[L.gU + e] - zl + zu));
         ec = fmax(ec, fmax(sl * zl, su * zu));
         ecm = fmax(ecm, fmax(fabs(sl * zl - mu), fabs(su * zu - mu)));
-        lg -= mu * log(sl * su);  // both slacks are positive and bounded by the box: no overflow
+        lg -= mu * real_log(sl * su);  // both slacks are positive and bounded by the box: no overflow
     }
     zs = wave_sum(zs); ed = wave_max(ed); ec = fmax(wave_max(ec), acc[0]); ecm = fmax(wave_max(ecm), acc[1]);
     const real is_d = s_max * fast_rcp(fmax(s_max, zs / (RL(2.0) * nvar)));
@@ -822,7 +837,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             for (int e = lane; e < nvar; e += 64) {
                 const int i = e % UD;
                 const real u = sm[L.Ut + e];
-                lg -= mu * log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
+                lg -= mu * real_log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
             }
             phi_t = J_t + wave_sum(lg);
             if (tiny || phi_t <= phi0 + o_eta_phi * a * dphi) { accepted = true; break; }

@@ -220,6 +220,19 @@ int upload_params(amk_mpc *m) {
 
 }  // namespace
 
+// Internal (tests/test_fast_math_gpu.py): fast_math.h on n doubles -- out = [exp(x), log(|x|), 1/x] planes
+__global__ void fast_math_probe_kernel(const double *__restrict__ x, double *__restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = amk::fast_exp(x[i]);
+    out[n + i] = amk::fast_log(fabs(x[i]));
+    out[2 * n + i] = amk::rcp_f64(x[i]);
+}
+extern "C" int amk__fast_math_probe(const double *d_x, double *d_out, int n, void *stream) {
+    hipLaunchKernelGGL(fast_math_probe_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, d_out, n);
+    return hipGetLastError() == hipSuccess ? AMK_OK : AMK_ERR_HIP;
+}
+
 // Internal debugging aid (not part of the C ABI): when set, scene 0 of mpc_solve_kernel writes 8 doubles per
 // interior-point iteration {J, kkt error, mu, delta, alpha, alpha_pr, alpha_du, dphi}.
 static double *g_trace = nullptr;

@@ -216,3 +216,22 @@ def test_mpc_object_semantics(oracle):
     w2, _, _ = _oracle.mpco_solve(Pfull, w, lbu, ubu, 10, 3, prm.dt)
     assert np.array_equal(u2, w2[10:14])
     assert np.all(u >= np.array(lbu) - 1e-9) and np.all(u <= np.array(ubu) + 1e-9)
+
+
+def test_solver_exp_log_restatement_against_libm():
+    """The solver section of the oracle evaluates exp / log by the same short-chain algorithms as the device
+    (oracle/mpc_oracle.c sexp / slog <-> avoid_mpc_amd/csrc/fast_math.h): <= 2 ulp against libm over the solver's ranges."""
+    import ctypes as C
+    lib = _oracle.load_oracle()
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-745, 709, 200000), rng.uniform(-40, 12, 200000), np.exp(rng.uniform(-60, 60, 200000))])
+    ce, cl = np.empty_like(x), np.empty_like(x)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.mpco_fast_math.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]; lib.mpco_fast_math.restype = None
+    lib.mpco_fast_math(vp(x), vp(ce), vp(cl), len(x))
+    with np.errstate(over="ignore"):
+        we, wl = np.exp(x), np.log(np.abs(x))
+    ok = np.isfinite(we) & (we > 1e-300)
+    ue = (np.abs(ce[ok] - we[ok]) / np.spacing(we[ok])).max(); ul = (np.abs(cl - wl) / np.spacing(np.abs(wl))).max()
+    print(f"max ulp error vs libm: exp {ue:.2f} log {ul:.2f}")
+    assert ue <= 2.0 and ul <= 2.0
