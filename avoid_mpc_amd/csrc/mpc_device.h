@@ -70,6 +70,7 @@ struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the t
 // The feedback gains of the Riccati sweep (4 x 10 + feed-forward per stage) live in a global, L2-resident scratch, not
 // in LDS: written once by the backward sweep, read once by the forward roll, 7.7 KB of the former 26.3 KB per scene --
 // with them in LDS a CU held 6 scenes, without them 8 (two per SIMD).  Layout [k][a][16]: row a of K_k in lane 16 a + j.
+constexpr int kTermRecord = 4;  // doubles per collision term in the global scratch (mpc_device_impl.h: YB)
 constexpr int GAIN_ROW = 16;
 constexpr int GAIN_STAGE = 4 * GAIN_ROW;
 

@@ -7,6 +7,7 @@ using namespace amk;
 typedef AMK_REAL real;
 #define RL(x) ((real)(x))
 constexpr real kGz = RL(9.81);   // mpc_obstacle_casadi.py:39
+constexpr int YB = amk::kTermRecord;  // doubles per collision term in the global scratch: y1, y2, 1/rho, g'/g
 
 // ---- cross-lane reductions on DPP (no LDS crossbar): quad_perm for lane^1 / lane^2, row_half_mirror and
 // row_mirror for the 8- and 16-lane levels (valid because every lane of the lower level already holds
@@ -121,30 +122,44 @@ __device__ __forceinline__ void term_mult(real y1, real y2, real mu, real kappa_
 // reproducible), and the complementarity maxima cmax = max yh_i w_i, cdev = max |yh_i w_i - mu|.
 // MODE 2: Newton step of the term's multipliers for the state step (dp, dv), own fraction-to-the-boundary length;
 // y1/y2 are updated in place (a term that is dormant here forgets its multipliers).
+// c_ir, c_gpg: 1 / |o - p| and g'/g of the term at the iterate, written by MODE 1 (c_ir = 0 for a dormant term) and read
+// back by MODE 2, which runs at the same point: the multiplier pass skips the sqrt -> exp -> log chain (~100 fp64
+// instructions per term) and finds the same bits.
 template <int MODE>
 __device__ __forceinline__ real collide_term(const real p[3], const real v[3], const real o[3], real lam, real radius,
                                                real mu, real kappa_sigma, real maj, real tau, real &y1, real &y2,
                                                const real *dp, const real *dv, real *gq, real *h21, real &cmax,
-                                               real &cdev) {
+                                               real &cdev, real &c_ir, real &c_gpg) {
     const real d0 = o[0] - p[0], d1 = o[1] - p[1], d2 = o[2] - p[2];
-    const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
-    const real x = -RL(32.0) * (rho - radius);
-    const real ex = real_exp(x);
-    const real g = real_log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
-    const real c = lam * g;
-    if (!(c > RL(0.0))) {              // dormant: c == 0 exactly, the term and all its derivatives vanish
-        if (MODE == 2) { y1 = -RL(1.0); y2 = -RL(1.0); }
-        return RL(0.0);
+    real ir, g = RL(0.0), c = RL(0.0), ex = RL(0.0);
+    if (MODE == 2) {
+        ir = c_ir;
+        if (!(ir > RL(0.0))) { y1 = -RL(1.0); y2 = -RL(1.0); return RL(0.0); }  // dormant at the iterate
+    } else {
+        const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        const real x = -RL(32.0) * (rho - radius);
+        ex = real_exp(x);
+        g = real_log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
+        c = lam * g;
+        if (!(c > RL(0.0))) {          // dormant: c == 0 exactly, the term and all its derivatives vanish
+            if (MODE == 1) c_ir = RL(0.0);
+            return RL(0.0);
+        }
+        ir = fast_rcp(rho);
     }
-    const real ir = fast_rcp(rho);
     const real n[3] = {d0 * ir, d1 * ir, d2 * ir};
     const real s = v[0] * n[0] + v[1] * n[1] + v[2] * n[2];
     real w1, w2;
     slacks(s, mu, w1, w2);
     const real t = RL(0.5) * (w1 + w2);
     if (MODE == 0) return c * (t - mu * real_log(w1 * w2));
-    const real sg = ex * fast_rcp(RL(1.0) + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
-    const real gp = -RL(32.0) * sg;
+    real sg = RL(0.0), gp = RL(0.0);
+    if (MODE == 1) {
+        sg = ex * fast_rcp(RL(1.0) + ex);  // = 1/(1+exp(-x)); x <= 32 r, no overflow
+        gp = -RL(32.0) * sg;
+        c_ir = ir;
+        c_gpg = gp * fast_rcp(g);
+    }
     const real tv[3] = {v[0] - s * n[0], v[1] - s * n[1], v[2] - s * n[2]};
     const real iw1 = fast_rcp(w1), iw2 = fast_rcp(w2);
     real a1, a2;
@@ -154,7 +169,7 @@ __device__ __forceinline__ real collide_term(const real p[3], const real v[3], c
     if (MODE == 2) {
         const real ndp = n[0] * dp[0] + n[1] * dp[1] + n[2] * dp[2];
         const real ds = -(tv[0] * dp[0] + tv[1] * dp[1] + tv[2] * dp[2]) * ir + (n[0] * dv[0] + n[1] * dv[1] + n[2] * dv[2]);
-        const real dlc = -(gp * fast_rcp(g)) * ndp;      // (grad c / c)' dz
+        const real dlc = -c_gpg * ndp;                   // (grad c / c)' dz
         const real dt = (-e * dlc - dD * ds) * iDh;      // the t row of the Newton system (its residual is 0)
         const real dy1 = mu * iw1 - a1 - D1 * (dt - ds), dy2 = mu * iw2 - a2 - D2 * (dt + ds);
         real al = RL(1.0);
@@ -273,10 +288,10 @@ __device__ __forceinline__ real collide_exact(const real p[3], const real v[3], 
 
 // Objective on (Xs, Us) held in LDS, in the solver's barrier form (EXACT = false) or as the plugin defines it (EXACT).  DERIV: also q, r, H6 (21 per stage), and acc[0] = max yh_i w_i,
 // acc[1] = max |yh_i w_i - mu| over the collision terms (wave-uniform).  Returns the value (wave-uniform).  Reads the
-// multipliers (ybuf, [N-1][K][2] doubles in global memory), writes none.  One wave; caller syncs before/after.
+// multipliers (ybuf, [N-1][K][YB] doubles in global memory: y1, y2, then the cache of collide_term) and, with DERIV, writes the cache.  One wave; caller syncs before/after.
 template <bool DERIV, bool EXACT = false>
 __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, const real *Xs,
-                           const real *Us, real mu, real kappa_sigma, real maj, const double *ybuf, real *acc,
+                           const real *Us, real mu, real kappa_sigma, real maj, double *ybuf, real *acc,
                            long long *tclk = nullptr) {
     const int lane = threadIdx.x;
     const real *prm = sm + L.prm;
@@ -304,13 +319,16 @@ __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneI
             if (EXACT) {  // the plugin's form c |s| (amk_mpc_eval)
                 Jloc += collide_exact<DERIV>(p, v, o, lamw, radius, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21);
             } else {
-                real y1 = RL(0.0), y2 = RL(0.0);
+                real y1 = RL(0.0), y2 = RL(0.0), c_ir = RL(0.0), c_gpg = RL(0.0);
+                double *yrec = ybuf + ((size_t)k * K + j) * YB;
                 if (DERIV) {
-                    const double2 yy = *reinterpret_cast<const double2 *>(ybuf + ((size_t)k * K + j) * 2);
+                    const double2 yy = *reinterpret_cast<const double2 *>(yrec);
                     y1 = (real)yy.x; y2 = (real)yy.y;
                 }
                 Jloc += collide_term<DERIV ? 1 : 0>(p, v, o, lamw, radius, mu, kappa_sigma, maj, RL(0.0), y1, y2, nullptr,
-                                                    nullptr, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21, cmax, cdev);
+                                                    nullptr, sm + L.q + (k + 1) * SD, sm + L.H6 + k * 21, cmax, cdev, c_ir,
+                                                    c_gpg);
+                if (DERIV) *reinterpret_cast<double2 *>(yrec + 2) = make_double2((double)c_ir, (double)c_gpg);
             }
         }
     }
@@ -398,11 +416,12 @@ __device__ __forceinline__ void update_term_multipliers(real *sm, const LdsMap &
             const real dp[3] = {dk[0], dk[1], dk[2]}, dv[3] = {dk[4], dk[5], dk[6]};
             const double *op = io.obs + ((size_t)k * K + j) * 3;
             const real o[3] = {(real)op[0], (real)op[1], (real)op[2]};
-            double2 *yp = reinterpret_cast<double2 *>(ybuf + ((size_t)k * K + j) * 2);
-            const double2 yy = *yp;
-            real y1 = (real)yy.x, y2 = (real)yy.y;
-            collide_term<2>(p, v, o, lamw, radius, mu, kappa_sigma, RL(0.0), tau, y1, y2, dp, dv, nullptr, nullptr, dummy0, dummy1);
-            *yp = make_double2((double)y1, (double)y2);
+            double2 *yp = reinterpret_cast<double2 *>(ybuf + ((size_t)k * K + j) * YB);
+            const double2 yy = yp[0], cc = yp[1];
+            real y1 = (real)yy.x, y2 = (real)yy.y, c_ir = (real)cc.x, c_gpg = (real)cc.y;
+            collide_term<2>(p, v, o, lamw, radius, mu, kappa_sigma, RL(0.0), tau, y1, y2, dp, dv, nullptr, nullptr, dummy0,
+                            dummy1, c_ir, c_gpg);
+            yp[0] = make_double2((double)y1, (double)y2);
         }
     }
 }
@@ -654,7 +673,7 @@ __device__ __forceinline__ real next_mu(real mu, real mu_min, real kappa_mu) {
 }
 
 // The whole solve for one scene.  w0/w_out: decision vector [X_0,U_0,...,U_{N-1},X_N] in global
-// memory (warm start in, solution out; may alias).  info[4] as in the C ABI.  ybuf: [N][K][2] doubles of scratch.
+// memory (warm start in, solution out; may alias).  info[4] as in the C ABI.  ybuf: [N][K][YB] doubles of scratch.
 // Statement by statement the algorithm of DESIGN.md section 5, as the CPU restatement of the tests (one difference in bookkeeping only: an accepted first
 // line-search trial is evaluated WITH derivatives, so the next iteration finds q, r, H6 of its iterate in LDS).
 __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
@@ -698,7 +717,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     }
     if (lane < SD) sm[L.X + lane] = sm[L.xinit + lane];
     for (int e = lane; e < (N - 1) * K; e += 64)  // no collision term has multipliers yet
-        *reinterpret_cast<double2 *>(ybuf + (size_t)e * 2) = make_double2(-1.0, -1.0);
+        *reinterpret_cast<double2 *>(ybuf + (size_t)e * YB) = make_double2(-1.0, -1.0);
     __syncthreads();
     {  // rollout X_{k+1} = A X_k + B U_k + c
         const real *c = prm + PRM_C;

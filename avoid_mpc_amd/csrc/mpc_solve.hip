@@ -269,7 +269,7 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     const double *target = P + SD + SD * N + 3 * K * N;
     double *w = w0 + (size_t)s * nx;
     solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, plan_coef, plan_meta,
-                ybuf + (size_t)s * N * (K > 0 ? K : 1) * 2, gains + (size_t)s * N * GAIN_STAGE, s == 0 ? trace : nullptr);
+                ybuf + (size_t)s * N * (K > 0 ? K : 1) * kTermRecord, gains + (size_t)s * N * GAIN_STAGE, s == 0 ? trace : nullptr);
     __syncthreads();
     const int lane = threadIdx.x;
     if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
@@ -395,7 +395,7 @@ int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk
     if ((e = m->prm.alloc(PRM_LEN)) != hipSuccess ||
         (e = m->plan_coef.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 1) + 64 * 2)) != hipSuccess ||
         (e = m->plan_meta.alloc((size_t)PLAN_ITEMS * (PLAN_TERMS + 4) + 64 * LANE_META_INTS)) != hipSuccess || (e = m->w0.alloc((size_t)n_scenes * m->nx)) != hipSuccess ||
-        (e = m->ybuf.alloc((size_t)n_scenes * N * (m->K > 0 ? m->K : 1) * 2)) != hipSuccess ||
+        (e = m->ybuf.alloc((size_t)n_scenes * N * (m->K > 0 ? m->K : 1) * kTermRecord)) != hipSuccess ||
         (e = m->gains.alloc((size_t)n_scenes * N * GAIN_STAGE)) != hipSuccess ||
         (e = hipMemset(m->gains.p, 0, sizeof(double) * (size_t)n_scenes * N * GAIN_STAGE)) != hipSuccess ||
         (e = hipMemset(m->w0.p, 0, sizeof(double) * (size_t)n_scenes * m->nx)) != hipSuccess ||
