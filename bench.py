@@ -391,8 +391,8 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(solve_ms, 4), "launches": cnt[5],
                          "alg_bytes_per_launch": alg_launch,
                          "note": "dominant kernel by time, NOT bound by HBM: a serial interior-point solve per wavefront, "
-                                 "limited by fp64 VALU issue / dependent latency and LDS traffic (roofline_solve_issue, "
-                                 "DESIGN.md section 5); avg_launch_ms is submit-to-complete on the launch stream with the "
+                                 "limited by dependent fp64 / LDS latency at the 8 waves per CU its LDS footprint allows "
+                                 "(roofline_solve_issue, DESIGN.md section 5); avg_launch_ms is submit-to-complete on the launch stream with the "
                                  "other in-flight steps sharing the chip"},
             "roofline_solve_issue": issue,
             "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (obstacle + edge launch averaged)",

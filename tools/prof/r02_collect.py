@@ -86,12 +86,24 @@ issue = {
     "lds_array_busy_cycles_per_wave": b["SQ_LDS_IDX_ACTIVE"] / waves,
     "lds_bank_conflict_frac_of_lds_busy": b["SQ_LDS_BANK_CONFLICT"] / b["SQ_LDS_IDX_ACTIVE"],
     "lds_busy_frac_of_wave_time": b["SQ_LDS_IDX_ACTIVE"] / (4 * a["SQ_WAVE_CYCLES"]),
-    "bound": "fp64 VALU issue + dependent-operation latency, then LDS: one wave alone issues VALU 40 % of its time and waits "
-             "37 %; with the 6 waves per CU that LDS allows (1.5 per SIMD) the VALU issue ports run at ~60 % and the LDS array "
-             "at ~55 %: the kernel is inside 2x of both ceilings at once, and neither HBM nor MFMA is involved",
 }
-issue["valu_issue_util_per_simd_at_6_waves_per_cu"] = 1.5 * issue["frac_of_wave_time_issuing_valu"]
-issue["lds_array_util_per_cu_at_6_waves_per_cu"] = 6 * issue["lds_busy_frac_of_wave_time"]
+# saturated solve-only rate (tools/experiments/ms_parts.py: 16 streams x 256 scenes, 8 waves per CU): solves per us, chip
+SAT = float(os.environ.get("AMK_SAT_SOLVES_PER_US", "2.35"))
+clk_per_solve_per_cu = 256 * 2400.0 / SAT          # 256 CUs, 2.4 GHz
+issue["saturated_solves_per_us (ms_parts.py, 8 waves per CU)"] = SAT
+issue["valu_issue_util_at_saturation"] = issue["valu_instructions_per_wave_solve"] * 4 / 4 / clk_per_solve_per_cu
+issue["lds_array_util_at_saturation (conflict level of the lone wave)"] = issue["lds_array_busy_cycles_per_wave"] / clk_per_solve_per_cu
+issue["wave_time_stretch_at_saturation"] = 8 * clk_per_solve_per_cu / issue["wave_cycles_per_wave"]
+issue["bound"] = ("dependent-operation latency at limited occupancy: a wave alone issues VALU %.0f %% of its time, LDS %.0f %%, "
+                  "and waits %.0f %%; LDS capacity (19.8 KB per scene) allows 8 waves per CU = 2 per SIMD, and at that occupancy "
+                  "the VALU pipes are %.0f %% busy and the LDS array %.0f %% -- neither is saturated, a wave just runs %.2fx "
+                  "slower than alone because its dependent fp64 operations and LDS round trips interleave with one other "
+                  "wave's; HBM and MFMA are not involved" % (
+                      100 * issue["frac_of_wave_time_issuing_valu"], 100 * issue["frac_of_wave_time_issuing_lds"],
+                      100 * issue["frac_of_wave_time_waiting (s_waitcnt / barrier)"],
+                      100 * issue["valu_issue_util_at_saturation"],
+                      100 * issue["lds_array_util_at_saturation (conflict level of the lone wave)"],
+                      issue["wave_time_stretch_at_saturation"]))
 json.dump(issue, open(os.path.join(dst, "r02_pmc_solve_issue.json"), "w"), indent=1)
 with open(os.path.join(dst, "r02_pmc_solve_issue.md"), "w") as f:
     f.write("What bounds `mpc_solve_kernel` (SQ counters, single stream: one wave per CU).\n\n| quantity | value |\n|---|---|\n")
