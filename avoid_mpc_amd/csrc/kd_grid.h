@@ -82,7 +82,11 @@ struct RawSrc {
     float *pmax_out; // [1] max |coordinate| of the kept points
     __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const {
         const float *q = p + (size_t)i * stride;
+#ifdef AMK_BUILD_NT_LOADS  // experiments: streaming hint on the cloud reads (do they evict the solves' L2-resident scratch?)
+        x = __builtin_nontemporal_load(q); y = __builtin_nontemporal_load(q + 1); z = __builtin_nontemporal_load(q + 2);
+#else
         x = q[0]; y = q[1]; z = q[2];
+#endif
     }
     __device__ __forceinline__ int group_base(int g) const { return grp[g]; }
 };
@@ -270,7 +274,11 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
                 gpt4[pos >= 0 ? i : 0] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
 #else
                 const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
+#ifdef AMK_BUILD_NT_STORES
+                __builtin_nontemporal_store(make_float4(x[j], y[j], z[j], __int_as_float(idx)), &gpt4[pos]);
+#else
                 gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));  // one 16-byte store per point
+#endif
 #endif
             }
         }

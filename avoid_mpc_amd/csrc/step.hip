@@ -314,6 +314,11 @@ __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
 
 }  // namespace
 
+// Internal (tools/experiments, bench.py AMK_BENCH_SKIP): leave kernel classes out of amk_step_batch to see what each costs
+// with the others in flight -- bit 0 queries, bit 1 plan/pack, bit 2 solves.  Results are garbage while set.
+static int g_diag_skip = 0;
+extern "C" void amk__diag_skip(int mask) { g_diag_skip = mask; }
+
 extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *prm,
                               const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
                               double *d_x0array, int *d_flags, void *stream_) {
@@ -349,7 +354,8 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     const int ex_obs = use_grid && obstacle->tie_order && obstacle->ex_vind.p, ex_edge = use_grid && edge->tie_order && edge->ex_vind.p;
     const ExactPtrs eobs = ex_obs ? amk_exact_ptrs(obstacle) : ExactPtrs{}, eedge = ex_edge ? amk_exact_ptrs(edge) : ExactPtrs{};
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
-        if (use_grid) {
+        if (g_diag_skip & 1) {
+        } else if (use_grid) {
             TimedLaunch tl(KC_SCAN_OBS, stream);
             hipLaunchKernelGGL(step_knn_grid_kernel, dim3(S8 * ((N + 4) / 4)), dim3(256), 0, stream, gobs, gedge, S,
                                d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
@@ -368,7 +374,7 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            edge->y.p, edge->z.p, edge->cap, edge->size.p, edge->pmax.p, S, d_ref_path, N, 1, 1,
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         }
-        { TimedLaunch tl(KC_PLAN, stream);
+        if (!(g_diag_skip & 2)) { TimedLaunch tl(KC_PLAN, stream);
         hipLaunchKernelGGL(ex_obs ? step_plan_pack_kernel<true> : step_plan_pack_kernel<false>, dim3(S), dim3(kWave), 0, stream,
                            gobs, use_grid, eobs, obstacle->x.p,
                            obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
@@ -376,6 +382,7 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
                            mpc->ref_states.p, mpc->done.p, d_flags); }
         AMK_HIP(hipGetLastError());
+        if (g_diag_skip & 4) continue;
         int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
         if (st != AMK_OK) return st;
     }

@@ -299,6 +299,8 @@ def main():
     for _ in range(nslots):                # untimed priming: every slot allocates its workspace once
         one_step()
     barrier()
+    if DIAG_SKIP in ("knn", "plan", "solve", "knn+plan"):   # diagnostics: kernel classes left out of the step from here on
+        lib.amk__diag_skip({"knn": 1, "plan": 2, "solve": 4, "knn+plan": 3}[DIAG_SKIP])
     for _ in range(args.warmup):
         one_step()
     barrier()

@@ -39,6 +39,16 @@ torch.cuda.synchronize()
 ts=run(solve,30,None,0); tb=run(None,0,build,10); tk=run(None,0,knn,30)
 print(f'alone: 30x{NS} solves {ts:.1f} ms ({ts*1e3/30/NS:.0f} us each); 10x{NS} builds {tb:.1f} ms ({tb*1e3/10/NS:.0f} us each); 30x{NS} knn {tk:.1f} ms ({tk*1e3/30/NS:.0f} us each)')
 t=run(solve,30,build,10); print(f'solves + builds on separate streams: {t:.1f} ms (sum {ts+tb:.1f}, max {max(ts,tb):.1f})')
+# when does each class finish inside the combined run?  (events on the last kernel of every stream)
+torch.cuda.synchronize(); e0=torch.cuda.Event(enable_timing=True); e0.record()
+for r in range(30):
+    for i in range(NS):
+        solve(i)
+        if r<10: build(i)
+ea=[torch.cuda.Event(enable_timing=True) for _ in range(NS)]; eb=[torch.cuda.Event(enable_timing=True) for _ in range(NS)]
+for i in range(NS): ea[i].record(sa[i]); eb[i].record(sb[i])
+torch.cuda.synchronize()
+print(f'  inside the combined run: builds done after {max(e0.elapsed_time(x) for x in eb):.1f} ms (alone {tb:.1f}), solves after {max(e0.elapsed_time(x) for x in ea):.1f} ms (alone {ts:.1f})')
 t=run(solve,30,knn,30); print(f'solves + knn on separate streams: {t:.1f} ms (sum {ts+tk:.1f}, max {max(ts,tk):.1f})')
 sa2=sa; 
 def knn_a(i): kouts[i]=kds[i].search(q,8,stream=sa[i],out=kouts[i])
