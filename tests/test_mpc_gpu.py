@@ -120,3 +120,32 @@ def test_host_api_and_errors(torch_cuda):
         uc, xc, ic = m.Solve(ref[s])
         assert np.abs(u[s] - uc).max() <= TOL and np.abs(x0[s] - xc).max() <= TOL
     assert lib.amk_mpc_destroy(h) == 0
+
+
+@pytest.mark.parametrize("N,K", [(7, 3), (15, 8), (23, 5), (32, 2)])
+def test_generic_horizon_kernel_matches_oracle(N, K, torch_cuda):
+    """Horizons other than the baked 10 / 20 / 30 run the generic instantiation (LDS offsets and the forward roll's
+    prefetch ring at run-time N; 7 and 23 are not multiples of the prefetch depth, 32 is AMK_MAX_HORIZON)."""
+    torch = torch_cuda
+    from avoid_mpc_amd.host import MpcBatch
+    prm = synth.MpcParams(T=N * 0.033 + 1e-4, K=K)
+    assert prm.N == N
+    seeds = list(range(400, 408))
+    logs = _scene_inputs(5000, seeds, prm)
+    ref = np.stack([l[0] for l in logs])
+    gpu = MpcBatch(prm.T, prm.dt, prm.K, len(seeds)); gpu.configure(prm)
+    u, x0, info = gpu.Solve(torch.from_numpy(ref).cuda(), faster=True)
+    torch.cuda.synchronize()
+    u, x0, info = u.cpu().numpy(), x0.cpu().numpy(), info.cpu().numpy()
+    worst, flipped = 0.0, 0
+    for s in range(len(seeds)):
+        m = _oracle.MpcOracle(prm.T, prm.dt, prm.K); m.configure(prm)
+        uc, xc, ic = m.Solve(ref[s], True)
+        d = max(np.abs(u[s] - uc).max(), np.abs(x0[s] - xc).max())
+        if np.array_equal(info[s], ic):
+            worst = max(worst, d)
+        else:
+            flipped += 1
+            assert d <= 1e-4, (N, s, info[s], ic, d)
+    print(f"N = {N}, K = {K}: max |gpu - oracle| = {worst:.3e}, flipped {flipped}/{len(seeds)}")
+    assert worst <= TOL and flipped <= 1

@@ -43,4 +43,6 @@ for w in (1, 2, 4):
     print("lds hog, %d waves/CU:    %.2f solves/us" % (w, run(lambda: hogs.launch_lds_hog(256 * w, 400000, C.c_void_p(sink.data_ptr()), sp))))
 for w in (1, 2, 4):
     print("valu hog, %d waves/CU:   %.2f solves/us" % (w, run(lambda: hogs.launch_valu_hog(256 * w, 200000, C.c_void_p(sink.data_ptr()), sp))))
-print("mem hog (copy 256 MB x40): %.2f solves/us" % run(lambda: hogs.launch_mem_hog(2048, C.c_void_p(big.data_ptr()), C.c_void_p(big2.data_ptr()), C.c_size_t(big.numel() // 16), 40, sp)))
+for blocks in (512, 2048):   # the copy must outlast the measurement window (~15 ms): 256 MB x 400 at <= 5 TB/s = 40+ ms
+    print("mem hog (copy 256 MB x400, %d blocks of 256): %.2f solves/us" % (blocks, run(lambda: hogs.launch_mem_hog(blocks, C.c_void_p(big.data_ptr()), C.c_void_p(big2.data_ptr()), C.c_size_t(big.numel() // 16), 400, sp))))
+    torch.cuda.synchronize()
