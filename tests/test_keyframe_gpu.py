@@ -10,7 +10,11 @@ from avoid_mpc_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def test_sweep_matches_oracle():
+@pytest.mark.parametrize("tie_order", [0, 1])
+def test_sweep_matches_oracle(tie_order):
+    """tie_order = 1: clouds on a 0.05 m lattice (equal squared distances are common) and both handles in
+    AMK_TIES_NANOFLANN mode -- the keyframe rebuilt by the sweep must then also return nanoflann's INDEX lists (its
+    reference-shaped tree is rebuilt from the compacted planes)."""
     import torch
     from avoid_mpc_amd.host import KdBatch
     rng = np.random.default_rng(5)
@@ -27,6 +31,8 @@ def test_sweep_matches_oracle():
             kf = cur.copy()                           # identical: no outliers -> no rebuild
         if s == 5:
             cur = cur[:1]                             # current tree with one point: SearchForNearest(.,1) gives nothing
+        if tie_order:
+            kf = np.round(kf * 20) / 20; cur = np.round(cur * 20) / 20
         scenes.append((kf.astype(np.float32), cur.astype(np.float32)))
     S = len(scenes)
     nk = max(len(k) for k, _ in scenes); nc = max(len(c) for _, c in scenes)
@@ -35,12 +41,15 @@ def test_sweep_matches_oracle():
     for s, (k, c) in enumerate(scenes):
         kb[s, :len(k)] = k; kn[s] = len(k); cb[s, :len(c)] = c; cn[s] = len(c)
     kd_k, kd_c = KdBatch(S, nk), KdBatch(S, nc)
+    kd_k.set_tie_order(tie_order); kd_c.set_tie_order(tie_order)
     kd_k.build(torch.from_numpy(kb).cuda(), torch.from_numpy(kn).cuda())
     kd_c.build(torch.from_numpy(cb).cuda(), torch.from_numpy(cn).cuda())
     outl, reb = kd_k.keyframe_sweep(kd_c, th_dist, th_count)
     torch.cuda.synchronize()
     outl, reb, sizes = outl.cpu().numpy(), reb.cpu().numpy(), kd_k.sizes()
     qs = np.stack([rng.uniform(0, 20, (S, 16)), rng.uniform(-6, 6, (S, 16)), rng.uniform(0, 4, (S, 16))], -1)
+    if tie_order:
+        qs = np.round(qs * 40) / 40
     res = kd_k.search(torch.from_numpy(qs).cuda(), 8)
     torch.cuda.synchronize()
     for s, (k, c) in enumerate(scenes):
