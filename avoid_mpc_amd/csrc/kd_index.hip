@@ -87,7 +87,10 @@ __device__ __forceinline__ void sample_bbox_scene(int s, const float *__restrict
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     constexpr int NW = kCompactThreads / kWave;
     __shared__ float wave_bb[6][NW];
-    const int step = n >= 16384 ? 16 : 1;
+#ifndef AMK_BBOX_STEP
+#define AMK_BBOX_STEP 16
+#endif
+    const int step = n >= 16384 ? AMK_BBOX_STEP : 1;
     float bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     for (int t = tid; (long long)t * step < n; t += kCompactThreads) {
         const float *p = src + (size_t)t * step * point_stride;

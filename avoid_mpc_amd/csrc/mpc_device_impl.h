@@ -426,10 +426,11 @@ __device__ __forceinline__ void update_term_multipliers(real *sm, const LdsMap &
     }
 }
 
+#ifdef AMK_ADJOINT_SEQ  // the sequential sweep the scans below replaced (kept for A/B: tools/experiments/ab_solve.sh)
 // Reduced gradient gU_k = r_k + B' lam_{k+1} by the adjoint sweep lam_k = q_k + A' lam_{k+1}, lam_N = q_N (oracle
 // eval_iterate).  Lane i < 10 owns lam[i], lanes 10..13 own gU[a]; column i of A / a of B has <= 3 non-zero rows
 // (rows_of_A / rows_of_B), read from a double-buffered copy of lam_{k+1} in LDS: one barrier per stage.
-__device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N, const double *prm_g) {
+__device__ __forceinline__ void adjoint_sweep_seq(real *sm, const LdsMap &L, int N, const double *prm_g) {
     int lane = threadIdx.x;
     asm volatile("" : "+v"(lane));  // the lane's coefficients are re-derived per sweep: hoisted out of the iteration loop
                                     // they would be live across the objective evaluation, which sets the register peak
@@ -459,6 +460,73 @@ __device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N, 
         }
         __syncthreads();
     }
+}
+#endif
+
+// value of lane k + d of the same 32-lane half (0 beyond it): two ds_bpermute per double, no LDS memory
+__device__ __forceinline__ real half_shift_down(real v, int d, int k) {
+    const real y = __shfl_down(v, d, 32);
+    return (k + d < 32) ? y : RL(0.0);
+}
+// x_e <- sum_{j >= 0} alpha^j x_{e+j} over the 32 lanes of a half (suffix scan of the recurrence x_e = b_e + alpha x_{e+1})
+__device__ __forceinline__ void suffix_scan2(real &x0, real &x1, real al0, real al1, int k) {
+#pragma unroll
+    for (int d = 1; d < 32; d <<= 1) {
+        const real y0 = half_shift_down(x0, d, k), y1 = half_shift_down(x1, d, k);
+        x0 = fma(al0, y0, x0);
+        x1 = fma(al1, y1, x1);
+        al0 *= al0;
+        al1 *= al1;
+    }
+}
+
+// The same reduced gradient without the N sequential stages.  The dynamics are chains p_a <- v_a <- c_a <- u_a per axis
+// (+ yaw <- u_3; build_plan checks it), so the adjoint recursion splits into scalar first-order recurrences with CONSTANT
+// coefficients, level by level:  lam_p[m] = q_p[m] + A_pp lam_p[m+1];  lam_v[m] = q_v[m] + A_pv lam_p[m+1] + A_vv lam_v[m+1];
+// lam_c[m] = q_c[m] + A_pc lam_p[m+1] + A_vc lam_v[m+1] + A_cc lam_c[m+1]  (m = N .. 1, lam[N+1] = 0), each a suffix scan:
+// 5 shuffle + FMA steps for up to 32 stages.  Lane = (half h, element e = m - 1); a lane carries two channels (axes 2h and
+// 2h + 1: x, y | z, yaw).  gU_e[a] = r_e[a] + B_pa lam_p[e+1] + B_va lam_v[e+1] + B_ca lam_c[e+1] needs no shift.
+// 10 LDS accesses and 72 ds_bpermute per sweep instead of 120 LDS accesses and 20 dependent stages; sums are taken in
+// a different order than the sequential recursion (relative differences ~1e-16).
+__device__ __forceinline__ void adjoint_sweep(real *sm, const LdsMap &L, int N, const double *prm_g) {
+    int lane = threadIdx.x;
+    asm volatile("" : "+v"(lane));  // the lane's coefficients are re-derived per sweep: hoisted out of the iteration loop
+                                    // they would be live across the objective evaluation, which sets the register peak
+    const double *A = prm_g + PRM_A, *B = prm_g + PRM_B;
+    const int h = lane >> 5, e = lane & 31;
+    const int a0 = 2 * h, a1 = 2 * h + 1;       // control / axis of the two channels; a1 == 3 is the yaw channel
+    const bool yaw1 = a1 == 3;
+    const int p0 = a0, v0 = 4 + a0, c0 = 7 + a0;
+    const int p1 = a1, v1 = yaw1 ? 3 : 4 + a1, c1 = yaw1 ? 3 : 7 + a1;
+    const bool on = e < N;
+    const real *qe = sm + L.q + (on ? e + 1 : 1) * SD;  // q_m, m = e + 1
+    // level p
+    real lp0 = on ? qe[p0] : RL(0.0), lp1 = on ? qe[p1] : RL(0.0);
+    suffix_scan2(lp0, lp1, (real)A[p0 * SD + p0], (real)A[p1 * SD + p1], e);
+    // level v
+    const real sp0 = half_shift_down(lp0, 1, e), sp1 = half_shift_down(lp1, 1, e);  // lam_p[m+1]
+    real lv0 = on ? fma((real)A[p0 * SD + v0], sp0, qe[v0]) : RL(0.0);
+    real lv1 = (on && !yaw1) ? fma((real)A[p1 * SD + v1], sp1, qe[v1]) : RL(0.0);
+    suffix_scan2(lv0, lv1, (real)A[v0 * SD + v0], yaw1 ? RL(0.0) : (real)A[v1 * SD + v1], e);
+    // level c
+    const real sv0 = half_shift_down(lv0, 1, e), sv1 = half_shift_down(lv1, 1, e);
+    real lc0 = on ? fma((real)A[v0 * SD + c0], sv0, fma((real)A[p0 * SD + c0], sp0, qe[c0])) : RL(0.0);
+    real lc1 = (on && !yaw1) ? fma((real)A[v1 * SD + c1], sv1, fma((real)A[p1 * SD + c1], sp1, qe[c1])) : RL(0.0);
+    suffix_scan2(lc0, lc1, (real)A[c0 * SD + c0], yaw1 ? RL(0.0) : (real)A[c1 * SD + c1], e);
+    if (on) {
+        const real *re = sm + L.r + e * UD;
+        real g0 = fma((real)B[p0 * UD + a0], lp0, re[a0]);
+        g0 = fma((real)B[v0 * UD + a0], lv0, g0);
+        g0 = fma((real)B[c0 * UD + a0], lc0, g0);
+        real g1 = fma((real)B[p1 * UD + a1], lp1, re[a1]);
+        if (!yaw1) {
+            g1 = fma((real)B[v1 * UD + a1], lv1, g1);
+            g1 = fma((real)B[c1 * UD + a1], lc1, g1);
+        }
+        sm[L.gU + e * UD + a0] = g0;
+        sm[L.gU + e * UD + a1] = g1;
+    }
+    __syncthreads();
 }
 
 struct LanePlan {                // the two items + the role of this lane, in registers for one backward sweep
@@ -748,7 +816,11 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
                                      : evaluate<true>(sm, L, io, N, K, sm + L.X, sm + L.U, mu, o_kappa_sigma,
                                                       o_maj * mu / o_mu_init, ybuf, acc, tclk);
         __syncthreads();
+        #ifdef AMK_ADJOINT_SEQ
+        adjoint_sweep_seq(sm, L, N, prm_g);
+#else
         adjoint_sweep(sm, L, N, prm_g);
+#endif
         return J + box_errors(sm, L, nvar, mu, o_s_max, acc, err);
     };
     // starting barrier parameter: the duals start on the central path of whatever mu is chosen, so mu_init is lowered
