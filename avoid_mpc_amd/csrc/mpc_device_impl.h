@@ -570,16 +570,13 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
     // solve: it is dead weight (~90 VGPRs) during the objective evaluation, which sets the register peak
     LanePlan lp;
     load_lane_plan(lp, plan_coef, plan_meta);
-    real *P = sm + L.P, *pv = sm + L.p, *lam = sm + L.lam;
+    real *P = sm + L.P, *pv = sm + L.p;
     // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
     for (int e = lane; e < 100; e += 64) {
         const int i = e / 10, j = e % 10;
         P[e] = (i == j) ? RL(2.0) * sm[L.prm + PRM_W + i] + delta : RL(0.0);
     }
-    if (lane < SD) {
-        pv[lane] = sm[L.q + N * SD + lane];
-        lam[lane] = pv[lane];
-    }
+    if (lane < SD) pv[lane] = sm[L.q + N * SD + lane];
     if (lane == 0) sm[L.red + 10] = RL(0.0);  // the zero cell of the plan
     __syncthreads();
     const LaneRole &R = lp.role;
@@ -626,7 +623,6 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
             }
             const real b0 = sm[R.b_idx[0] + k * R.b_ks[0]], b1 = sm[R.b_idx[1] + k * R.b_ks[1]];
             const real b2 = sm[R.b_idx[2] + k * R.b_ks[2]];
-            const real lamv = sm[R.lam_src];
             const real c00 = h11 * h22 - h21 * h21, c10 = h21 * h20 - h10 * h22, c20 = h10 * h21 - h11 * h20;
             const real c11 = h00 * h22 - h20 * h20, c21 = h10 * h20 - h00 * h21, c22 = h00 * h11 - h10 * h10;
             const real det = (h00 * c00 + h10 * c10) + h20 * c20;
@@ -646,8 +642,6 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
             }
             if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
                 sm[R.out1] = val;
-                sm[R.out2] = val;
-                sm[R.lam_dst] = lamv;
             }
         }
         __syncthreads();

@@ -98,7 +98,7 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
             if (Lf[l * ls + ci] == 0.0) continue;
             for (int mm = 0; mm < SD; ++mm) {
                 if (Rf[mm * rs + cj] == 0.0 || zeroP(l, mm)) continue;
-                t.push_back({L.P + l * 10 + mm, Lf[l * ls + ci] * Rf[mm * rs + cj]});
+                t.push_back({L.P + (l >= mm ? l * 10 + mm : mm * 10 + l), Lf[l * ls + ci] * Rf[mm * rs + cj]});  // P is symmetric: only its lower triangle is kept current
             }
         }
         return t;
@@ -125,11 +125,10 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
             auto t = mat_terms(B, UD, a, A, SD, j);
             if (!t.empty()) items.push_back({t, L.G + a * 10 + j, 0, ZERO, 0, 0.0});
         }
-    // q_k + A'p and q_k + A'lam (= lam_k): the stage gradient rides in as the per-stage addend
+    // q_k + A'p: the stage gradient rides in as the per-stage addend (the reduced gradient gU = r + B'lam is the adjoint
+    // scans' job, mpc_device_impl.h: adjoint_sweep)
     for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.p), L.Atp + i, 0, L.q + i, SD, 0.0});
-    for (int i = 0; i < SD; ++i) items.push_back({vec_terms(A, SD, i, L.lam), L.Atl + i, 0, L.q + i, SD, 0.0});
     for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.p), L.qu + a, 0, L.rb + a, UD, 0.0});
-    for (int a = 0; a < UD; ++a) items.push_back({vec_terms(B, UD, a, L.lam), L.gU + a, UD, L.r + a, UD, 0.0});
     if ((int)items.size() > PLAN_ITEMS) return AMK_ERR_UNSUPPORTED;
     // heavy items first: lane l executes items l (<= 9 terms) and 64 + l (<= PLAN_TERMS_LIGHT terms)
     std::stable_sort(items.begin(), items.end(), [](const Item &a, const Item &b) { return a.t.size() > b.t.size(); });
@@ -186,7 +185,7 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
             r[4 + nb] = L.H6 - 21 + (pi >= pj ? pi * (pi + 1) / 2 + pj : pj * (pj + 1) / 2 + pi); r[7 + nb] = 21; ++nb;
         }
         lc[lane * 2 + 1] = (i == j) ? 1.0 : 0.0;  // + delta on the diagonal
-        r[10] = L.P + i * 10 + j; r[11] = L.P + j * 10 + i;
+        r[10] = L.P + i * 10 + j; r[11] = DUMMY;   // lower triangle (i >= j)
         if (i == j) r[12] = i;
     }
     if ((int)free_lanes.size() < SD) return AMK_ERR_UNSUPPORTED;
@@ -197,10 +196,6 @@ int build_plan(amk_mpc *m, std::vector<double> &coef, std::vector<int> &meta) {
         r[4] = L.Atp + i; r[7] = 0;
         r[10] = L.p + i; r[11] = L.p + i;
         if (i == 0) r[12] = SD;  // feed-forward column
-    }
-    for (int i = 0; i < SD; ++i) {  // lam_k = q_k + A'lam_{k+1}: a copy, ridden by lanes 0..9
-        int *r = lm + i * LANE_META_INTS;
-        r[13] = L.Atl + i; r[14] = L.lam + i;
     }
     return AMK_OK;
 }
