@@ -12,7 +12,7 @@
 //   fast_exp  k = rint(x / ln2), r = x - k ln2 (hi/lo), e^r = 1 + r + r^2 Q(r) with Q the degree-11 Taylor tail
 //             evaluated by Estrin's scheme (depth 4), scaled by 2^k with v_ldexp.  ~11 dependent operations.
 // Domain: fast_log wants a positive, finite, normal argument (every call site passes products of positive slacks or
-// 1 + e^x >= 1); anything else is handed to the library's log.  fast_exp clamps x to [-745.2, 709.7] (results 0 / inf
+// 1 + e^x >= 1); denormals are rescaled, 0 / inf / negative / NaN arguments get the IEEE answers by selects.  fast_exp clamps x to [-745.2, 709.7] (results 0 / inf
 // outside are not needed: the callers' arguments are bounded above by 32 x the drone radius).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -27,7 +27,19 @@ __device__ __forceinline__ double rcp_f64(double x) {  // 1/x, <= 1 ulp: v_rcp_f
 
 __device__ __forceinline__ double fast_log(double x) {
 #pragma clang fp contract(off)  // every step below is the IEEE operation it is written as (the tests' CPU restatement repeats them)
+#ifdef AMK_FAST_LOG_LIBRARY_FALLBACK  // (the library's log inlined at every call site: ~150 instructions each, 12 sites)
     if (!(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308)) return log(x);  // <= 0, denormal, inf, NaN
+#else
+    // outside the domain (never reached by the solver): NaN for negative / NaN, -inf for 0, +inf for +inf; a denormal is
+    // scaled into the normal range first
+    const bool special = !(x >= 2.2250738585072014e-308 && x <= 1.7976931348623157e308);
+    const double x_in = x;
+    double bias = 0.0;
+    if (special) {
+        if (x > 0.0 && x < 2.2250738585072014e-308) { x = x * 18014398509481984.0; bias = -54.0; }  // 2^54
+        else x = 1.0;
+    }
+#endif
     double m = __builtin_amdgcn_frexp_mant(x);  // [0.5, 1)
     int k = __builtin_amdgcn_frexp_exp(x);
     const bool lo = m < 0.70710678118654752440;
@@ -35,7 +47,11 @@ __device__ __forceinline__ double fast_log(double x) {
     k = lo ? k - 1 : k;
     const double f = m - 1.0;                   // exact
     const double s = f * rcp_f64(2.0 + f);
+#ifdef AMK_FAST_LOG_LIBRARY_FALLBACK
     const double dk = (double)k;
+#else
+    const double dk = (double)k + bias;
+#endif
     const double z = s * s, w = z * z;
     const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
     const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01),
@@ -43,7 +59,14 @@ __device__ __forceinline__ double fast_log(double x) {
     const double R = t2 + t1;
     const double hfsq = 0.5 * f * f;
     // log(1 + f) = f - hfsq + s (hfsq + R);  + k ln2 in two parts (ln2_hi has 21 trailing zero bits: k ln2_hi is exact)
-    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+    const double res = dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+#ifdef AMK_FAST_LOG_LIBRARY_FALLBACK
+    return res;
+#else
+    if (special && !(bias < 0.0))
+        return x_in == 0.0 ? -__builtin_huge_val() : (x_in > 1.0 ? __builtin_huge_val() : __builtin_nan(""));
+    return res;
+#endif
 }
 
 __device__ __forceinline__ double fast_exp(double x) {
