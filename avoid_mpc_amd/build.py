@@ -17,8 +17,11 @@ LIB = os.path.join(HERE, "libavoid_mpc_amd.so")
 RES = os.path.join(HERE, "kernel_resources.json")   # per-kernel VGPRs / scratch / LDS as the compiler reports them
 ARCH = "gfx950"
 
+# -amdgpu-sched-strategy=max-ilp: every hot kernel here is bound by dependent-operation latency at a fixed occupancy (the
+# solve's 2 waves per SIMD are set by LDS), so the machine scheduler should favour ILP over register economy; same-box A/B
+# of the bench: +1.2 % (tools/experiments/ab_solve.sh).
 FLAGS = ["--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result", "-mllvm", "-amdgpu-sched-strategy=max-ilp"]
 
 
 def hipcc():
