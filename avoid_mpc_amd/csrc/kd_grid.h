@@ -39,7 +39,7 @@ constexpr int kGridPointsPerCell = AMK_GRID_PPC;  // target occupancy of a cell
 #endif
 constexpr int kGridBuildThreads = AMK_BUILD_THREADS;
 #ifndef AMK_GRID_UNROLL
-#define AMK_GRID_UNROLL 8
+#define AMK_GRID_UNROLL 16  // points in flight per thread; 24 and more: the block's registers no longer fit beside a solve wave (tests/test_abi.py)
 #endif
 constexpr int kGridUnroll = AMK_GRID_UNROLL;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz

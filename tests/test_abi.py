@@ -74,3 +74,9 @@ def test_default_path_kernels_use_no_scratch_memory(lib):
             assert r["scratch_bytes_per_lane"] <= 2048, (name, r)
     solve = [r for n, r in table.items() if "mpc_solve_kernel" in n]
     assert solve and all(r["vgprs"] <= 256 for r in solve)
+    # a 512-thread index-build block is two waves per SIMD: it must fit beside ONE fp64 solve wave of the bench's horizon
+    # in the 512-register file of a SIMD (with 24 points in flight per thread it did not, and the step rate fell by a third)
+    build = [r for n, r in table.items() if n.startswith("_Z15kd_build_kernel")][0]
+    solve20 = [r for n, r in table.items() if "mpc_solve_kernelILi20" in n][0]
+    g = lambda v: (v + 7) // 8 * 8        # allocation granule
+    assert 2 * g(build["vgprs"]) + g(solve20["vgprs"]) <= 512, (build, solve20)
