@@ -365,6 +365,15 @@ def main():
                 if kk:
                     traffic = round(kk["hbm_bytes_per_launch_x2"])
                     traffic_src = f"profiles/{PROFILE_TAG}_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
+        lone_build = None   # the obstacle build alone on the chip (single-stream kernel trace): the kernel's own roofline
+        spath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_streams1.json")
+        if os.path.exists(spath) and (S, n) == (256, 50000):
+            kb1 = json.load(open(spath))["kernels"].get("kd_build_kernel")
+            if kb1:   # max = the obstacle launch (the edge launch is the min)
+                lone_build = {"obstacle_launch_us": kb1["max_us"], "alg_bytes": 28 * S * n,
+                              "achieved": round(28 * S * n / (kb1["max_us"] * 1e-6) / 1e9, 1), "unit": "GB/s",
+                              "frac": round(28 * S * n / (kb1["max_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                              "source": f"profiles/{PROFILE_TAG}_kernel_stats_streams1.md"}
         ipath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_solve_issue.json")
         if os.path.exists(ipath):
             issue = json.load(open(ipath))
@@ -402,7 +411,7 @@ def main():
                                   "launches": cnt[7], "achieved": round(build_alg / (build_ms * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(build_alg / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic": build_traffic,
+                                  "traffic": build_traffic, "single_stream": lone_build,
                                   "note": "the HBM-heavy kernel: algorithmic 28 B per point (12 read, 16 written as a bucket "
                                           "record); avg_launch_ms is submit-to-complete with the other in-flight steps "
                                           "sharing the chip (single-stream kernel times: profiles/)"},

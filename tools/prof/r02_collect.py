@@ -50,6 +50,13 @@ for sub, name, args in (("kt20", "r02_kernel_stats.md", "--steps 256 --no-cpu-ba
     rows = [l for l in md.splitlines() if l.startswith("|")]
     keep = rows[:2] + [l for l in rows[2:] if any(t in l for t in ("mpc_", "kd_", "step_", "rocclr"))]
     open(os.path.join(dst, name), "w").write(hdr % (args, tag) + "\n".join(keep) + "\n")
+    if sub == "kt1":   # the clean single-stream durations as json too (bench.py quotes the lone obstacle build from it)
+        st = {}
+        for l in keep[2:]:
+            c = [x.strip() for x in l.strip("|").split("|")]
+            st[c[0].strip("`")] = {"calls": int(c[1]), "avg_us": float(c[3]), "min_us": float(c[4]), "max_us": float(c[5])}
+        json.dump({"_source": "rocprofv3 --kernel-trace, bench.py --streams 1 (%s)" % tag, "kernels": st},
+                  open(os.path.join(dst, "r02_kernel_stats_streams1.json"), "w"), indent=1)
 out = io.StringIO()
 sys.stdout = out
 sys.argv = ["pmc_traffic.py", os.path.join(src, "pmc_fetch", "f_counter_collection.csv"),
