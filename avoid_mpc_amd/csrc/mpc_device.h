@@ -145,9 +145,9 @@ struct LaneRole {
     int gi, gi_stride;           // column "i": sm[gi + a * gi_stride], a < 4
     int gj, gj_stride;           // column "j"
     int b_idx[3], b_ks[3];       // base = bconst + bdelta * delta + sum_n sm[b_idx[n] + k * b_ks[n]]
-    int out1, out2;              // where the value goes (P[i][j] and P[j][i]; p[i] twice)
+    int out1, out2;              // where the value goes (lower-triangle P[i][j] / p[i]); out2: unused since only the lower triangle of P is kept current
     int gain_col;                // >= 0: this lane also stores column gain_col of the gains (-Hm^-1 g)
-    int lam_src, lam_dst;        // lam_k copy ridden by lanes 0..9
+    int lam_src, lam_dst;        // unused (the adjoint recursion is no longer carried by this sweep: adjoint_sweep's scans)
     int pad;
 };
 

@@ -556,7 +556,7 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
     lp.bdelta = plan_coef[PLAN_ITEMS * (PLAN_TERMS + 1) + 2 * lane + 1];
 }
 
-// Backward Riccati sweep (+ adjoint sweep for the reduced gradient gU).  Returns false when a
+// Backward Riccati sweep.  Returns false when a
 // control block is not positive definite.  Gains go to the scene's global scratch ([k][a][GAIN_ROW], column 10 =
 // feed-forward): stores that nothing in the sweep waits for.
 //
@@ -571,7 +571,7 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
     LanePlan lp;
     load_lane_plan(lp, plan_coef, plan_meta);
     real *P = sm + L.P, *pv = sm + L.p;
-    // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = lam = q_N
+    // terminal: P = Q_N + delta I = diag(2 Qgoal) + delta I, p = q_N
     for (int e = lane; e < 100; e += 64) {
         const int i = e / 10, j = e % 10;
         P[e] = (i == j) ? RL(2.0) * sm[L.prm + PRM_W + i] + delta : RL(0.0);
@@ -582,8 +582,7 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
     const LaneRole &R = lp.role;
 #pragma unroll 1
     for (int k = N - 1; k >= 0; --k) {
-        // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, q + A'lam,
-        // r_bar + B'p, r + B'lam)
+        // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, r_bar + B'p)
         {
             // item 0: up to 9 terms; item 1: up to 3 (the items are sorted by term count on the host: 460 terms in
             // 109 items, so the light half of the slots needs a third of the loads and FMAs)
