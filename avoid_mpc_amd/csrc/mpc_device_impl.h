@@ -584,8 +584,8 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
     for (int k = N - 1; k >= 0; --k) {
         // ---- round A: the two plan items of this lane (entries of A'PA, B'PB + R_bar, B'PA, q + A'p, r_bar + B'p)
         {
-            // item 0: up to 9 terms; item 1: up to 3 (the items are sorted by term count on the host: 460 terms in
-            // 109 items, so the light half of the slots needs a third of the loads and FMAs)
+            // item 0: up to 9 terms; item 1: up to 3 (the items are sorted by term count on the host: 431 terms in
+            // 95 items, so the light half of the slots needs a third of the loads and FMAs)
             real v[PLAN_TERMS], u[PLAN_TERMS_LIGHT], ax[2];
 #pragma unroll
             for (int t = 0; t < PLAN_TERMS; ++t) v[t] = sm[lp.idx[0][t]];
