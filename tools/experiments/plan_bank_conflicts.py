@@ -9,7 +9,7 @@ lib=capi.load()
 buf=(C.c_int*8192)()
 lib.amk__plan_dump.restype=C.c_int
 n=lib.amk__plan_dump(m.h, buf, 8192)
-meta=np.array(buf[:n])
+meta=np.array(buf[8:n])   # 8-int header: LDS offsets of P, p, lam, M, Hm, G, q and the total
 items=meta[:128*13].reshape(128,13)
 roles=meta[128*13:].reshape(64,16)
 def cost_b64(addrs):
