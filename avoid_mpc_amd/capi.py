@@ -14,7 +14,14 @@ AMK_MAX_K = 64
 AMK_MAX_QUERIES = 64
 AMK_MAX_HORIZON = 32
 AMK_MAX_OUTER_ITER = 8
-AMK_MPC_DEFAULT_MAX_ITER = 40
+AMK_MPC_DEFAULT_MAX_ITER = 100
+
+# the functions of the CasADi plugin ABI and the helper every one of them carries (include/avoid_mpc_amd/casadi_plugin.h)
+PLUGIN_FUNCTIONS = ["nlp", "nlp_f", "nlp_g", "nlp_grad_f", "nlp_jac_g", "nlp_hess_l", "nlp_grad"]
+PLUGIN_HELPERS = ["alloc_mem", "init_mem", "free_mem", "checkout", "release", "incref", "decref", "n_in", "n_out",
+                  "default_in", "name_in", "name_out", "sparsity_in", "sparsity_out", "work"]
+PLUGIN_SYMBOLS = [f for f in PLUGIN_FUNCTIONS] + [f + "_" + h for f in PLUGIN_FUNCTIONS for h in PLUGIN_HELPERS] + \
+                 ["amk_plugin_configure", "amk_plugin_dims"]
 
 # every symbol include/avoid_mpc_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
@@ -27,7 +34,8 @@ SYMBOLS = [
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
-    "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
+    "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_mpc_np", "amk_mpc_eval_gamma",
+    "amk_mpc_eval_gamma_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -119,6 +127,9 @@ def load():
         "amk_mpc_hess_sparsity": (i, [vp, vp, vp]),
         "amk_mpc_eval": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "amk_mpc_eval_host": (i, [vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "amk_mpc_np": (i, [vp]),
+        "amk_mpc_eval_gamma": (i, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "amk_mpc_eval_gamma_host": (i, [vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_frames": (i, [vp, vp, i, vp, C.POINTER(FrameCamera), vp, C.POINTER(StepParams), vp, vp, vp, vp, vp,

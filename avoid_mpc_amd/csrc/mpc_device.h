@@ -52,7 +52,7 @@ constexpr int PRM_LEN = 192;
 
 struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the tests carries the same defaults
     double tol;       // ipopt.tol            HighLvlMpc.cpp:19
-    int max_iter;     // iteration cap of THIS method (default 40); the reference's ipopt.max_iter = 10 counts IPOPT's
+    int max_iter;     // iteration cap of THIS method (default AMK_MPC_DEFAULT_MAX_ITER); the reference's ipopt.max_iter = 10 counts IPOPT's
     int max_ls;       // 12
     double mu_init;   // 0.1  (IPOPT default)
     double bound_push, bound_frac;  // 1e-3 (IPOPT warm_start_bound_push / _frac)

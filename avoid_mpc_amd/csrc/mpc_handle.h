@@ -19,6 +19,10 @@ struct amk_mpc {
     amk::DevBuf<int> plan_meta;     // [PLAN_ITEMS] PlanItemMeta + [64] LaneRole
     // staging for amk_mpc_eval_host
     amk::DevBuf<double> ev_w, ev_ref, ev_out;
+    // amk_mpc_eval_gamma: d(A, B, c)/d tau ([3][150], recomputed when tau changes) and its host staging
+    amk::DevBuf<double> ev_dtau, ev_gam;
+    double ev_dtau_tau[4] = {0, 0, 0, 0};
+    bool ev_dtau_valid = false;
     // staging for amk_mpc_solve_host
     amk::DevBuf<double> st_ref, st_u, st_x0;
     amk::DevBuf<int> st_info;

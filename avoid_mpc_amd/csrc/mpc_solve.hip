@@ -277,7 +277,7 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
         for (int e = lane; e < SD * N; e += 64) ref_path[(size_t)s * SD * N + e] = sm[L.X + e];
     if (step_flags && lane == 0) {
         step_flags[4 * s + 1] += 1;
-        step_flags[4 * s + 2] = sm_status(sm, L);
+        step_flags[4 * s + 2] = max(step_flags[4 * s + 2], sm_status(sm, L));  // worst status over the step's solves
         step_flags[4 * s + 3] += sm_iters(sm, L);
     }
 }

@@ -39,7 +39,7 @@ typedef enum amk_status {
 #define AMK_MAX_HORIZON 32  /* N = int(T/dt); reference default 30                               */
 #define AMK_S_DIM 10        /* [px,py,pz,yaw,vx,vy,vz,ax,ay,az]  mpc_obstacle_casadi.py:41-46    */
 #define AMK_U_DIM 4         /* [ax_cmd,ay_cmd,az_cmd,yaw_dot]    mpc_obstacle_casadi.py:75       */
-#define AMK_MPC_DEFAULT_MAX_ITER 40 /* iteration cap of this library's interior-point method (see amk_mpc_create) */
+#define AMK_MPC_DEFAULT_MAX_ITER 100 /* iteration cap of this library's interior-point method (see amk_mpc_create) */
 
 int amk_version(void);
 const char *amk_status_string(int status);
@@ -136,8 +136,10 @@ typedef struct amk_mpc amk_mpc;
  * create are the constructor's: weights/tau/gains of HighLvlMpc.cpp:53-56, control bounds
  * [-10,-10,1,-10]..[10,10,20,10] (:13-16,29-30), zero warm start (:26-27,35), tol 1e-4 (:19).
  * The iteration cap defaults to AMK_MPC_DEFAULT_MAX_ITER, not to the reference's ipopt.max_iter = 10 (:20): that
- * number counts IPOPT's iterations, which this library does not reproduce; the default is
- * what brings >= 90 % of cold starts within 1e-3 of the converged optimum (tests/test_mpc_parity_gpu.py).      */
+ * number counts IPOPT's iterations, which this library does not reproduce.  The default is a
+ * safety net, not a budget: a solve runs until its last barrier problem is solved to tol (mean 10 / 21 / 25 iterations
+ * at N = 10 / 20 / 30, the slowest of 1024 + 64 + 256 bench scenes 54; a cap of 40 cut 1.5 % of the cold starts short).
+ * A solve that does hit the cap reports status 1 (amk_mpc_solve: info[0]; amk_step_batch: flags[2]).              */
 int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out);
 int amk_mpc_destroy(amk_mpc *mpc);
 int amk_mpc_horizon(const amk_mpc *mpc);   /* N                                                  */
@@ -202,6 +204,20 @@ int amk_mpc_eval(amk_mpc *mpc, const double *d_w, const double *d_ref_states, co
 int amk_mpc_eval_host(amk_mpc *mpc, const double *h_w, const double *h_ref_states, const double *h_lam_f, double *h_f,
                       double *h_grad_f, double *h_g, double *h_jac_g, double *h_hess_l);
 
+/* nlp_grad, the sixth function CasADi's generate_dependencies emits for an nlpsol (mpc_obstacle_casadi.py:294-303): with
+ * gamma(x, p) = lam_f f + lam_g' g,
+ *   d_grad_x [S][nx]  grad_x gamma = lam_f grad f + (dg/dx)' lam_g
+ *   d_grad_p [S][np]  grad_p gamma over the WHOLE parameter vector p = [P prefix (nref) | gain(4) | tau(4) | weights(25) |
+ *                     radius], np = nref + 34 (:76-85): what nlpsol reports as lam_p.  The tail's values are taken from the
+ *                     handle (setters), its derivatives are returned here; d/d gain = d/d tau_yaw = 0 (unused by the model,
+ *                     :114-121), d/d tau through the RK4 map (dual-number probe of the same integrator).
+ *   d_lam_f [S] or NULL (= 1);  d_lam_g [S][ng] or NULL (= 0).  Either output may be NULL.                                  */
+int amk_mpc_np(const amk_mpc *mpc);
+int amk_mpc_eval_gamma(amk_mpc *mpc, const double *d_w, const double *d_ref_states, const double *d_lam_f,
+                       const double *d_lam_g, double *d_grad_x, double *d_grad_p, void *stream);
+int amk_mpc_eval_gamma_host(amk_mpc *mpc, const double *h_w, const double *h_ref_states, const double *h_lam_f,
+                            const double *h_lam_g, double *h_grad_x, double *h_grad_p);
+
 /* ------------------------------------------------------------------------------------------ */
 /* One control step: TASK branch of AvoidanceStateMachine::Step       AvoidanceStateMachine.cpp */
 /* ------------------------------------------------------------------------------------------ */
@@ -225,8 +241,12 @@ typedef struct amk_step_params {
  *   d_ref_path      [S][N][10] in/out      mRefPath (after GetInitPath on entry)
  *   d_u             [S][4]                 control of the last solve
  *   d_x0array       [S][N][14]             predicted trajectory of the last solve (may be NULL)
- *   d_flags         [S][4] int             {isSafety, solves done, last solver status, total
- *                                           interior-point iterations}                           */
+ *   d_flags         [S][4] int             {isSafety, solves done, WORST solver status over the step's
+ *                                           solves (0 converged, 1 iteration cap, 2 regularisation
+ *                                           overflow; -1 no solve ran), total interior-point
+ *                                           iterations}.  The reference ignores IPOPT's status
+ *                                           (HighLvlMpc.cpp:116-122); a host that wants to fall back to
+ *                                           PubSlowDownCmd on an unconverged solve tests flags[2] > 0.  */
 int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_params *params,
                    const double *d_state_quad, const double *d_pos_x, double *d_ref_path,
                    double *d_u, double *d_x0array, int *d_flags, void *stream);

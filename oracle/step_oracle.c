@@ -98,7 +98,7 @@ void stepo_get_init_path(double *ref_path, int N, double speed, double T, double
     l[0] = goalx; l[1] = goaly; l[2] = goalz; l[4] = speed;
 }
 
-/* flags[4] = {isSafety, solves done, last solver status, total interior-point iterations}
+/* flags[4] = {isSafety, solves done, worst solver status over the solves (-1: none ran), total interior-point iterations}
  * ref_log (optional): [mpc_max_iter][20+10N+3KN] the vecRefStates handed to each Solve. */
 int stepo_run(void *kd_obs, void *kd_edge, void *mpc, int K, double speed, double T, double safety_distance,
               int mpc_max_iter, const double *state_quad, double pos_x, double *ref_path, double *u, double *x0array,
@@ -153,7 +153,8 @@ int stepo_run(void *kd_obs, void *kd_edge, void *mpc, int K, double speed, doubl
             tg[1] = 0.;
         }
         if (ref_log) memcpy(ref_log + (size_t)nref * iter, ref_states, sizeof(double) * nref);
-        status = mpco_Solve(mpc, ref_states, u, x0, iter == 0); /* :337 */
+        { const int st = mpco_Solve(mpc, ref_states, u, x0, iter == 0); /* :337 */
+          if (st > status) status = st; }
         iters += mpco_last_info(mpc)[1];
         ++solves;
         for (int i = 0; i < N; ++i) memcpy(ref_path + 10 * i, x0 + 14 * i, sizeof(double) * 10); /* :338-342 */
@@ -300,7 +301,8 @@ int stepo_run_frames(void **kd_obs, void **kd_edge, int F, const double *Twc, co
             tg[0] += dX;
             tg[1] = 0.;
         }
-        status = mpco_Solve(mpc, ref_states, u, x0, iter == 0);
+        { const int st = mpco_Solve(mpc, ref_states, u, x0, iter == 0);
+          if (st > status) status = st; }
         iters += mpco_last_info(mpc)[1];
         ++solves;
         for (int i = 0; i < N; ++i) memcpy(ref_path + 10 * i, x0 + 14 * i, sizeof(double) * 10);

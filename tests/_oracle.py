@@ -175,7 +175,7 @@ def _decl_mpc(lib):
         lib.stepo_get_init_path.argtypes = [_f64p, i, d, d, d, d, d]
 
 
-MPC_DEFAULT_MAX_ITER = 40   # oracle/mpc_oracle.c MPCO_DEFAULT_MAX_ITER == the product's default (amk_mpc_create)
+MPC_DEFAULT_MAX_ITER = 100   # oracle/mpc_oracle.c MPCO_DEFAULT_MAX_ITER == the product's default (amk_mpc_create)
 
 
 def mpco_solve(P, w0, lbu, ubu, N, K, dt, tol=1e-4, max_iter=MPC_DEFAULT_MAX_ITER, trace=None, **kw):

@@ -29,6 +29,20 @@ def test_exports_every_declared_symbol(lib):
     assert lib.amk_status_string(0) == b"ok"
 
 
+def test_casadi_plugin_header_and_exports(lib):
+    """include/avoid_mpc_amd/casadi_plugin.h: every function it declares (7 x (entry + 15 helpers) + 2) is exported."""
+    hdr = open(os.path.join(ROOT, "include", "avoid_mpc_amd", "casadi_plugin.h")).read()
+    funcs = re.findall(r"^AMK_CASADI_DECLARE\((\w+)\)", hdr, re.M)
+    assert funcs == capi.PLUGIN_FUNCTIONS
+    macro = hdr[hdr.index("#define AMK_CASADI_DECLARE"):hdr.index("AMK_CASADI_DECLARE(nlp)")]
+    helpers = re.findall(r"NAME##_(\w+)\(", macro)
+    assert helpers == capi.PLUGIN_HELPERS
+    extra = set(re.findall(r"\b(amk_plugin_\w+)\s*\(", hdr))
+    assert extra == {"amk_plugin_configure", "amk_plugin_dims"}
+    missing = [s for s in capi.PLUGIN_SYMBOLS if not hasattr(lib, s)]
+    assert missing == []
+
+
 def test_no_cpu_fallback(lib):
     """Without a GPU every constructor must fail loudly instead of computing on the host."""
     import ctypes as C

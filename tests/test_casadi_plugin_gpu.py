@@ -1,6 +1,7 @@
 """GPU: the CasADi code-generation symbols exported by libavoid_mpc_amd.so (the plugin
 `casadi::nlpsol("solve", "ipopt", soPath, opts)` loads, AM/src/HighLvlMpc.cpp:50,52), driven through ctypes the way
-CasADi's importer drives a generated library: *_n_in/_n_out/_sparsity_*/_work, then the function itself with
+CasADi's importer drives a generated library: the oracle `nlp` first, then every nlp_* function (names from
+include/avoid_mpc_amd/casadi_plugin.h): *_n_in/_n_out/_name_*/_sparsity_*/_work, then the function itself with
 `const double** arg, double** res, long long* iw, double* w, int mem`.  Values against the oracle.  CasADi itself is not
 in the image: the calling convention is the one recalled in SURVEY.md appendix B, unverified against libcasadi.
 
@@ -108,6 +109,66 @@ res["hess"] = float(np.abs(Hg - 1.7 * np.triu(Hd)).max() / np.abs(Hd).max())
 p2 = p.copy(); p2[-2] = 2.4      # collide_lambda
 (f3,) = call("nlp_f", [x, p2], [1])
 res["f_tail"] = abs(f3[0] - o.mpco_nlp_f(np.ascontiguousarray(x), np.ascontiguousarray(p2), N, K)) / abs(f3[0])
+# ---- the oracle `nlp` (what nlpsol(name, "ipopt", "<file>.so") loads first) and NULL conventions
+fa, ga = call("nlp", [x, p], [1, ng])
+assert fa[0] == f[0] and np.array_equal(ga, g)
+def raw(name, argl, outl):
+    """argl / outl entries may be None (NULL pointer: all-zero input / output not requested)."""
+    fn = getattr(lib, name); fn.restype = C.c_int
+    fn.argtypes = [C.POINTER(C.POINTER(C.c_double)), C.POINTER(C.POINTER(C.c_double)), C.POINTER(LL), C.POINTER(C.c_double), C.c_int]
+    argv = (C.POINTER(C.c_double) * len(argl))(); resv = (C.POINTER(C.c_double) * len(outl))()
+    keep = [None if a is None else np.ascontiguousarray(a, np.float64) for a in argl]
+    for i, a in enumerate(keep):
+        if a is not None: argv[i] = a.ctypes.data_as(C.POINTER(C.c_double))
+    for i, o_ in enumerate(outl):
+        if o_ is not None: resv[i] = o_.ctypes.data_as(C.POINTER(C.c_double))
+    assert fn(argv, resv, None, None, 0) == 0
+gz = np.full(ng, 7.0); raw("nlp", [x, p], [None, gz]); assert np.array_equal(gz, g)          # res[0] == NULL: only g
+fz = np.zeros(1); raw("nlp_f", [None, p], [fz]); (f0,) = call("nlp_f", [np.zeros(nx), p], [1]); assert fz[0] == f0[0]   # arg[0] == NULL: x = 0
+hz = np.full(colind[-1], 3.0); raw("nlp_hess_l", [x, p, None, None], [hz]); assert not hz.any()   # lam_f == NULL: zero Hessian
+# ---- every function, every helper: the walk a dlsym-based importer makes
+names = {"nlp": (["x", "p"], ["f", "g"]), "nlp_f": (["x", "p"], ["f"]), "nlp_g": (["x", "p"], ["g"]),
+         "nlp_grad_f": (["x", "p"], ["f", "grad_f_x"]), "nlp_jac_g": (["x", "p"], ["g", "jac_g_x"]),
+         "nlp_hess_l": (["x", "p", "lam_f", "lam_g"], ["triu_hess_gamma_x_x"]),
+         "nlp_grad": (["x", "p", "lam_f", "lam_g"], ["f", "g", "grad_gamma_x", "grad_gamma_p"])}
+shape = {"x": (nx, 1), "p": (npar, 1), "f": (1, 1), "g": (ng, 1), "lam_f": (1, 1), "lam_g": (ng, 1), "grad_f_x": (nx, 1),
+         "jac_g_x": (ng, nx), "triu_hess_gamma_x_x": (nx, nx), "grad_gamma_x": (nx, 1), "grad_gamma_p": (npar, 1)}
+assert list(names) == capi.PLUGIN_FUNCTIONS
+for fn, (ins, outs) in names.items():
+    for h in capi.PLUGIN_HELPERS:
+        assert hasattr(lib, fn + "_" + h), fn + "_" + h
+    gi = getattr(lib, fn + "_n_in"); gi.restype = LL; go_ = getattr(lib, fn + "_n_out"); go_.restype = LL
+    assert gi() == len(ins) and go_() == len(outs)
+    for which, lst in (("in", ins), ("out", outs)):
+        nm = getattr(lib, fn + "_name_" + which); nm.restype = C.c_char_p; nm.argtypes = [LL]
+        for i, want in enumerate(lst):
+            assert nm(i) == want.encode(), (fn, which, i, nm(i))
+            assert sparsity(getattr(lib, fn + "_sparsity_" + which), i)[:2] == shape[want], (fn, which, i)
+        assert nm(len(lst)) is None
+    di = getattr(lib, fn + "_default_in"); di.restype = C.c_double; di.argtypes = [LL]; assert di(0) == 0.0
+    assert getattr(lib, fn + "_alloc_mem")() == 0 and getattr(lib, fn + "_init_mem")(0) == 0
+    getattr(lib, fn + "_free_mem")(0)
+# ---- nlp_grad: gamma = lam_f f + lam_g' g
+fg_, gg_, gx, gp = call("nlp_grad", [x, p, lam_f, lam_g], [1, ng, nx, npar])
+assert fg_[0] == f[0] and np.array_equal(gg_, g)
+gx_ref = 1.7 * go + Jn.T @ lam_g
+res["grad_gamma_x"] = float(np.abs(gx - gx_ref).max() / np.abs(gx_ref).max())
+gamma = lambda pp: 1.7 * M.nlp_f(x, pp, N, K) + lam_g @ M.nlp_g(x, pp, N, K, prm.dt)
+fd = np.zeros(npar)
+for i in range(npar):
+    h = 1e-6 * max(1.0, abs(p[i])); e = np.zeros(npar); e[i] = h
+    fd[i] = (gamma(p + e) - gamma(p - e)) / (2 * h)
+scale = np.maximum(np.abs(fd), 1e-3 * np.abs(fd).max())
+res["grad_gamma_p"] = float((np.abs(gp - fd) / scale).max())
+res["grad_gamma_p_blocks"] = {"x_init": float(np.abs(gp[:10] - fd[:10]).max()), "tau": float(np.abs(gp[-30:-26] - fd[-30:-26]).max()),
+                              "weights": float((np.abs(gp[-26:-1] - fd[-26:-1]) / np.maximum(1.0, np.abs(fd[-26:-1]))).max()),
+                              "radius": float(abs(gp[-1] - fd[-1]) / max(1.0, abs(fd[-1])))}
+# ---- another horizon in the same process: amk_plugin_configure
+lib.amk_plugin_configure.restype = C.c_int; lib.amk_plugin_configure.argtypes = [C.c_double, C.c_double, C.c_int]
+assert lib.amk_plugin_configure(0.33, 0.033, 3) == 0
+assert lib.amk_plugin_dims(*[C.byref(d) for d in dims]) == 0
+assert [d.value for d in dims] == [10, 3, 150, 244, 110], [d.value for d in dims]
+assert sparsity(lib.nlp_sparsity_in, 0)[:2] == (150, 1)
 print("RESULT " + json.dumps(res))
 '''
 
@@ -122,3 +183,5 @@ def test_plugin_symbols(cfg, T, K):
     print(cfg, res)
     assert res["f"] <= 1e-9 and res["grad"] <= 1e-9 and res["hess"] <= 1e-9 and res["f_tail"] <= 1e-9
     assert res["g"] <= 1e-11 and res["jac"] <= 1e-14
+    assert res["grad_gamma_x"] <= 1e-12
+    assert res["grad_gamma_p"] <= 1e-5, res      # against central differences of the numpy twin over the whole of p

@@ -6,7 +6,8 @@ Scene by scene: same status, same iteration / regularisation / line-search-failu
 |u - u_oracle|_inf, |x - x_oracle|_inf <= 1e-6.  A rounding-level flip of a branch (a line-search
 acceptance or a barrier update decided by a comparison that is a tie to the last digits) may change the
 COUNTS of a scene; both sides then still stop at the same optimum: such a scene must be converged on both
-sides and agree to 1e-4, and at most 1 scene in 8 may be of that kind."""
+sides and agree to 1e-4, and at most 1 solve in 100 (one, in these batches of 16 - 48 solves) may be of that kind
+(observed: 1 of the 48 C2 solves, none at C1 / C5; census over 2048 scenes: 0.2 %)."""
 import numpy as np
 import pytest
 
@@ -71,7 +72,7 @@ def test_solve_matches_oracle(cfg, torch_cuda):
                 gpu_w = warm.copy(); gpu_w[s] = cpu[s].warm_start      # keep the two sides on the same warm start
                 gpu.set_warm_start(torch.from_numpy(gpu_w).cuda())
     print(f"{cfg}: max |du| = {worst_u:.3e}, max |dx| = {worst_x:.3e}, scenes with flipped counts: {flipped}/{S * n_it}")
-    assert worst_u <= TOL and worst_x <= TOL and flipped * 8 <= S * n_it
+    assert worst_u <= TOL and worst_x <= TOL and flipped <= max(1, S * n_it // 100)
 
 
 def test_constructor_defaults_and_setters(torch_cuda):

@@ -3,9 +3,10 @@ tests/golden/make_mpc_parity_golden.py).
 
 SURVEY.md section 8(d): `|u - u*|_inf <= 1e-3 m/s^2` and `|x - x*|_inf <= 1e-3` against the CONVERGED optimum (IPOPT's
 iterates are not reproducible: CasADi/IPOPT are absent -- PARITY UNPINNED against them).  u*, x*, J* are the local optimum
-reached from the reference's zero warm start (HighLvlMpc.cpp:26-27,35), cross-checked by scipy's L-BFGS-B.  The shipped
-options (tol 1e-4, AMK_MPC_DEFAULT_MAX_ITER iterations) must put >= 90 % of the 64 bench scenes of every BASELINE size
-inside the bound; the GPU twin of this test is tests/test_mpc_parity_gpu.py."""
+reached from the reference's zero warm start (HighLvlMpc.cpp:26-27,35), cross-checked by scipy's L-BFGS-B.  With the shipped
+options (tol 1e-4; the iteration cap AMK_MPC_DEFAULT_MAX_ITER is a safety net no fixture scene reaches) EVERY one of the 64
+bench scenes of every BASELINE size must converge (status 0) with |u - u*|_inf <= 1e-3, and >= 98 % of them with
+|x - x*|_inf <= 1e-3 (one C2 scene stops 1.7e-3 from x* with the scaled error already below tol); the GPU twin of this test is tests/test_mpc_parity_gpu.py."""
 import os
 
 import numpy as np
@@ -16,10 +17,10 @@ from avoid_mpc_amd import synth
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "mpc_parity_golden.npz"))
 GATE_U = 1e-3
-GATE_FRACTION = 0.9
+GATE_FRACTION_X = 0.98   # trajectory gate (round 2: 0.9 for both)
 
 
-def gate_report(cfg, u, w, J):
+def gate_report(cfg, u, w, J, status=None):
     """-> dict of the numbers quoted with every result (also used by the GPU test and by bench.py's parity block)."""
     ws, Js = G[cfg + ".wstar"], G[cfg + ".Jstar"]
     du = np.abs(u - ws[:, 10:14]).max(axis=1)
@@ -27,7 +28,16 @@ def gate_report(cfg, u, w, J):
     dJ = (J - Js) / Js
     return dict(scenes=len(du), frac_u_within_1e3=float(np.mean(du <= GATE_U)), du_median=float(np.median(du)),
                 du_p90=float(np.quantile(du, 0.9)), du_max=float(du.max()), frac_x_within_1e3=float(np.mean(dw <= GATE_U)),
-                dJ_rel_median=float(np.median(dJ)), dJ_rel_max=float(dJ.max()))
+                dJ_rel_median=float(np.median(dJ)), dJ_rel_max=float(dJ.max()),
+                converged=None if status is None else int((np.asarray(status) == 0).sum()))
+
+
+def assert_gate(rep):
+    """The gate itself (CPU oracle and GPU alike)."""
+    assert rep["converged"] == rep["scenes"], rep
+    assert rep["du_max"] <= GATE_U and rep["frac_u_within_1e3"] == 1.0, rep
+    assert rep["frac_x_within_1e3"] >= GATE_FRACTION_X, rep
+    assert rep["dJ_rel_median"] <= 1e-7 and rep["dJ_rel_max"] <= 1e-5, rep
 
 
 @pytest.mark.parametrize("cfg", ["C1", "C2", "C5"])
@@ -52,14 +62,13 @@ def test_oracle_with_the_shipped_options_meets_the_gate(cfg):
     lbu = [-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot]
     ubu = [prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot]
     refs = G[cfg + ".ref"]
-    W, J, it = [], [], []
+    W, J, it, status = [], [], [], []
     for ref in refs:
         P = np.concatenate([ref, prm.gain, prm.tau, prm.weights, [prm.radius]])
         w, info, st = _oracle.mpco_solve(P, np.zeros(10 + 14 * N), lbu, ubu, N, K, prm.dt)   # defaults
-        W.append(w); J.append(st[0]); it.append(info[1])
+        W.append(w); J.append(st[0]); it.append(info[1]); status.append(info[0])
     W = np.array(W)
-    rep = gate_report(cfg, W[:, 10:14], W, np.array(J))
+    rep = gate_report(cfg, W[:, 10:14], W, np.array(J), status)
     print(cfg, rep, "iterations mean %.1f max %d" % (np.mean(it), np.max(it)))
-    assert rep["frac_u_within_1e3"] >= GATE_FRACTION, rep
-    assert rep["frac_x_within_1e3"] >= GATE_FRACTION, rep
-    assert rep["dJ_rel_median"] <= 1e-7, rep
+    assert np.max(it) < _oracle.MPC_DEFAULT_MAX_ITER
+    assert_gate(rep)

@@ -61,11 +61,12 @@ def run_both(torch, scenes, prm, n_steps=1, tie_order=0):
 def compare(gpu, cpu, tol=TOL):
     """Scene by scene: identical flags {isSafety, solves, status, interior-point iterations} and |gpu - oracle| <= tol.
     A rounding-level branch flip inside a solve (tests/test_mpc_gpu.py) may change the iteration COUNT of a scene; it must
-    then keep isSafety / solves / status (first step only: later steps inherit the warm start), and at most 1 scene in 8
-    may be of that kind.  Such a scene normally still ends at the same optimum (1e-4 asserted); the problem is non-convex
-    and non-smooth, so once in a few hundred scenes the flipped branch leads to ANOTHER local minimum of the same NLP
-    (both sides converged, status 0) -- at most 1 scene in 64 (and never more than the flipped ones) may do that, and
-    they are printed."""
+    then keep isSafety / solves / status (first step only: later steps inherit the warm start).  Such a scene normally still
+    ends at the same optimum (1e-4 asserted); the problem is non-convex and non-smooth, so once in a few hundred scenes the
+    flipped branch leads to ANOTHER local minimum of the same NLP (both sides converged, status 0); they are printed.
+    Allowances = ~3 x what the census over the 2048 scenes of configs[3] observed (4 flipped = 0.2 %, 3 of them in another
+    minimum = 0.15 %): <= 1 % flipped, <= 0.5 % in another minimum, and one scene of each kind in a
+    batch too small for the percentages to mean anything."""
     worst, flipped, other_basin, total = 0.0, 0, [], 0
     diverged = set()
     for t in range(len(gpu)):
@@ -88,8 +89,8 @@ def compare(gpu, cpu, tol=TOL):
                     other_basin.append((t, s, gpu[t]["flags"][s].tolist(), r["flags"].tolist(), float(du)))
     if other_basin:
         print("scenes whose flipped branch ended in another local minimum:", other_basin)
-    assert flipped * 8 <= total, (flipped, total)
-    assert len(other_basin) * 64 <= max(total, 64), other_basin
+    assert flipped <= max(1, total // 100), (flipped, total)
+    assert len(other_basin) <= max(1, total // 200), other_basin
     return worst
 
 
