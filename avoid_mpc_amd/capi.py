@@ -36,6 +36,11 @@ SYMBOLS = [
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
     "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_mpc_np", "amk_mpc_eval_gamma",
     "amk_mpc_eval_gamma_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
+    "amk_pipeline_create", "amk_pipeline_destroy", "amk_pipeline_slots", "amk_pipeline_mpc", "amk_pipeline_kd",
+    "amk_pipeline_stream", "amk_pipeline_submit", "amk_pipeline_wait", "amk_pipeline_query", "amk_pipeline_drain",
+    "amk_pipeline_outputs",
+    "amk_shard_scene_range", "amk_shard_unique_id", "amk_shard_create", "amk_shard_destroy", "amk_shard_rank",
+    "amk_shard_world", "amk_shard_last_rccl_error", "amk_shard_gather", "amk_shard_gather_u", "amk_shard_max",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -48,6 +53,20 @@ class AmkError(RuntimeError):
 class StepParams(C.Structure):
     _fields_ = [("speed", C.c_double), ("safety_distance", C.c_double),
                 ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
+
+
+class PipelineConfig(C.Structure):
+    """amk_pipeline_config"""
+    _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
+                ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("reserved", C.c_int),
+                ("step", StepParams)]
+
+
+class PipelineFrame(C.Structure):
+    """amk_pipeline_frame"""
+    _fields_ = [("d_cloud", C.c_void_p), ("d_cloud_counts", C.c_void_p), ("d_edge", C.c_void_p), ("d_edge_counts", C.c_void_p),
+                ("point_stride", C.c_int), ("keep_warm_start", C.c_int), ("d_state_quad", C.c_void_p), ("d_pos_x", C.c_void_p),
+                ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p)]
 
 
 class FrameCamera(C.Structure):
@@ -134,6 +153,27 @@ def load():
         "amk_step_batch_host": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp]),
         "amk_step_batch_frames": (i, [vp, vp, i, vp, C.POINTER(FrameCamera), vp, C.POINTER(StepParams), vp, vp, vp, vp, vp,
                                       vp, vp]),
+        "amk_pipeline_create": (i, [C.POINTER(PipelineConfig), C.POINTER(vp)]),
+        "amk_pipeline_destroy": (i, [vp]),
+        "amk_pipeline_slots": (i, [vp]),
+        "amk_pipeline_mpc": (vp, [vp, i]),
+        "amk_pipeline_kd": (vp, [vp, i, i]),
+        "amk_pipeline_stream": (vp, [vp, i]),
+        "amk_pipeline_submit": (i, [vp, C.POINTER(PipelineFrame), C.POINTER(i)]),
+        "amk_pipeline_wait": (i, [vp, i]),
+        "amk_pipeline_query": (i, [vp, i]),
+        "amk_pipeline_drain": (i, [vp]),
+        "amk_pipeline_outputs": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "amk_shard_scene_range": (i, [i, i, i, C.POINTER(i), C.POINTER(i)]),
+        "amk_shard_unique_id": (i, [C.c_char_p]),
+        "amk_shard_create": (i, [C.c_char_p, i, i, C.POINTER(vp)]),
+        "amk_shard_destroy": (i, [vp]),
+        "amk_shard_rank": (i, [vp]),
+        "amk_shard_world": (i, [vp]),
+        "amk_shard_last_rccl_error": (i, []),
+        "amk_shard_gather": (i, [vp, vp, ll, vp, vp]),
+        "amk_shard_gather_u": (i, [vp, vp, i, vp, vp]),
+        "amk_shard_max": (i, [vp, vp, i, vp]),
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
         "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
         "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
@@ -161,6 +201,21 @@ def check(status, what=""):
         lib = load()
         msg = lib.amk_status_string(status).decode()
         raise AmkError(f"{what}: {msg} (status {status}, hipError {lib.amk_last_hip_error()})")
+
+
+def hip_memcpy_dtoh(host_array, dev_ptr):
+    """Synchronous device -> host copy of a raw device pointer into a numpy array (hipMemcpy through torch's HIP runtime);
+    returns the hipError_t."""
+    import torch
+    hip = C.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    hip.hipMemcpy.restype = C.c_int
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip.hipMemcpy(host_array.ctypes.data_as(C.c_void_p), C.c_void_p(dev_ptr), host_array.nbytes, 2)
+
+
+def check_hip(err, what=""):
+    if err != 0:
+        raise AmkError(f"{what}: hipError {err}")
 
 
 def dptr(t):

@@ -23,16 +23,20 @@ def _dev():
 
 
 class KdBatch:
-    def __init__(self, n_scenes, max_points):
+    def __init__(self, n_scenes, max_points, handle=None):
+        """handle: a borrowed amk_kd* (a pipeline slot's); it is then not destroyed by this object."""
         self.lib = capi.load()
         self.S, self.max_points = int(n_scenes), int(max_points)
-        h = C.c_void_p()
-        capi.check(self.lib.amk_kd_create(self.S, self.max_points, C.byref(h)), "amk_kd_create")
-        self.h = h
+        self.owned = handle is None
+        if handle is None:
+            handle = C.c_void_p()
+            capi.check(self.lib.amk_kd_create(self.S, self.max_points, C.byref(handle)), "amk_kd_create")
+        self.h = handle if isinstance(handle, C.c_void_p) else C.c_void_p(handle)
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.amk_kd_destroy(self.h)
+            if self.owned:
+                self.lib.amk_kd_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -116,11 +120,15 @@ def kd_tie_flags(kd, queries, k, query_stride=3, stream=None):
 
 
 class MpcBatch:
-    def __init__(self, T, dt, nearest_point_num, n_scenes):
+    def __init__(self, T, dt, nearest_point_num, n_scenes, handle=None):
+        """handle: a borrowed amk_mpc* (a pipeline slot's); it is then not destroyed by this object."""
         self.lib = capi.load()
-        h = C.c_void_p()
-        capi.check(self.lib.amk_mpc_create(float(T), float(dt), int(nearest_point_num), int(n_scenes),
-                                           C.byref(h)), "amk_mpc_create")
+        self.owned = handle is None
+        if handle is None:
+            handle = C.c_void_p()
+            capi.check(self.lib.amk_mpc_create(float(T), float(dt), int(nearest_point_num), int(n_scenes),
+                                               C.byref(handle)), "amk_mpc_create")
+        h = handle if isinstance(handle, C.c_void_p) else C.c_void_p(handle)
         self.h = h
         self.S, self.K = int(n_scenes), int(nearest_point_num)
         self.N = self.lib.amk_mpc_horizon(h)
@@ -129,7 +137,8 @@ class MpcBatch:
 
     def close(self):
         if getattr(self, "h", None):
-            self.lib.amk_mpc_destroy(self.h)
+            if self.owned:
+                self.lib.amk_mpc_destroy(self.h)
             self.h = None
 
     __del__ = close
@@ -211,6 +220,103 @@ class MpcBatch:
 
     def reset_warm_start(self, stream=None):
         capi.check(self.lib.amk_mpc_reset_warm_start(self.h, capi.stream_ptr(stream)), "reset_warm_start")
+
+
+class Pipeline:
+    """amk_pipeline: n_slots control steps in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs}."""
+
+    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm):
+        self.lib = capi.load()
+        cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
+                                  int(prm.K), 0, capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
+        h = C.c_void_p()
+        capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
+        self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
+        self.N = self.lib.amk_mpc_horizon(self.lib.amk_pipeline_mpc(h, 0))
+        self._mpc = [MpcBatch(prm.T, prm.dt, prm.K, n_scenes, handle=self.lib.amk_pipeline_mpc(h, i)) for i in range(n_slots)]
+        self._kd = [(KdBatch(n_scenes, max_points, handle=self.lib.amk_pipeline_kd(h, i, 0)),
+                     KdBatch(n_scenes, max_edge_points, handle=self.lib.amk_pipeline_kd(h, i, 1))) for i in range(n_slots)]
+        for m in self._mpc:
+            m.configure(prm)
+
+    def mpc(self, slot):
+        return self._mpc[slot]
+
+    def kd(self, slot, which):
+        return self._kd[slot][which]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amk_pipeline_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def submit(self, clouds, edges, state_quad, pos_x, ref_path_init, cloud_counts=None, edge_counts=None, u_out=None,
+               keep_warm_start=False):
+        """One fresh frame + control step on the next slot; returns the slot index at once (blocks only when that slot's
+        previous step is still running).  All tensors are device tensors that must stay alive until the slot finished."""
+        assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
+        fr = capi.PipelineFrame(clouds.data_ptr(), cloud_counts.data_ptr() if cloud_counts is not None else None,
+                                edges.data_ptr(), edge_counts.data_ptr() if edge_counts is not None else None,
+                                int(clouds.shape[2]), int(bool(keep_warm_start)), state_quad.data_ptr(), pos_x.data_ptr(),
+                                ref_path_init.data_ptr(), u_out.data_ptr() if u_out is not None else None)
+        slot = C.c_int(-1)
+        capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
+        return slot.value
+
+    def wait(self, slot):
+        capi.check(self.lib.amk_pipeline_wait(self.h, int(slot)), "amk_pipeline_wait")
+
+    def drain(self):
+        capi.check(self.lib.amk_pipeline_drain(self.h), "amk_pipeline_drain")
+
+    def outputs(self, slot):
+        """Host copies of the slot's results (after wait): dict(u [S,4], x0array [S,N,14], flags [S,4], ref_path [S,N,10])."""
+        ptr = [C.c_void_p() for _ in range(4)]
+        capi.check(self.lib.amk_pipeline_outputs(self.h, int(slot), *[C.byref(p) for p in ptr]), "amk_pipeline_outputs")
+        S, N = self.S, self.N
+        shapes = [((S, 4), np.float64), ((S, N, 14), np.float64), ((S, 4), np.int32), ((S, N, 10), np.float64)]
+        out = {}
+        for name, p, (shp, dt) in zip(("u", "x0array", "flags", "ref_path"), ptr, shapes):
+            a = np.empty(shp, dt)
+            capi.check_hip(capi.hip_memcpy_dtoh(a, p.value), name)
+            out[name] = a
+        return out
+
+
+class Shard:
+    """amk_shard: one process per GPU, RCCL bound by the library (ncclCommInitRank / ncclAllGather / ncclAllReduce)."""
+
+    def __init__(self, rank, world, unique_id):
+        self.lib = capi.load()
+        h = C.c_void_p()
+        capi.check(self.lib.amk_shard_create(unique_id, int(rank), int(world), C.byref(h)), "amk_shard_create")
+        self.h, self.rank, self.world = h, int(rank), int(world)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        capi.check(capi.load().amk_shard_unique_id(buf), "amk_shard_unique_id")
+        return buf.raw
+
+    def gather(self, local, out, stream=None):
+        """out[r * n : (r + 1) * n] = rank r's `local` (float64 device tensors, n = local.numel())."""
+        assert local.dtype == torch.float64 and out.dtype == torch.float64 and out.numel() == local.numel() * self.world
+        capi.check(self.lib.amk_shard_gather(self.h, capi.dptr(local), int(local.numel()), capi.dptr(out),
+                                             capi.stream_ptr(stream)), "amk_shard_gather")
+        return out
+
+    def max(self, values, stream=None):
+        capi.check(self.lib.amk_shard_max(self.h, capi.dptr(values), int(values.numel()), capi.stream_ptr(stream)), "amk_shard_max")
+        return values
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amk_shard_destroy(self.h)
+            self.h = None
+
+    __del__ = close
 
 
 def step_batch(kd_obstacle, kd_edge, mpc, prm, state_quad, pos_x, ref_path, stream=None, out=None):

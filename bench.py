@@ -8,8 +8,10 @@ depth frame (build the obstacle + edge KD indices) and one control step (<= 3 ou
 interior-point solve to tol 1e-4, <= 40 iterations}, zero warm start), SURVEY.md section 8(d).  value = scenes
 processed by all ranks / wall time (max over ranks).
 Workload: BASELINE.json configs[1] (50k-point cloud, N = 20, K = 8) batched as configs[2] (256 scenes per GPU); scenes
-are independent, so N GPUs run N x 256 scenes (weak scaling) and the only collective is the gather of the controls
-(RCCL all_gather of 4 doubles per scene).  Every in-flight step owns its own frames (distinct clouds: the working set
+are independent, so N GPUs run N x 256 scenes (weak scaling) and the only collective is the gather of the sweep's controls
+(one ncclAllGather of 4 doubles per scene-step at the end of the timed region, issued through the library's own RCCL binding
+amk_shard_gather).  The steps are kept in flight by the C ABI's amk_pipeline_* (what a C++ host calls; tests/cpp/sweep_driver.cpp
+is that host).  Every in-flight step owns its own frames (distinct clouds: the working set
 is `streams` x 169 MB, far beyond the 256 MiB Infinity Cache).
 
 Besides the contract's fields the JSON line carries
@@ -208,8 +210,8 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import numpy as np
     import torch
-    from avoid_mpc_amd import capi, fsm, shard, synth
-    from avoid_mpc_amd.host import KdBatch, MpcBatch, step_batch
+    from avoid_mpc_amd import capi, fsm, synth
+    from avoid_mpc_amd.host import Pipeline, Shard, step_batch
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -233,11 +235,10 @@ def main():
     S, n, ne, N = args.scenes, args.points, args.points // 10, prm.N
     nslots = max(1, args.streams)
 
-    class Slot:
-        """Everything one in-flight step owns: a HIP stream, its frames (obstacle + edge clouds of S scenes, odometry),
-        the dual KD indices built from them, its MPC batch (warm start, workspace), reference path and outputs.
-        Consecutive steps are independent frames, so several are kept in flight: while one step sits in its
-        latency-bound solve another streams its clouds."""
+    class Frames:
+        """The inputs one in-flight step owns: its frames (obstacle + edge clouds of S scenes) and odometry.  Consecutive
+        steps are independent frames, so several are kept in flight (amk_pipeline: one slot = HIP stream + dual KD indices +
+        MPC batch + outputs); while one step sits in its latency-bound solve another streams its clouds."""
 
         def __init__(self, i):
             seed = 100000 + (rank * nslots + i) * S
@@ -250,37 +251,50 @@ def main():
             self.sq_h, self.ref0_h, self.posx_h = sq, ref0, posx
             self.sq = torch.from_numpy(sq).to(dev); self.ref0 = torch.from_numpy(ref0).to(dev)
             self.posx = torch.from_numpy(posx).to(dev)
-            self.stream = torch.cuda.Stream(device=dev)
-            self.kd_o, self.kd_e = KdBatch(S, n), KdBatch(S, ne)
-            self.kd_o.set_tie_order(args.tie_order); self.kd_e.set_tie_order(args.tie_order)
-            self.mpc = MpcBatch(prm.T, prm.dt, prm.K, S); self.mpc.configure(prm); self.mpc.set_precision(args.precision)
-            if args.ipm_max_iter is not None:
-                self.mpc.set_solver_options(1e-4, args.ipm_max_iter)
-            self.ref = self.ref0.clone()
-            self.u_all = torch.empty((S * world, 4), dtype=torch.float64, device=dev) if collective else None
-            self.out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev),
-                            x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
-                            flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
+            self.last_row = 0
 
-    slots = [Slot(i) for i in range(nslots)]
+    # the C ABI's pipeline (include/avoid_mpc_amd.h: amk_pipeline_*): what a C++ host would call; bench.py only feeds it
+    pl = Pipeline(nslots, S, n, ne, prm)
+    for i in range(nslots):
+        pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
+        pl.mpc(i).set_precision(args.precision)
+        if args.ipm_max_iter is not None:
+            pl.mpc(i).set_solver_options(1e-4, args.ipm_max_iter)
+    slots = [Frames(i) for i in range(nslots)]
+    max_rows = max(args.steps, args.steady_steps if args.steps < args.steady_steps else 0, nslots, args.warmup, 64)
+    u_sweep = torch.zeros((max_rows, S, 4), dtype=torch.float64, device=dev)   # the sweep's controls, one row per step
+    sh = None
+    if collective:   # RCCL through the library's own binding (amk_shard_*); torch.distributed only carries the 128-byte id
+        ids = [Shard.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        sh = Shard(rank, world, ids[0])
     step_no = [0]
     # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
     # value is then NOT the metric (the JSON line says so)
     DIAG_SKIP = os.environ.get("AMK_BENCH_SKIP", "")
+    diag_streams = [torch.cuda.ExternalStream(lib.amk_pipeline_stream(pl.h, i), device=dev) for i in range(nslots)] \
+        if DIAG_SKIP in ("build", "step") else None
+    diag_ref = [fr.ref0.clone() for fr in slots] if diag_streams else None
+    diag_x0 = torch.empty((S, N, 14), dtype=torch.float64, device=dev) if diag_streams else None
+    diag_fl = torch.empty((S, 4), dtype=torch.int32, device=dev) if diag_streams else None
 
-    def one_step():
-        sl = slots[step_no[0] % nslots]
+    def one_step(row):
+        i = step_no[0] % nslots
+        fr = slots[i]
         step_no[0] += 1
-        with torch.cuda.stream(sl.stream):
-            sl.ref.copy_(sl.ref0, non_blocking=True)  # fresh frame: mRefPath after GetInitPath
-            sl.mpc.reset_warm_start(sl.stream)        # zero warm start (HighLvlMpc.cpp:26-27,35)
+        fr.last_row = row
+        if diag_streams is None:
+            pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row])
+            return
+        st = diag_streams[i]
+        with torch.cuda.stream(st):
+            diag_ref[i].copy_(fr.ref0, non_blocking=True)
+            pl.mpc(i).reset_warm_start(st)
             if DIAG_SKIP != "build" or step_no[0] <= nslots:
-                sl.kd_o.build(sl.clouds, stream=sl.stream)   # FrameKDMap::AddVertex: obstacle index ...
-                sl.kd_e.build(sl.edges, stream=sl.stream)    # ... and edge index (FrameKDMap.cpp:44-47)
+                pl.kd(i, 0).build(fr.clouds, stream=st); pl.kd(i, 1).build(fr.edges, stream=st)
             if DIAG_SKIP != "step":
-                step_batch(sl.kd_o, sl.kd_e, sl.mpc, prm, sl.sq, sl.posx, sl.ref, stream=sl.stream, out=sl.out)
-            if collective:
-                shard.gather_controls(sl.out["u"], out=sl.u_all)   # the one exchange step: controls to every rank
+                step_batch(pl.kd(i, 0), pl.kd(i, 1), pl.mpc(i), prm, fr.sq, fr.posx, diag_ref[i], stream=st,
+                           out=dict(u=u_sweep[row], x0array=diag_x0, flags=diag_fl))
 
     def barrier():
         torch.cuda.synchronize()
@@ -290,40 +304,62 @@ def main():
 
     def timed(steps):
         t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
+        for j in range(steps):
+            one_step(j)
         t_enq = time.perf_counter() - t0   # host time to enqueue everything (diagnostic: launch-bound if ~= dt)
+        if diag_streams is None:
+            pl.drain()
+        if collective:   # the ONE exchange step of the sweep: every rank's controls to every rank (ncclAllGather)
+            sh.gather(u_sweep[:steps], u_gather(steps))
         barrier()
         return time.perf_counter() - t0, t_enq
 
-    for _ in range(nslots):                # untimed priming: every slot allocates its workspace once
-        one_step()
+    gather_bufs = {}
+
+    def u_gather(steps):
+        if steps not in gather_bufs:
+            gather_bufs[steps] = torch.empty((world, steps, S, 4), dtype=torch.float64, device=dev)
+        return gather_bufs[steps]
+
+    def max_over_ranks(seconds):
+        if sh is None:
+            return float(seconds)
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        sh.max(t)
+        torch.cuda.synchronize()
+        return float(t.item())
+
+    for j in range(nslots):                # untimed priming: every slot allocates its workspace once
+        one_step(j)
     barrier()
     if DIAG_SKIP in ("knn", "plan", "solve", "knn+plan"):   # diagnostics: kernel classes left out of the step from here on
         lib.amk__diag_skip({"knn": 1, "plan": 2, "solve": 4, "knn+plan": 3}[DIAG_SKIP])
-    for _ in range(args.warmup):
-        one_step()
+    for j in range(args.warmup):
+        one_step(j)
     barrier()
+    for k_ in (args.steps, args.steady_steps):   # the gather's receive buffers exist before the clock starts
+        if collective:
+            u_gather(k_)
     lib.amk__timing_enable(1)              # HIP events around the solve and build kernels, on their launch stream
     dt, t_enq = timed(args.steps)
     ms = (C.c_double * 8)(); cnt = (C.c_int * 8)()
     capi.check(lib.amk__timing_collect(ms, cnt), "timing")
     lib.amk__timing_enable(0)
-    dt = shard.max_over_ranks(dt, dev)
+    dt = max_over_ranks(dt)
 
-    flags = np.concatenate([sl.out["flags"].cpu().numpy() for sl in slots])
+    flags = np.concatenate([pl.outputs(i)["flags"] for i in range(nslots)]) if diag_streams is None else np.zeros((1, 4), np.int32)
     solves = float(flags[:, 1].mean()); ipm_iters = float(flags[:, 3].mean())
     steady = None
     if args.steps < args.steady_steps:     # the timed region above is mostly ramp-up / drain of the in-flight slots
         dts, _ = timed(args.steady_steps)
-        dts = shard.max_over_ranks(dts, dev)
+        dts = max_over_ranks(dts)
         steady = S * world * args.steady_steps / dts
     breakdown = None
     if args.breakdown and world == 1:   # (extra steps on one rank would unbalance the collectives)
         lib.amk__timing_enable(2)
         reps = max(3, min(args.steps, 64))
-        for _ in range(reps):
-            one_step()
+        for j in range(reps):
+            one_step(j)
         torch.cuda.synchronize()
         ms2 = (C.c_double * 8)(); cnt2 = (C.c_int * 8)()
         capi.check(lib.amk__timing_collect(ms2, cnt2), "timing")
@@ -339,7 +375,7 @@ def main():
         torch.cuda.synchronize()
         cl, ed = sl.clouds.cpu().numpy(), sl.edges.cpu().numpy()
         scenes = [(cl[s], ed[s], sl.sq_h[s], float(sl.posx_h[s]), sl.ref0_h[s]) for s in range(S)]
-        cpu, check = cpu_baseline_and_check(scenes, args.T, args.K, sl.out["u"].cpu().numpy(), sl.out["flags"].cpu().numpy())
+        cpu, check = cpu_baseline_and_check(scenes, args.T, args.K, u_sweep[sl.last_row].cpu().numpy(), pl.outputs(0)["flags"])
         parity = dict(parity or {}, timed_workload_vs_cpu_oracle=check)
 
     if rank == 0:
@@ -395,8 +431,10 @@ def main():
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "tie_order": "nanoflann" if args.tie_order else "lowest index",
                        "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
-                       "parallelism": (f"scenes sharded over {world} GPU(s); RCCL all_gather of u" if collective
-                                       else "single GPU, no process group")},
+                       "parallelism": (f"scenes sharded over {world} GPU(s); one ncclAllGather (amk_shard_gather) of the sweep's "
+                                       f"controls, {args.steps} x {S} x 4 doubles per rank, inside the timed region" if collective
+                                       else "single GPU, no process group"),
+                       "orchestration": "amk_pipeline_* (C ABI): submit() per step, drain() at the end"},
             "roofline": {"bound": "hbm", "kernel": "mpc_solve_kernel", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(solve_ms, 4), "launches": cnt[5],

@@ -278,6 +278,78 @@ int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_
                         double *h_u, double *h_x0array, int *h_flags);
 
 /* ------------------------------------------------------------------------------------------ */
+/* Several control steps in flight on one GPU (the throughput configuration)                    */
+/* ------------------------------------------------------------------------------------------ */
+/* One step (both index builds of a fresh frame + amk_step_batch) is a chain of dependent launches around a latency-bound
+ * solve: a single stream reaches ~15 % of what the chip does with 20 independent steps in flight.
+ * A pipeline owns n_slots slots = {HIP stream, obstacle + edge amk_kd, amk_mpc, reference-path buffer, outputs}; submit()
+ * enqueues on the next slot -- per frame the reference's sequence FrameKDMap::AddVertex (FrameKDMap.cpp:34-52: the two
+ * InitializeNew) -> AvoidanceStateMachine::Step TASK branch (AvoidanceStateMachine.cpp:322-355) -- and returns at once;
+ * it blocks only when that slot's previous step is still running.  The host should export GPU_MAX_HW_QUEUES >= n_slots
+ * before the first HIP call (ROCm multiplexes streams onto 4 hardware queues by default; two streams on one queue
+ * serialise).  Input buffers belong to the caller and must stay valid until the slot has finished.                      */
+typedef struct amk_pipeline amk_pipeline;
+#define AMK_PIPELINE_MAX_SLOTS 64
+typedef struct amk_pipeline_config {
+    int n_slots;            /* independent steps in flight                                                              */
+    int n_scenes;           /* scenes per step (S of every handle)                                                      */
+    int max_points;         /* capacity per scene of the obstacle cloud ...                                             */
+    int max_edge_points;    /* ... and of the edge cloud                                                                */
+    double T, dt;           /* ObstacleAvoidanceMPC(T, dt, .)                                     HighLvlMpc.cpp:5-12  */
+    int nearest_point_num;  /* K                                                                  mpc_parameters.yaml:5 */
+    int reserved;
+    amk_step_params step;
+} amk_pipeline_config;
+typedef struct amk_pipeline_frame {
+    const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame                   */
+    const int *d_cloud_counts;     /* [S] or NULL (= max_points)                                                        */
+    const float *d_edge;           /* [S][max_edge_points][point_stride] edge cloud                                     */
+    const int *d_edge_counts;      /* [S] or NULL                                                                       */
+    int point_stride;              /* 3, 4 (pcl::PointXYZ) or 0 (= 3)                                                   */
+    int keep_warm_start;           /* 0: zero warm start (a fresh ObstacleAvoidanceMPC, HighLvlMpc.cpp:26-27,35);        */
+                                   /* 1: the slot's last solution (mNlpW0 = sol, :129)                                  */
+    const double *d_state_quad;    /* [S][mpc_max_iter][10]  as amk_step_batch                                          */
+    const double *d_pos_x;         /* [S]                                                                               */
+    const double *d_ref_path_init; /* [S][N][10]  mRefPath after GetInitPath; copied, the slot's copy is refilled       */
+    double *d_u_out;               /* [S][4] or NULL: where the control goes instead of the slot's own buffer (e.g. a   */
+                                   /* row of the sweep's result array that amk_shard_gather exchanges at the end)       */
+} amk_pipeline_frame;
+int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out);
+int amk_pipeline_destroy(amk_pipeline *p);
+int amk_pipeline_slots(const amk_pipeline *p);
+/* The slot's handles, to configure them (weights, limits, tie order, precision ...) and its stream.                       */
+amk_mpc *amk_pipeline_mpc(amk_pipeline *p, int slot);
+amk_kd *amk_pipeline_kd(amk_pipeline *p, int slot, int which /* 0 obstacle, 1 edge */);
+void *amk_pipeline_stream(amk_pipeline *p, int slot);
+int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *frame, int *slot_out);
+int amk_pipeline_wait(amk_pipeline *p, int slot);   /* until that slot's step has finished                                */
+int amk_pipeline_query(amk_pipeline *p, int slot);  /* 1 finished / idle, 0 running, -1 error                             */
+int amk_pipeline_drain(amk_pipeline *p);            /* wait for every slot                                                */
+/* Device pointers of the slot's results (valid after wait): u [S][4], x0array [S][N][14], flags [S][4], ref_path [S][N][10] */
+int amk_pipeline_outputs(amk_pipeline *p, int slot, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path);
+
+/* ------------------------------------------------------------------------------------------ */
+/* Scenes sharded over the GPUs of a node (one process per GPU), RCCL over xGMI                 */
+/* ------------------------------------------------------------------------------------------ */
+/* Scenes are independent (the reference runs a single instance, mpc_obstacle_avoidance_node.cpp:8): block partition, no
+ * data-path collective; the one exchange step is an ncclAllGather of the controls.  Rank 0 makes the id, the host
+ * distributes its AMK_SHARD_ID_BYTES bytes by its own means (MPI, TCP, a file), every rank calls amk_shard_create with
+ * its GPU current.  RCCL is bound at run time; AMK_ERR_UNSUPPORTED when librccl cannot be loaded.                        */
+typedef struct amk_shard amk_shard;
+#define AMK_SHARD_ID_BYTES 128
+int amk_shard_scene_range(int rank, int world, int total, int *first, int *count);
+int amk_shard_unique_id(char *id_out /* [AMK_SHARD_ID_BYTES] */);
+int amk_shard_create(const char *id, int rank, int world, amk_shard **out);
+int amk_shard_destroy(amk_shard *s);
+int amk_shard_rank(const amk_shard *s);
+int amk_shard_world(const amk_shard *s);
+int amk_shard_last_rccl_error(void);
+/* d_all[r * n + i] = rank r's d_local[i]: equal shards (pad the last one); stream-ordered.                                */
+int amk_shard_gather(amk_shard *s, const double *d_local, long long n_doubles_per_rank, double *d_all, void *stream);
+int amk_shard_gather_u(amk_shard *s, const double *d_u_local, int n_local_scenes, double *d_u_all, void *stream);
+int amk_shard_max(amk_shard *s, double *d_values, int n, void *stream);   /* in-place max over ranks (timing)              */
+
+/* ------------------------------------------------------------------------------------------ */
 /* Depth image -> obstacle cloud: FrameKDMap::ProcessDepth            FrameKDMap.cpp:75-138   */
 /* (the step immediately before the tree build)                   */
 /* ------------------------------------------------------------------------------------------ */
