@@ -5,7 +5,7 @@
 
 One "step" = one pass of the hot path over one batch of synthetic scenes resident in HBM: for every scene a fresh
 depth frame (build the obstacle + edge KD indices) and one control step (<= 3 outer passes of {dual KD queries, pack P,
-interior-point solve to tol 1e-4, <= 40 iterations}, zero warm start), SURVEY.md section 8(d).  value = scenes
+interior-point solve run to tol 1e-4}, zero warm start), SURVEY.md section 8(d).  value = scenes
 processed by all ranks / wall time (max over ranks).
 Workload: BASELINE.json configs[1] (50k-point cloud, N = 20, K = 8) batched as configs[2] (256 scenes per GPU); scenes
 are independent, so N GPUs run N x 256 scenes (weak scaling) and the only collective is the gather of the sweep's controls
@@ -33,8 +33,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
-KCLASS = ["kd_compact", "step_knn", "step_knn_edge", "step_plan_pack", "pack", "mpc_solve", "step_begin", "kd_build"]
-PROFILE_TAG = "r02"
+# amk_common.h KernelClass: what the library's HIP-event timing (amk__timing_*) can bracket
+KCLASS = [None, "step_knn_grid_kernel", "step_scan_kernel (cross-check mode only)", "step_plan_pack_kernel", None,
+          "mpc_solve_kernel", "step_begin_kernel", "kd_build_kernel"]
+PROFILE_TAG = "r03"
+N_CU, N_SIMD, CLOCK_GHZ = 256, 4, 2.4   # MI355X: /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def alg_bytes_per_step(n, ne, N, K):
@@ -140,11 +143,12 @@ def cpu_baseline_and_check(scenes, T, K, gpu_u, gpu_flags):
     check = {"scenes": len(res), "flags_identical": int(same.sum()),
              "du_max_where_flags_identical": float(du[same].max()) if same.any() else None,
              "du_max_all": float(du.max()), "scenes_in_another_local_minimum": other,
-             "ok": bool(same.sum() * 8 >= 7 * len(res) and (not same.any() or du[same].max() <= 1e-6)
-                        and other * 64 <= max(len(res), 64)),
+             "ok": bool(int((~same).sum()) <= max(1, len(res) // 100) and (not same.any() or du[same].max() <= 1e-6)
+                        and other <= max(1, len(res) // 200)),
              "note": "same scenes, GPU step vs CPU oracle; a scene whose iteration counts differ took a different branch "
-                     "at a rounding-level tie: it normally ends at the same optimum (1e-3, the parity gate); at most 1 "
-                     "scene in 64 may end in another local minimum of the non-convex NLP (counted above)"}
+                     "at a rounding-level tie: it normally ends at the same optimum (1e-3, the parity gate); allowed: "
+                     "<= 1 % such scenes, <= 0.5 % in another local minimum of the non-convex NLP (census over 2048 scenes: "
+                     "0.2 % / 0.15 %)"}
     return base, check
 
 
@@ -176,8 +180,11 @@ def fixture_parity(torch, precision):
                     "dJ_rel_median": float(np.median(dJ)), "dJ_rel_max": float(dJ.max()),
                     "ipm_iters_mean": round(float(info[:, 1].mean()), 2), "converged": int((info[:, 0] == 0).sum())}
         m.close()
-    out["gate"] = "SURVEY.md 8(d): |u - u*|_inf <= 1e-3 on >= 90 % of the scenes, u* = converged local optimum (fixture)"
-    out["ok"] = bool(all(out[c]["frac_u_within_1e-3"] >= 0.9 for c in ("C1", "C2", "C5")))
+    out["gate"] = ("SURVEY.md 8(d): every fixture scene converged (status 0) with |u - u*|_inf <= 1e-3, |x - x*|_inf <= 1e-3 on "
+                   ">= 98 %; u* = converged local optimum of this project's method (fixture); what independent solvers reach "
+                   "from the same start: tests/test_mpc_independent.py")
+    out["ok"] = bool(all(out[c]["converged"] == out[c]["scenes"] and out[c]["du_max"] <= 1e-3 and
+                         out[c]["frac_x_within_1e-3"] >= 0.98 for c in ("C1", "C2", "C5")))
     return out
 
 
@@ -268,6 +275,9 @@ def main():
         ids = [Shard.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         sh = Shard(rank, world, ids[0])
+        warm = torch.zeros((world, 8), dtype=torch.float64, device=dev)
+        sh.gather(warm[rank].clone(), warm)   # RCCL sets a communicator's channels up at its first collective: not in the clock
+        torch.cuda.synchronize()
     step_no = [0]
     # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
     # value is then NOT the metric (the JSON line says so)
@@ -278,9 +288,9 @@ def main():
     diag_x0 = torch.empty((S, N, 14), dtype=torch.float64, device=dev) if diag_streams else None
     diag_fl = torch.empty((S, 4), dtype=torch.int32, device=dev) if diag_streams else None
 
-    def one_step(row):
+    def one_step(row, frames=None):
         i = step_no[0] % nslots
-        fr = slots[i]
+        fr = slots[i if frames is None else frames]
         step_no[0] += 1
         fr.last_row = row
         if diag_streams is None:
@@ -295,6 +305,11 @@ def main():
             if DIAG_SKIP != "step":
                 step_batch(pl.kd(i, 0), pl.kd(i, 1), pl.mpc(i), prm, fr.sq, fr.posx, diag_ref[i], stream=st,
                            out=dict(u=u_sweep[row], x0array=diag_x0, flags=diag_fl))
+
+    def one_step_and_slot(row, frames=None):
+        i = step_no[0] % nslots
+        one_step(row, frames)
+        return i
 
     def barrier():
         torch.cuda.synchronize()
@@ -354,6 +369,23 @@ def main():
         dts, _ = timed(args.steady_steps)
         dts = max_over_ranks(dts)
         steady = S * world * args.steady_steps / dts
+    # The kernels' OWN durations: a pass with ONE step on the chip at a time (submit, wait, submit, ...), every kernel class
+    # bracketed by HIP events on its launch stream.  Nothing else is resident, so submit-to-complete is the kernel's duration
+    # (+ a few us of launch latency) -- the number `rocprofv3 --kernel-trace` of `bench.py --streams 1` reports
+    # (profiles/r03_kernel_stats_streams1.md; same scenes: the frames of in-flight slot 0).  In the timed region above the same events also contain the wait for CUs the
+    # other 19 steps occupy, which is why that figure is reported separately as in_flight_submit_to_complete_ms.
+    lone = None
+    if rank == 0 and diag_streams is None:
+        lib.amk__timing_enable(2)
+        reps = 6   # always the frames of in-flight slot 0 = the scenes of `bench.py --streams 1` (the committed rocprof trace)
+        for j in range(reps):
+            pl.wait(one_step_and_slot(j, frames=0))
+        torch.cuda.synchronize()
+        ms1 = (C.c_double * 8)(); cnt1 = (C.c_int * 8)()
+        capi.check(lib.amk__timing_collect(ms1, cnt1), "timing")
+        lib.amk__timing_enable(0)
+        lone = {KCLASS[i]: {"avg_launch_us": round(1e3 * ms1[i] / cnt1[i], 2), "launches_per_step": cnt1[i] / reps}
+                for i in range(8) if cnt1[i] and KCLASS[i]}
     breakdown = None
     if args.breakdown and world == 1:   # (extra steps on one rank would unbalance the collectives)
         lib.amk__timing_enable(2)
@@ -381,38 +413,53 @@ def main():
     if rank == 0:
         total_scenes = S * world * args.steps
         value = total_scenes / dt
-        solve_launches = max(cnt[5], 1)
-        solve_ms = ms[5] / solve_launches or 1e-9
-        alg_launch = solve_alg_bytes(N, prm.K) * S
-        achieved = alg_launch / (solve_ms * 1e-3) / 1e9
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
-        build_ms = ms[7] / max(cnt[7], 1) or 1e-9
+        alg_launch = solve_alg_bytes(N, prm.K) * S
         build_alg = 28 * S * (n + ne) // 2       # 12 B read + 16 B written per point; mean of the obstacle and the edge launch
-        traffic, build_traffic, traffic_src, issue = None, None, None, None
-        tpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic.json")
-        if os.path.exists(tpath):   # PMC passes cannot run inside this process: reuse the committed rocprofv3 result
-            tj = json.load(open(tpath))
+        inflight_solve_ms = ms[5] / max(cnt[5], 1)
+        inflight_build_ms = ms[7] / max(cnt[7], 1)
+        solve_us = lone["mpc_solve_kernel"]["avg_launch_us"] if lone else None
+        build_us = lone["kd_build_kernel"]["avg_launch_us"] if lone else None
+        prof = {}
+        for key, fname in (("traffic", "pmc_traffic"), ("issue", "pmc_solve_issue"), ("kt1", "kernel_stats_streams1"),
+                           ("kt20", "kernel_stats")):
+            fpath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_{fname}.json")
+            if os.path.exists(fpath):
+                prof[key] = json.load(open(fpath))
+        traffic = build_traffic = traffic_src = None
+        tj = prof.get("traffic")
+        if tj:   # PMC passes cannot run inside this process: reuse the committed rocprofv3 result of the same command
             m = tj.get("_meta", {})
             if (m.get("scenes_per_gpu"), m.get("points"), m.get("horizon"), m.get("K")) == (S, n, N, prm.K):
-                kk = tj["kernels"].get(f"mpc_solve_kernel<{N}>")
-                kb = tj["kernels"].get("kd_build_kernel")
-                if kb:
-                    build_traffic = round(kb["hbm_bytes_per_launch_x2"])
-                if kk:
-                    traffic = round(kk["hbm_bytes_per_launch_x2"])
-                    traffic_src = f"profiles/{PROFILE_TAG}_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
-        lone_build = None   # the obstacle build alone on the chip (single-stream kernel trace): the kernel's own roofline
-        spath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_stats_streams1.json")
-        if os.path.exists(spath) and (S, n) == (256, 50000):
-            kb1 = json.load(open(spath))["kernels"].get("kd_build_kernel")
-            if kb1:   # max = the obstacle launch (the edge launch is the min)
-                lone_build = {"obstacle_launch_us": kb1["max_us"], "alg_bytes": 28 * S * n,
-                              "achieved": round(28 * S * n / (kb1["max_us"] * 1e-6) / 1e9, 1), "unit": "GB/s",
-                              "frac": round(28 * S * n / (kb1["max_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                              "source": f"profiles/{PROFILE_TAG}_kernel_stats_streams1.md"}
-        ipath = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_solve_issue.json")
-        if os.path.exists(ipath):
-            issue = json.load(open(ipath))
+                kk = tj["kernels"].get(f"mpc_solve_kernel<{N}>"); kb = tj["kernels"].get("kd_build_kernel")
+                traffic = round(kk["hbm_bytes_per_launch_x2"]) if kk else None
+                build_traffic = round(kb["hbm_bytes_per_launch_x2"]) if kb else None
+                traffic_src = f"profiles/{PROFILE_TAG}_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, KiB, separate passes)"
+
+        def rocprof_us(which, kernel):
+            k = (prof.get(which) or {}).get("kernels", {}).get(kernel)
+            return k["avg_us"] if k else None
+        # what bounds the dominant kernel (SQ counters of the committed profile): VALU issue slots.  Live part: how many
+        # solves the timed region ran per second; committed part: VALU instructions per wave-solve (a property of the
+        # kernel on this workload, profiles/r03_pmc_solve_issue.json), 4 issue cycles each on one of 1024 SIMDs.
+        issue = prof.get("issue")
+        valu_per_solve = issue["valu_instructions_per_wave_solve"] if issue else None
+        solves_per_s = value * solves
+        valu_frac_timed = (solves_per_s * valu_per_solve * 4 / (N_CU * N_SIMD * CLOCK_GHZ * 1e9)) if valu_per_solve else None
+        hbm = lambda nbytes, us: None if not us else round(nbytes / (us * 1e-6) / 1e9, 2)
+        frac = lambda gbs: None if gbs is None else round(gbs / HBM_PEAK_GBS, 6)
+        roof_solve_hbm = {
+            "bound": "hbm", "kernel": f"mpc_solve_kernel<{N}>", "alg_bytes_per_launch": alg_launch,
+            "avg_launch_us": solve_us, "achieved": hbm(alg_launch, solve_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": frac(hbm(alg_launch, solve_us)), "traffic": traffic, "traffic_source": traffic_src,
+            "rocprof_avg_us_same_command": rocprof_us("kt1", f"mpc_solve_kernel<{N}>"),
+            "in_flight_submit_to_complete_ms": round(inflight_solve_ms, 4), "in_flight_launches": cnt[5],
+            "in_flight_rocprof_avg_us": rocprof_us("kt20", f"mpc_solve_kernel<{N}>"),
+            "note": "HBM view of the dominant kernel, kept because the contract asks for bytes / launch duration: the kernel "
+                    "moves 4 MB per launch and is nowhere near this roofline by construction (a serial interior-point solve "
+                    "per wavefront).  avg_launch_us: HIP events on the launch stream with one step on the chip at a time "
+                    "(= rocprofv3's kernel duration of `bench.py --streams 1`, profiles/); in_flight_*: the same events in "
+                    "the timed region, where they also contain the wait for CUs held by the other steps in flight"}
         line = {
             "metric": f"MPC steps/sec ({n // 1000}k-pt cloud, N={N}, {prm.K} obstacle constraints)",
             "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
@@ -435,27 +482,38 @@ def main():
                                        f"controls, {args.steps} x {S} x 4 doubles per rank, inside the timed region" if collective
                                        else "single GPU, no process group"),
                        "orchestration": "amk_pipeline_* (C ABI): submit() per step, drain() at the end"},
-            "roofline": {"bound": "hbm", "kernel": "mpc_solve_kernel", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(solve_ms, 4), "launches": cnt[5],
-                         "alg_bytes_per_launch": alg_launch,
-                         "note": "dominant kernel by time, NOT bound by HBM: a serial interior-point solve per wavefront, "
-                                 "limited by dependent fp64 / LDS latency at the 8 waves per CU its LDS footprint allows "
-                                 "(roofline_solve_issue, DESIGN.md section 5); avg_launch_ms is submit-to-complete on the launch stream with the "
-                                 "other in-flight steps sharing the chip"},
+            "roofline": {"bound": "valu-issue (dependent fp64 / LDS latency at 2 waves per SIMD; neither HBM nor MFMA)",
+                         "kernel": f"mpc_solve_kernel<{N}>",
+                         "achieved": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),
+                         "peak": round(N_CU * N_SIMD * CLOCK_GHZ, 1), "unit": "G VALU issue cycles/s (1024 SIMDs x 2.4 GHz)",
+                         "frac": None if valu_frac_timed is None else round(valu_frac_timed, 4),
+                         "frac_at_saturation_solves_only": issue.get("valu_issue_util_at_saturation") if issue else None,
+                         "lds_array_frac_at_saturation": issue.get("lds_array_util_at_saturation (conflict level of the lone wave)") if issue else None,
+                         "valu_instructions_per_wave_solve": valu_per_solve, "solves_per_s_timed_region": round(solves_per_s, 1),
+                         "traffic": traffic, "hbm": roof_solve_hbm,
+                         "note": "frac = (solves/s of the timed region) x (VALU instructions per wave-solve, SQ_INSTS_VALU of the "
+                                 "committed profile) x 4 issue cycles / (1024 SIMDs x 2.4 GHz): the share of the chip's VALU issue "
+                                 "slots the dominant kernel fills while the builds and searches of the other steps share the CUs; "
+                                 "frac_at_saturation_solves_only is the same quantity with nothing but solves resident "
+                                 "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (LDS 19.8 KB and 224 "
+                                 "VGPRs per scene) cannot cover ~32-cycle dependent fp64 issue and LDS round trips "
+                                 f"(profiles/{PROFILE_TAG}_pmc_solve_issue.md, DESIGN.md section 5)"},
+            "roofline_hbm": roof_solve_hbm,
             "roofline_solve_issue": issue,
             "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (obstacle + edge launch averaged)",
-                                  "alg_bytes_per_launch": build_alg, "avg_launch_ms": round(build_ms, 4),
-                                  "launches": cnt[7], "achieved": round(build_alg / (build_ms * 1e-3) / 1e9, 1),
-                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(build_alg / (build_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                  "traffic": build_traffic, "single_stream": lone_build,
+                                  "alg_bytes_per_launch": build_alg, "avg_launch_us": build_us,
+                                  "achieved": hbm(build_alg, build_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": frac(hbm(build_alg, build_us)), "traffic": build_traffic,
+                                  "rocprof_avg_us_same_command": rocprof_us("kt1", "kd_build_kernel"),
+                                  "in_flight_submit_to_complete_ms": round(inflight_build_ms, 4), "in_flight_launches": cnt[7],
+                                  "in_flight_rocprof_avg_us": rocprof_us("kt20", "kd_build_kernel"),
                                   "note": "the HBM-heavy kernel: algorithmic 28 B per point (12 read, 16 written as a bucket "
-                                          "record); avg_launch_ms is submit-to-complete with the other in-flight steps "
-                                          "sharing the chip (single-stream kernel times: profiles/)"},
+                                          "record), obstacle (50k points) and edge (5k) launch averaged like rocprofv3's "
+                                          "per-kernel average; avg_launch_us with one step on the chip at a time"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},
+            "kernels_single_stream": lone,
             "parity": parity,
             "cpu_baseline": cpu,
         }
