@@ -26,7 +26,7 @@ PLUGIN_SYMBOLS = [f for f in PLUGIN_FUNCTIONS] + [f + "_" + h for f in PLUGIN_FU
 # every symbol include/avoid_mpc_amd.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "amk_version", "amk_status_string", "amk_last_hip_error", "amk_device_count",
-    "amk_kd_create", "amk_kd_destroy", "amk_kd_build", "amk_kd_sizes", "amk_kd_search",
+    "amk_kd_create", "amk_kd_destroy", "amk_kd_build", "amk_kd_build_pair", "amk_kd_sizes", "amk_kd_search",
     "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_set_tie_order", "amk_kd_keyframe_sweep",
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
@@ -113,6 +113,7 @@ def load():
         "amk_kd_create": (i, [i, i, C.POINTER(vp)]),
         "amk_kd_destroy": (i, [vp]),
         "amk_kd_build": (i, [vp, vp, i, ll, vp, vp]),
+        "amk_kd_build_pair": (i, [vp, vp, vp, vp, vp, vp, i, vp]),
         "amk_kd_sizes": (i, [vp, vp, vp]),
         "amk_kd_search": (i, [vp, vp, i, i, vp, vp, vp, vp, vp]),
         "amk_kd_tie_flags": (i, [vp, vp, i, i, i, vp, vp]),

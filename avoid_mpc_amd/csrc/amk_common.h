@@ -91,6 +91,7 @@ struct amk_kd {
     int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
     // opt-in "nanoflann tie order" (amk_kd_set_tie_order, kd_exact.h): the reference's own tree, built beside the bucketed index
     int tie_order = 0;
+    int ex_valid = 0;   // host flag: the exact tree was built from the cloud the bucketed index currently holds
     int ex_max_nodes = 0;
     amk::DevBuf<unsigned> ex_vind, ex_left, ex_right, ex_sa, ex_sb;
     amk::DevBuf<int> ex_feat, ex_child, ex_nn;

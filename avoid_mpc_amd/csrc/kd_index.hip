@@ -126,11 +126,29 @@ __device__ __forceinline__ void sample_bbox_scene(int s, const float *__restrict
 // needs them (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand
 // (ensure_soa).
 static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
-__global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(
-    const float *__restrict__ xyz, int point_stride, long long scene_stride, const int *__restrict__ counts,
-    int max_points, int cap, int *__restrict__ grp_all, int grp_stride, int *__restrict__ size_out,
-    float *__restrict__ pmax_out, float *__restrict__ bbox_out, float4 *__restrict__ GP,
-    int *__restrict__ cell_start, double *__restrict__ gparams) {
+struct BuildArgs {   // one tree's InitializeNew
+    const float *xyz;
+    int point_stride;
+    long long scene_stride;
+    const int *counts;
+    int max_points, cap;
+    int *grp_all;
+    int grp_stride;
+    int *size_out;
+    float *pmax_out, *bbox_out;
+    float4 *GP;
+    int *cell_start;
+    double *gparams;
+};
+// grid = (scenes, trees): blockIdx.y selects the tree.  FrameKDMap::AddVertex builds TWO trees per depth frame (obstacle +
+// edge cloud, FrameKDMap.cpp:44-47): amk_kd_build_pair issues them as one launch, so the small edge build (24 us alone,
+// mostly latency) runs in the shadow of the obstacle build instead of behind it.
+__device__ __forceinline__ void build_one_tree(const float *__restrict__ xyz, int point_stride, long long scene_stride,
+                                               const int *__restrict__ counts, int max_points, int cap,
+                                               int *__restrict__ grp_all, int grp_stride, int *__restrict__ size_out,
+                                               float *__restrict__ pmax_out, float *__restrict__ bbox_out,
+                                               float4 *__restrict__ GP, int *__restrict__ cell_start,
+                                               double *__restrict__ gparams) {
     const int s = blockIdx.x;
     const float *src = xyz + (long long)s * scene_stride;
     int n = counts ? counts[s] : max_points;
@@ -139,6 +157,16 @@ __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(
     sample_bbox_scene(s, src, point_stride, n, bbox_out);
     const amk::RawSrc rs{src, point_stride, grp, size_out + s, pmax_out + s};
     amk::grid_build_scene(s, rs, cap, n, n, bbox_out, GP, cell_start, gparams);
+}
+struct BuildArgs2 { BuildArgs t[2]; };
+__global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildArgs2 args) {
+    const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
+    build_one_tree(a.xyz, a.point_stride, a.scene_stride, a.counts, a.max_points, a.cap, a.grp_all, a.grp_stride, a.size_out,
+                   a.pmax_out, a.bbox_out, a.GP, a.cell_start, a.gparams);
+}
+static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride, const int *d_counts) {
+    return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p, kd->cap / kWave + 2,
+                     kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p};
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
@@ -362,6 +390,7 @@ static int exact_build(amk_kd *kd, hipStream_t stream) {
     hipLaunchKernelGGL(kd_exact_build_kernel, dim3(kd->n_scenes), dim3(amk::kExactThreads), 0, stream, exact_ptrs(kd),
                        kd->size.p);
     AMK_HIP(hipGetLastError());
+    kd->ex_valid = 1;
     return AMK_OK;
 }
 
@@ -515,6 +544,7 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
                        keyframe->cell_start.p, keyframe->gparams.p);
     keyframe->async_pending = 1;
     AMK_HIP(hipGetLastError());
+    keyframe->ex_valid = 0;   // a rebuilt keyframe's old tree describes another cloud
     if (keyframe->tie_order) return exact_build(keyframe, stream);  // (the planes are valid: the sweep compacted them)
     return AMK_OK;
 }
@@ -630,14 +660,39 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
     if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
-        hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes), dim3(kCompactThreads), 0, (hipStream_t)stream, d_xyz,
-                           point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p, kd->cap / kWave + 2,
-                           kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p);
+        const BuildArgs a = build_args(kd, d_xyz, point_stride, scene_stride, d_counts);
+        hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes, 1), dim3(kCompactThreads), 0, (hipStream_t)stream, BuildArgs2{{a, a}});
         kd->soa_valid = 0;
+        kd->ex_valid = 0;   // the exact tree (if any) describes the previous cloud until exact_build has run
         kd->async_pending = 1;
     }
     AMK_HIP(hipGetLastError());
     if (kd->tie_order) return exact_build(kd, (hipStream_t)stream);
+    return AMK_OK;
+}
+
+int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts, amk_kd *edge, const float *d_edge_xyz,
+                      const int *d_edge_counts, int point_stride, void *stream) {
+    if (!obstacle || !edge || obstacle->n_scenes != edge->n_scenes || point_stride < 3 || (!d_xyz && obstacle->max_points > 0) ||
+        (!d_edge_xyz && edge->max_points > 0))
+        return AMK_ERR_INVALID_ARG;
+    {
+        amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
+        const BuildArgs a = build_args(obstacle, d_xyz, point_stride, (long long)obstacle->max_points * point_stride, d_counts);
+        const BuildArgs b = build_args(edge, d_edge_xyz, point_stride, (long long)edge->max_points * point_stride, d_edge_counts);
+        hipLaunchKernelGGL(kd_build_kernel, dim3(obstacle->n_scenes, 2), dim3(kCompactThreads), 0, (hipStream_t)stream, BuildArgs2{{a, b}});
+        for (amk_kd *kd : {obstacle, edge}) {
+            kd->soa_valid = 0;
+            kd->ex_valid = 0;
+            kd->async_pending = 1;
+        }
+    }
+    AMK_HIP(hipGetLastError());
+    for (amk_kd *kd : {obstacle, edge})
+        if (kd->tie_order) {
+            const int st = exact_build(kd, (hipStream_t)stream);
+            if (st != AMK_OK) return st;
+        }
     return AMK_OK;
 }
 
@@ -673,7 +728,7 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
         hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p,
                            kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts);
         AMK_HIP(hipGetLastError());
-        if (kd->tie_order && kd->ex_vind.p) {  // nanoflann's own traversal where its tree is available
+        if (kd->tie_order && kd->ex_valid) {  // nanoflann's own traversal where its tree is available (and current)
             const size_t rows = (size_t)kd->n_scenes * n_queries;
             hipLaunchKernelGGL(kd_exact_search_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
                                exact_ptrs(kd), kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts,

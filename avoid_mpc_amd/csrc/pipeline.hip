@@ -111,9 +111,7 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *slot_
     int st = AMK_OK;
     if (!f->keep_warm_start && (st = amk_mpc_reset_warm_start(s.mpc, s.stream)) != AMK_OK) return st;
     // FrameKDMap::AddVertex: obstacle index and edge index of the frame (FrameKDMap.cpp:44-47)
-    if ((st = amk_kd_build(s.obstacle, f->d_cloud, stride, (long long)c.max_points * stride, f->d_cloud_counts, s.stream)) != AMK_OK)
-        return st;
-    if ((st = amk_kd_build(s.edge, f->d_edge, stride, (long long)c.max_edge_points * stride, f->d_edge_counts, s.stream)) != AMK_OK)
+    if ((st = amk_kd_build_pair(s.obstacle, f->d_cloud, f->d_cloud_counts, s.edge, f->d_edge, f->d_edge_counts, stride, s.stream)) != AMK_OK)
         return st;
     double *u = f->d_u_out ? f->d_u_out : s.u.p;
     if ((st = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, f->d_state_quad, f->d_pos_x, s.ref_path.p, u, s.x0array.p,

@@ -363,8 +363,8 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         mpc->mf_exact_host.assign(sizeof(FrameExact), 0);
         FrameExact *h = reinterpret_cast<FrameExact *>(mpc->mf_exact_host.data());
         for (int f = 0; f < F; ++f) {
-            h->use_obs[f] = obstacle[f]->tie_order && obstacle[f]->ex_vind.p;
-            h->use_edge[f] = edge[f]->tie_order && edge[f]->ex_vind.p;
+            h->use_obs[f] = obstacle[f]->tie_order && obstacle[f]->ex_valid;
+            h->use_edge[f] = edge[f]->tie_order && edge[f]->ex_valid;
             if (h->use_obs[f]) h->obs[f] = amk_exact_ptrs(obstacle[f]);
             if (h->use_edge[f]) h->edge[f] = amk_exact_ptrs(edge[f]);
             any_exact |= h->use_obs[f] || h->use_edge[f];

@@ -109,6 +109,14 @@ class KdBatch:
         return dict(indices=idx, sqdist=d2, pts=pts, counts=cnt)
 
 
+def kd_build_pair(kd_obstacle, xyz, kd_edge, edge_xyz, counts=None, edge_counts=None, stream=None):
+    """amk_kd_build_pair: FrameKDMap::AddVertex's two InitializeNew calls as one launch (clouds packed [S, max_points, 3|4])."""
+    assert xyz.dtype == torch.float32 and edge_xyz.dtype == torch.float32 and xyz.shape[2] == edge_xyz.shape[2]
+    assert xyz.shape[1] == kd_obstacle.max_points and edge_xyz.shape[1] == kd_edge.max_points
+    capi.check(capi.load().amk_kd_build_pair(kd_obstacle.h, capi.dptr(xyz), capi.dptr(counts), kd_edge.h, capi.dptr(edge_xyz),
+                                             capi.dptr(edge_counts), int(xyz.shape[2]), capi.stream_ptr(stream)), "amk_kd_build_pair")
+
+
 def kd_tie_flags(kd, queries, k, query_stride=3, stream=None):
     """amk_kd_tie_flags: int32 [S, n_queries], 1 where the k nearest (or the k-th and the best rejected) hold an exact tie."""
     S = kd.S if hasattr(kd, "S") else queries.shape[0]

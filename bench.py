@@ -415,7 +415,7 @@ def main():
         value = total_scenes / dt
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
         alg_launch = solve_alg_bytes(N, prm.K) * S
-        build_alg = 28 * S * (n + ne) // 2       # 12 B read + 16 B written per point; mean of the obstacle and the edge launch
+        build_alg = 28 * S * (n + ne)            # 12 B read + 16 B written per point; ONE launch builds the obstacle and the edge index (amk_kd_build_pair)
         inflight_solve_ms = ms[5] / max(cnt[5], 1)
         inflight_build_ms = ms[7] / max(cnt[7], 1)
         solve_us = lone["mpc_solve_kernel"]["avg_launch_us"] if lone else None
@@ -500,7 +500,7 @@ def main():
                                  f"(profiles/{PROFILE_TAG}_pmc_solve_issue.md, DESIGN.md section 5)"},
             "roofline_hbm": roof_solve_hbm,
             "roofline_solve_issue": issue,
-            "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (obstacle + edge launch averaged)",
+            "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (one launch: obstacle + edge index of every scene)",
                                   "alg_bytes_per_launch": build_alg, "avg_launch_us": build_us,
                                   "achieved": hbm(build_alg, build_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": frac(hbm(build_alg, build_us)), "traffic": build_traffic,
@@ -508,8 +508,8 @@ def main():
                                   "in_flight_submit_to_complete_ms": round(inflight_build_ms, 4), "in_flight_launches": cnt[7],
                                   "in_flight_rocprof_avg_us": rocprof_us("kt20", "kd_build_kernel"),
                                   "note": "the HBM-heavy kernel: algorithmic 28 B per point (12 read, 16 written as a bucket "
-                                          "record), obstacle (50k points) and edge (5k) launch averaged like rocprofv3's "
-                                          "per-kernel average; avg_launch_us with one step on the chip at a time"},
+                                          "record), both trees of a frame in one launch (grid.y = tree); "
+                                          "avg_launch_us with one step on the chip at a time"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},

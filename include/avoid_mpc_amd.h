@@ -62,6 +62,11 @@ int amk_kd_destroy(amk_kd *kd);
 int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride,
                  const int *d_counts, void *stream);
 
+/* FrameKDMap::AddVertex's two InitializeNew calls (obstacle cloud + edge cloud of one depth frame, FrameKDMap.cpp:44-47) as
+ * ONE launch: both clouds packed [S][max_points of the handle][point_stride]; results identical to two amk_kd_build calls. */
+int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts, amk_kd *edge, const float *d_edge_xyz,
+                      const int *d_edge_counts, int point_stride, void *stream);
+
 /* cloud.pts.size() per scene after the NaN-x filter (synchronises the stream).                   */
 int amk_kd_sizes(amk_kd *kd, int *h_sizes, void *stream);
 
@@ -96,7 +101,9 @@ int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int 
  * takes a fraction of one: meant for the reference's real frame sizes (<= 3072 points, quantised edge clouds), set it
  * before amk_kd_build.  amk_step_batch and amk_step_batch_frames honour it (queries and the edge snap's
  * re-query then go through nanoflann's traversal too).  A scene whose tree would exceed the node capacity
- * (cap / 2 + 64) or a traversal depth of 60 -- pathological data -- keeps the bucketed index's answer.              */
+ * (cap / 2 + 64) or a traversal depth of 48 -- pathological data -- keeps the bucketed index's answer.  The mode takes effect at the NEXT
+ * build: a search between amk_kd_set_tie_order(NANOFLANN) and that build still answers from the bucketed index (the
+ * handle tracks whether its exact tree belongs to the cloud it currently holds).                                        */
 #define AMK_TIES_LOWEST_INDEX 0
 #define AMK_TIES_NANOFLANN 1
 int amk_kd_set_tie_order(amk_kd *kd, int mode);

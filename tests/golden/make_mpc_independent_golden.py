@@ -21,7 +21,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-G = np.load(os.path.join(ROOT, "tests", "golden", "mpc_parity_golden.npz"))
+G = dict(np.load(os.path.join(ROOT, "tests", "golden", "mpc_parity_golden.npz")))   # in memory: the workers are forked
 
 
 def problem(cfg, s):
@@ -56,13 +56,12 @@ def one(job):
 
 
 def main():
-    cfgs = sys.argv[1:] or ["C1", "C2", "C5"]
-    jobs = [(cfg, s) for cfg in cfgs for s in range(64)]
-    with ProcessPoolExecutor(int(os.environ.get("NPROC", "8"))) as ex:
-        res = list(ex.map(one, jobs, chunksize=1))
     path = os.path.join(ROOT, "tests", "golden", "mpc_independent_golden.npz")
-    out = dict(np.load(path)) if os.path.exists(path) else {}
-    for cfg in cfgs:
+    for cfg in sys.argv[1:] or ["C1", "C2", "C5"]:   # saved after every size
+        jobs = [(cfg, s) for s in range(64)]
+        with ProcessPoolExecutor(int(os.environ.get("NPROC", "8"))) as ex:
+            res = list(ex.map(one, jobs, chunksize=1))
+        out = dict(np.load(path)) if os.path.exists(path) else {}
         rr = [r for r in res if r["cfg"] == cfg]
         st = lambda k: np.array([r[k] for r in rr])
         out.update({cfg + ".ipopt10.u": st("u10"), cfg + ".ipopt10.f": st("f10"), cfg + ".ipopt10.theta": st("th10"),
@@ -70,8 +69,8 @@ def main():
                     cfg + ".ipoptc.u": st("uc"), cfg + ".ipoptc.f": st("fc"), cfg + ".ipoptc.status": st("stc"),
                     cfg + ".ipoptc.iters": st("itc"), cfg + ".tc.u": st("utc"), cfg + ".tc.f": st("ftc"),
                     cfg + ".tc.status": st("sttc"), cfg + ".tc.nit": st("nittc"), cfg + ".tc.viol": st("violtc")})
-    np.savez_compressed(path, **out)
-    print("wrote", path, os.path.getsize(path), "bytes")
+        np.savez_compressed(path, **out)
+        print("wrote", path, os.path.getsize(path), "bytes", flush=True)
 
 
 if __name__ == "__main__":

@@ -298,3 +298,64 @@ def test_nanoflann_tie_order_mode(torch_cuda, oracle):
                 differ_default += not np.array_equal(t.bruteforce(q, k)[0][:len(ia)], ia)
         kd.close()
     assert differ_default > 50     # the default (lowest-index) policy does differ on these clouds: the mode matters
+
+
+def test_pair_build_equals_two_builds(torch_cuda, oracle):
+    """amk_kd_build_pair (FrameKDMap::AddVertex's two InitializeNew calls as one launch, grid.y = tree): the obstacle and
+    the edge index answer exactly like two separately built ones -- ragged counts, NaN-x points, 16-byte stride."""
+    torch = torch_cuda
+    from avoid_mpc_amd.host import KdBatch, kd_build_pair
+    rng = np.random.default_rng(21)
+    S, n, ne = 6, 3000, 400
+    cl = np.zeros((S, n, 4), np.float32); ed = np.zeros((S, ne, 4), np.float32)
+    cn = np.array([3000, 2999, 17, 0, 1024, 2500], np.int32); en = np.array([400, 0, 9, 1, 399, 64], np.int32)
+    for s in range(S):
+        c, e = synth.make_cloud(n, 500 + s)
+        cl[s, :, :3] = c; ed[s, :len(e[:ne]), :3] = e[:ne]
+    cl[0, ::13, 0] = np.nan
+    kd_o, kd_e, ref_o, ref_e = KdBatch(S, n), KdBatch(S, ne), KdBatch(S, n), KdBatch(S, ne)
+    d_cl, d_ed = torch.from_numpy(cl).cuda(), torch.from_numpy(ed).cuda()
+    d_cn, d_en = torch.from_numpy(cn).cuda(), torch.from_numpy(en).cuda()
+    kd_build_pair(kd_o, d_cl, kd_e, d_ed, d_cn, d_en)
+    ref_o.build(d_cl, d_cn); ref_e.build(d_ed, d_en)
+    qs = torch.from_numpy(np.stack([rng.uniform(0, 20, (S, 16)), rng.uniform(-4, 4, (S, 16)), rng.uniform(0, 3, (S, 16))], -1)).cuda()
+    for a, b, k in ((kd_o, ref_o, 8), (kd_e, ref_e, 1), (kd_e, ref_e, 3)):
+        ra, rb = a.search(qs, k), b.search(qs, k)
+        torch.cuda.synchronize()
+        assert np.array_equal(a.sizes(), b.sizes())
+        for key in ("indices", "sqdist", "pts", "counts"):
+            assert torch.equal(ra[key], rb[key]), key
+    # and against the oracle for one scene of each tree
+    t = _oracle.kd_oracle(cl[0, :cn[0], :3])
+    r = kd_o.search(qs, 8)
+    for q in range(16):
+        ia, da, _ = t.search(qs[0, q].cpu().numpy(), 8)
+        assert np.array_equal(r["indices"][0, q, :len(ia)].cpu().numpy(), ia)
+        assert np.array_equal(r["sqdist"][0, q, :len(ia)].cpu().numpy(), da)
+
+
+def test_exact_tree_is_never_used_stale(torch_cuda, oracle):
+    """NANOFLANN mode, build; back to LOWEST_INDEX, rebuild with ANOTHER cloud; NANOFLANN again WITHOUT a build: the
+    tree of the first cloud must not be walked over the second cloud's points -- until the next build the bucketed index
+    answers (lowest-index order), afterwards nanoflann's order again."""
+    torch = torch_cuda
+    from avoid_mpc_amd.host import KdBatch
+    g1 = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    g2 = (g1[::-1] * 0.5 + 3.0).astype(np.float32).copy()
+    kd = KdBatch(1, len(g1))
+    q = np.array([[[3.5, 3.5, 3.5], [4.25, 4.25, 4.25], [0.1, 7.0, 2.0]]])
+    dq = torch.from_numpy(q).cuda()
+    kd.set_tie_order(1); kd.build(torch.from_numpy(g1[None].copy()).cuda())
+    kd.set_tie_order(0); kd.build(torch.from_numpy(g2[None].copy()).cuda())
+    kd.set_tie_order(1)
+    r = kd.search(dq, 4); torch.cuda.synchronize()
+    t2 = _oracle.kd_oracle(g2)
+    for i in range(3):
+        ib, db = t2.bruteforce(q[0, i], 4)                      # lowest index among equal distances
+        assert np.array_equal(r["sqdist"][0, i].cpu().numpy(), db)
+        assert np.array_equal(r["indices"][0, i].cpu().numpy(), ib)
+    kd.build(torch.from_numpy(g2[None].copy()).cuda())          # now the tree belongs to g2
+    r = kd.search(dq, 4); torch.cuda.synchronize()
+    for i in range(3):
+        ia, da, _ = t2.search(q[0, i], 4)
+        assert np.array_equal(r["indices"][0, i].cpu().numpy(), ia) and np.array_equal(r["sqdist"][0, i].cpu().numpy(), da)

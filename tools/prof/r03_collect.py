@@ -71,7 +71,7 @@ n, ne, S = cfg["points"], cfg["points"] // 10, cfg["scenes_per_gpu"]
 tj = {k: v for k, v in tj.items() if any(t in k for t in ("mpc_", "kd_", "step_"))}
 json.dump({"_meta": {"scenes_per_gpu": S, "points": n, "horizon": cfg["horizon"], "K": cfg["K"], "streams": 1,
                      "units": "FETCH_SIZE / WRITE_SIZE in KiB (MI355X_MICROARCH.md, HBM section); x2 = gfx950 wide-read correction",
-                     "algorithmic_bytes_per_launch": {"kd_build_kernel (obstacle+edge averaged)": 28 * S * (n + ne) // 2}},
+                     "algorithmic_bytes_per_launch": {"kd_build_kernel (one launch: obstacle + edge index)": 28 * S * (n + ne)}},
            "kernels": tj}, open(os.path.join(dst, "r03_pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "r03_pmc_traffic.md"), "w").write(
     "HBM traffic per launch, `bench.py --steps 8 --warmup 2 --streams 1` under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
