@@ -58,7 +58,7 @@ class StepParams(C.Structure):
 class PipelineConfig(C.Structure):
     """amk_pipeline_config"""
     _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
-                ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("reserved", C.c_int),
+                ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("queue_depth", C.c_int),
                 ("step", StepParams)]
 
 

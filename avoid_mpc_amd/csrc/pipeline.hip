@@ -10,6 +10,7 @@
 // FrameKDMap::AddVertex (FrameKDMap.cpp:34-52) -> AvoidanceStateMachine::Step.
 #include "mpc_handle.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -17,17 +18,36 @@ struct amk_pipeline {
     amk_pipeline_config cfg;
     struct Slot {
         hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
+        std::vector<hipEvent_t> done;   // ring of queue_depth events: done[k % depth] marks the end of the slot's k-th step
+        long long count = 0;            // steps submitted on this slot
+        long long waited = 0;           // steps known to have finished
         amk_kd *obstacle = nullptr, *edge = nullptr;
         amk_mpc *mpc = nullptr;
         amk::DevBuf<double> ref_path, u, x0array;
         amk::DevBuf<int> flags;
-        bool busy = false;
     };
+    int depth = 1;
     std::vector<Slot> slots;
     int next = 0;
     long long submitted = 0;
 };
+
+namespace {
+// Waits for a slot's step.  hipEventSynchronize parks the thread on an HSA signal; with AMK_PIPELINE_SPIN=1 the thread polls
+// hipEventQuery instead (diagnostics: tools/experiments/rccl_presence.py).
+int wait_event(hipEvent_t ev) {
+    static const bool spin = [] { const char *e = std::getenv("AMK_PIPELINE_SPIN"); return e && e[0] == '1'; }();
+    if (!spin) {
+        AMK_HIP(hipEventSynchronize(ev));
+        return AMK_OK;
+    }
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return AMK_OK;
+        if (e != hipErrorNotReady) return amk::hip_fail(e);
+    }
+}
+}  // namespace
 
 extern "C" {
 
@@ -39,12 +59,20 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
     if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
     amk_pipeline *p = new amk_pipeline();
     p->cfg = *cfg;
+    p->depth = cfg->queue_depth > 0 ? cfg->queue_depth : AMK_PIPELINE_DEFAULT_DEPTH;
+    if (p->depth > AMK_PIPELINE_MAX_DEPTH) p->depth = AMK_PIPELINE_MAX_DEPTH;
     p->slots.resize(cfg->n_slots);
     int st = AMK_OK;
     for (auto &s : p->slots) {
         hipError_t e;
-        if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipEventCreateWithFlags(&s.done, hipEventDisableTiming)) != hipSuccess) {
+        if ((e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking)) != hipSuccess) {
+            st = amk::hip_fail(e);
+            break;
+        }
+        s.done.assign(p->depth, nullptr);
+        for (auto &ev : s.done)
+            if ((e = hipEventCreateWithFlags(&ev, hipEventDisableTiming)) != hipSuccess) break;
+        if (e != hipSuccess) {
             st = amk::hip_fail(e);
             break;
         }
@@ -73,7 +101,8 @@ int amk_pipeline_destroy(amk_pipeline *p) {
         if (s.obstacle) amk_kd_destroy(s.obstacle);
         if (s.edge) amk_kd_destroy(s.edge);
         if (s.mpc) amk_mpc_destroy(s.mpc);
-        if (s.done) (void)hipEventDestroy(s.done);
+        for (auto ev : s.done)
+            if (ev) (void)hipEventDestroy(ev);
         if (s.stream) (void)hipStreamDestroy(s.stream);
     }
     delete p;
@@ -98,9 +127,14 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *slot_
         return AMK_ERR_INVALID_ARG;
     const int si = p->next;
     auto &s = p->slots[si];
-    if (s.busy) {  // back-pressure: the slot's previous step must have finished before its handles are reused
-        AMK_HIP(hipEventSynchronize(s.done));
-        s.busy = false;
+    // Flow control.  A slot's steps are ordered by its stream, so queuing the next step behind a running one is safe (same
+    // handles, same workspaces, in order); submit() only blocks when `depth` steps of this slot are still unfinished --
+    // the event about to be re-recorded belongs to the step submitted `depth` submits ago.  depth 1 = at most one step per
+    // slot on the device (every step then pays the host's reaction time between its predecessor's end and its own start).
+    if (s.count - s.waited >= p->depth) {
+        const int ws = wait_event(s.done[s.count % p->depth]);
+        if (ws != AMK_OK) return ws;
+        s.waited = s.count - p->depth + 1;
     }
     const amk_pipeline_config &c = p->cfg;
     const int N = amk_mpc_horizon(s.mpc);
@@ -117,8 +151,8 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *slot_
     if ((st = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, f->d_state_quad, f->d_pos_x, s.ref_path.p, u, s.x0array.p,
                              s.flags.p, s.stream)) != AMK_OK)
         return st;
-    AMK_HIP(hipEventRecord(s.done, s.stream));
-    s.busy = true;
+    AMK_HIP(hipEventRecord(s.done[s.count % p->depth], s.stream));
+    ++s.count;
     p->next = (si + 1) % (int)p->slots.size();
     ++p->submitted;
     if (slot_out) *slot_out = si;
@@ -128,9 +162,10 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *slot_
 int amk_pipeline_wait(amk_pipeline *p, int slot) {
     if (!p || slot < 0 || slot >= (int)p->slots.size()) return AMK_ERR_INVALID_ARG;
     auto &s = p->slots[slot];
-    if (s.busy) {
-        AMK_HIP(hipEventSynchronize(s.done));
-        s.busy = false;
+    if (s.waited < s.count) {   // the newest event implies all earlier ones (in-order stream)
+        const int ws = wait_event(s.done[(s.count - 1) % p->depth]);
+        if (ws != AMK_OK) return ws;
+        s.waited = s.count;
     }
     return AMK_OK;
 }
@@ -138,9 +173,9 @@ int amk_pipeline_wait(amk_pipeline *p, int slot) {
 int amk_pipeline_query(amk_pipeline *p, int slot) {  // 1 = finished (or idle), 0 = still running
     if (!p || slot < 0 || slot >= (int)p->slots.size()) return -1;
     auto &s = p->slots[slot];
-    if (!s.busy) return 1;
-    const hipError_t e = hipEventQuery(s.done);
-    if (e == hipSuccess) { s.busy = false; return 1; }
+    if (s.waited >= s.count) return 1;
+    const hipError_t e = hipEventQuery(s.done[(s.count - 1) % p->depth]);
+    if (e == hipSuccess) { s.waited = s.count; return 1; }
     return e == hipErrorNotReady ? 0 : -1;
 }
 

@@ -233,10 +233,10 @@ class MpcBatch:
 class Pipeline:
     """amk_pipeline: n_slots control steps in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs}."""
 
-    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm):
+    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0):
         self.lib = capi.load()
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
-                                  int(prm.K), 0, capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
+                                  int(prm.K), int(queue_depth), capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm

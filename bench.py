@@ -200,6 +200,7 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--streams", type=int, default=20,
                     help="independent steps in flight (each on its own HIP stream with its own frames and handles)")
+    ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1 without, 8 with a process group)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
     ap.add_argument("--ipm-max-iter", type=int, default=None, help="iteration cap of the solve (default: the library's)")
@@ -261,7 +262,11 @@ def main():
             self.last_row = 0
 
     # the C ABI's pipeline (include/avoid_mpc_amd.h: amk_pipeline_*): what a C++ host would call; bench.py only feeds it
-    pl = Pipeline(nslots, S, n, ne, prm)
+    # steps queued per slot before submit() blocks.  1 is best without a communicator (+1-2 %); with a live RCCL communicator in
+    # the process the host sees a finished step ~0.3 ms late (cause not found: tools/experiments/rccl_presence.py) and a slot
+    # that waits for the host idles: 287 k steps/s at depth 1, 384 k at 3, 402 k at 8 -- so the next steps are queued ahead
+    qdepth = args.queue_depth if args.queue_depth > 0 else (8 if collective else 1)
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=qdepth)
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
         pl.mpc(i).set_precision(args.precision)
@@ -321,15 +326,21 @@ def main():
         t0 = time.perf_counter()
         for j in range(steps):
             one_step(j)
-        t_enq = time.perf_counter() - t0   # host time to enqueue everything (diagnostic: launch-bound if ~= dt)
+        t_enq = time.perf_counter() - t0   # host time in submit(): enqueue + back-pressure waits on busy slots
         if diag_streams is None:
             pl.drain()
+        t_drain = time.perf_counter() - t0
         if collective:   # the ONE exchange step of the sweep: every rank's controls to every rank (ncclAllGather)
             sh.gather(u_sweep[:steps], u_gather(steps))
+            torch.cuda.synchronize()
+        t_gather = time.perf_counter() - t0
         barrier()
-        return time.perf_counter() - t0, t_enq
+        t_all = time.perf_counter() - t0
+        phases["submit_s"], phases["drain_s"], phases["gather_s"], phases["barrier_s"] = t_enq, t_drain - t_enq, t_gather - t_drain, t_all - t_gather
+        return t_all, t_enq
 
     gather_bufs = {}
+    phases = {}
 
     def u_gather(steps):
         if steps not in gather_bufs:
@@ -357,6 +368,7 @@ def main():
             u_gather(k_)
     lib.amk__timing_enable(1)              # HIP events around the solve and build kernels, on their launch stream
     dt, t_enq = timed(args.steps)
+    timed_phases = {k: round(v, 5) for k, v in phases.items()}
     ms = (C.c_double * 8)(); cnt = (C.c_int * 8)()
     capi.check(lib.amk__timing_collect(ms, cnt), "timing")
     lib.amk__timing_enable(0)
@@ -477,11 +489,11 @@ def main():
                        "streams_in_flight": nslots, "distinct_frames_bytes": int(nslots * S * 12 * (n + ne)),
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "tie_order": "nanoflann" if args.tie_order else "lowest index",
-                       "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
+                       "host_submit_ms_per_step": round(1e3 * t_enq / args.steps, 4), "timed_region_phases_s": timed_phases,
                        "parallelism": (f"scenes sharded over {world} GPU(s); one ncclAllGather (amk_shard_gather) of the sweep's "
                                        f"controls, {args.steps} x {S} x 4 doubles per rank, inside the timed region" if collective
                                        else "single GPU, no process group"),
-                       "orchestration": "amk_pipeline_* (C ABI): submit() per step, drain() at the end"},
+                       "orchestration": "amk_pipeline_* (C ABI): submit() per step, drain() at the end", "queue_depth_per_slot": qdepth},
             "roofline": {"bound": "valu-issue (dependent fp64 / LDS latency at 2 waves per SIMD; neither HBM nor MFMA)",
                          "kernel": f"mpc_solve_kernel<{N}>",
                          "achieved": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),

@@ -290,13 +290,15 @@ int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_
 /* One step (both index builds of a fresh frame + amk_step_batch) is a chain of dependent launches around a latency-bound
  * solve: a single stream reaches ~15 % of what the chip does with 20 independent steps in flight.
  * A pipeline owns n_slots slots = {HIP stream, obstacle + edge amk_kd, amk_mpc, reference-path buffer, outputs}; submit()
- * enqueues on the next slot -- per frame the reference's sequence FrameKDMap::AddVertex (FrameKDMap.cpp:34-52: the two
+ * enqueues on the next slot (round robin) -- per frame the reference's sequence FrameKDMap::AddVertex (FrameKDMap.cpp:34-52: the two
  * InitializeNew) -> AvoidanceStateMachine::Step TASK branch (AvoidanceStateMachine.cpp:322-355) -- and returns at once;
- * it blocks only when that slot's previous step is still running.  The host should export GPU_MAX_HW_QUEUES >= n_slots
+ * it blocks only when queue_depth steps of that slot are still unfinished.  The host should export GPU_MAX_HW_QUEUES >= n_slots
  * before the first HIP call (ROCm multiplexes streams onto 4 hardware queues by default; two streams on one queue
  * serialise).  Input buffers belong to the caller and must stay valid until the slot has finished.                      */
 typedef struct amk_pipeline amk_pipeline;
 #define AMK_PIPELINE_MAX_SLOTS 64
+#define AMK_PIPELINE_DEFAULT_DEPTH 3
+#define AMK_PIPELINE_MAX_DEPTH 64
 typedef struct amk_pipeline_config {
     int n_slots;            /* independent steps in flight                                                              */
     int n_scenes;           /* scenes per step (S of every handle)                                                      */
@@ -304,7 +306,10 @@ typedef struct amk_pipeline_config {
     int max_edge_points;    /* ... and of the edge cloud                                                                */
     double T, dt;           /* ObstacleAvoidanceMPC(T, dt, .)                                     HighLvlMpc.cpp:5-12  */
     int nearest_point_num;  /* K                                                                  mpc_parameters.yaml:5 */
-    int reserved;
+    int queue_depth;        /* steps that may be queued per slot before submit() blocks (0 = AMK_PIPELINE_DEFAULT_DEPTH).   */
+                            /* A slot's steps run in order on its stream; with depth >= 2 the next step is already queued   */
+                            /* when one ends (no host round trip between them).  Results of a step must be read -- wait(),  */
+                            /* outputs() -- before a later submit() on the same slot overwrites them, or go to d_u_out.      */
     amk_step_params step;
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {

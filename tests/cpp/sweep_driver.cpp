@@ -166,7 +166,7 @@ int main(int argc, char **argv) {
     amk_pipeline_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n_slots = n_slots; cfg.n_scenes = S; cfg.max_points = n; cfg.max_edge_points = ne;
-    cfg.T = sc[0]; cfg.dt = sc[1]; cfg.nearest_point_num = K;
+    cfg.T = sc[0]; cfg.dt = sc[1]; cfg.nearest_point_num = K; cfg.queue_depth = 0;
     cfg.step.speed = sc[2]; cfg.step.safety_distance = sc[3]; cfg.step.mpc_max_iter = max_iter;
     amk_pipeline *pl = nullptr;
     CHECK(amk_pipeline_create(&cfg, &pl));
