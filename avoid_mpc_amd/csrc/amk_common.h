@@ -94,6 +94,7 @@ struct amk_kd {
     int ex_valid = 0;   // host flag: the exact tree was built from the cloud the bucketed index currently holds
     int ex_max_nodes = 0;
     amk::DevBuf<unsigned> ex_vind, ex_left, ex_right, ex_sa, ex_sb;
+    amk::DevBuf<float> ex_pc;   // [3][S][cap] the coordinates in vAcc_ order (leaves are contiguous runs)
     amk::DevBuf<int> ex_feat, ex_child, ex_nn;
     amk::DevBuf<double> ex_low, ex_high, ex_nbbox, ex_root;
     amk::DevBuf<unsigned char> flags; // [S][cap] keyframe sweep: 1 = outlier

@@ -11,21 +11,25 @@
 //                       (AM/include/kd_tree_two.h:68)
 //   exact_knn_thread    findNeighbors -> computeInitialDistances -> searchLevel + KNNResultSet
 //                       (nanoflann_two.hpp:1563-1586, 1296-1315, 1729-1793, 179-255)
-// The build is level-synchronous, one workgroup per scene, one WAVEFRONT per tree node: the data passes of a node
-// (min/max per dimension, the two Hoare partitions of planeSplit) run 64 points at a time.  planeSplit's sequential
-// swap loop pairs the j-th misplaced element from the left with the j-th misplaced element from the right; the same
-// permutation is produced here from two order-preserving compactions (ballot + popcount) and a parallel swap, so vAcc_
-// ends up identical.  divlow / divhigh are the refined child boxes' bounds on the cut dimension = max of the left /
-// min of the right subtree's coordinates, taken when the node is split.
-// Cost: ~depth x 8 gathered passes over the cloud; milliseconds per build where the bucketed index takes a fraction
-// of one -- a mode for the reference's real frame sizes (<= 3072 points), not for the synthetic 50k-200k clouds.
+// The build is level-synchronous, one workgroup (8 wavefronts) per scene.  A node with more than kExactBigNode points is
+// processed by the WHOLE workgroup (the top ~5 levels of a 50k-point tree: one wavefront per node left 7 of 8 waves idle
+// there and the first three levels alone took most of the build), smaller nodes by one WAVEFRONT each.  The data passes of a
+// node (min/max per dimension, the two Hoare partitions of planeSplit) read the coordinates from planes kept IN vAcc_ ORDER
+// (px/py/pz are permuted together with vAcc_), so they are coalesced streams instead of gathers through the permutation.
+// planeSplit's sequential swap loop pairs the j-th misplaced element from the left with the j-th misplaced element from the
+// right; the same permutation is produced here from two order-preserving compactions (ballot + popcount, across the
+// workgroup through an LDS prefix for big nodes) and a parallel swap, so vAcc_ ends up identical.  divlow / divhigh are the
+// refined child boxes' bounds on the cut dimension = max of the left / min of the right subtree's coordinates, taken when
+// the node is split.  Round 2 (wave per node, gathers): 23 ms per 256 x 50k-point build, now 7 ms (0.4 ms at the reference's 3072 points):
+// DESIGN.md section 4.
 #pragma once
 #include "kd_grid.h"
 
 namespace amk {
 
 constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
-constexpr int kExactThreads = 256;  // 4 wavefronts per scene
+constexpr int kExactThreads = 1024; // 16 wavefronts per scene
+constexpr int kExactBigNode = 1024; // more points than this: the node is split by the whole workgroup
 constexpr int kExactMaxDepth = 48;  // traversal stack (one frame per level); deeper trees fall back to the bucketed index
 
 struct ExactTree {  // one scene
@@ -38,18 +42,24 @@ struct ExactTree {  // one scene
     double *nbbox;           // [node][6] boxes handed down by divideTree (lo0, hi0, lo1, hi1, lo2, hi2)
     double *root_bbox;       // [6] root_bbox_
     unsigned *sa, *sb;       // scratch lists of planeSplit
+    // the coordinates in vAcc_ order: pc[d * pstride + i] == coordinate d of point vind[i] (kept so by every swap of the
+    // build).  ONE base pointer and a plane stride, not three pointers: `dim == 0 ? px[i] : dim == 1 ? py[i] : pz[i]` made the
+    // compiler select the ADDRESS of the member and load the pointer from the struct, which then lived in scratch memory
+    // (160 B per lane; scratch on a queue is what tests/test_abi.py forbids outside the opt-in thread-per-query kernels).
+    float *pc;
+    size_t pstride;
     int *n_nodes;            // [1] number of nodes; -1: the tree is not available (capacity / depth exceeded)
     int max_nodes;
-    __device__ __forceinline__ double val(unsigned i, int dim) const {
-        const unsigned a = vind[i];
-        return (double)(dim == 0 ? x[a] : (dim == 1 ? y[a] : z[a]));
-    }
+    __device__ __forceinline__ float *plane(int dim) const { return pc + (size_t)dim * pstride; }
+    __device__ __forceinline__ double val(unsigned i, int dim) const { return (double)pc[(size_t)dim * pstride + i]; }
 };
 
 struct ExactPtrs {  // the batch
     const float *x, *y, *z;
     int cap;
     unsigned *vind, *left, *right, *sa, *sb;
+    float *pc;        // [3][S][cap]
+    size_t pstride;   // S * cap
     int *feat, *child, *n_nodes;
     double *low, *high, *nbbox, *root_bbox;
     int max_nodes;
@@ -58,6 +68,7 @@ struct ExactPtrs {  // the batch
         const size_t pc = (size_t)s * cap, nc = (size_t)s * max_nodes;
         t.x = x + pc; t.y = y + pc; t.z = z + pc;
         t.vind = vind + pc; t.sa = sa + pc; t.sb = sb + pc;
+        t.pc = this->pc + pc; t.pstride = pstride;
         t.feat = feat + nc; t.left = left + nc; t.right = right + nc; t.child = child + nc;
         t.low = low + nc; t.high = high + nc; t.nbbox = nbbox + nc * 6;
         t.root_bbox = root_bbox + (size_t)s * 6;
@@ -78,133 +89,226 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return v;
 }
 
-// computeMinMax over positions [lo, hi) of the node (nanoflann_two.hpp:1037-1052), by one wavefront
-__device__ __forceinline__ void node_minmax(const ExactTree &T, unsigned lo, unsigned hi, int dim, double &mn, double &mx) {
-    const int lane = threadIdx.x & 63;
+// ---- who works on a node: one wavefront, or the whole workgroup.  Both expose the same five collectives.
+struct WaveCoop {
+    static constexpr int kN = 64;
+    __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
+    __device__ __forceinline__ void sync() const { __threadfence_block(); }   // lanes of one wave: memory order only
+    // exclusive prefix of `f` over the group (in tid order) and the group's total
+    __device__ __forceinline__ unsigned scan(bool f, unsigned &total) const {
+        const unsigned long long m = __ballot(f);
+        total = __popcll(m);
+        return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    }
+    __device__ __forceinline__ unsigned sum(unsigned v) const {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    }
+    __device__ __forceinline__ double min(double v) const { return wave_min_f64(v); }
+    __device__ __forceinline__ double max(double v) const { return wave_max_f64(v); }
+    __device__ __forceinline__ int bcast(int v) const { return __shfl(v, 0); }
+};
+struct BlockCoop {  // every thread of the kExactThreads workgroup; scratch in LDS (exact_build_scene owns it)
+    static constexpr int kN = kExactThreads;
+    unsigned *wcnt;   // [kExactThreads / 64 + 1]
+    double *wred;     // [kExactThreads / 64]
+    __device__ __forceinline__ int tid() const { return threadIdx.x; }
+    __device__ __forceinline__ void sync() const { __threadfence_block(); __syncthreads(); }
+    __device__ __forceinline__ unsigned scan(bool f, unsigned &total) const {
+        const int w = threadIdx.x >> 6, nw = kExactThreads / 64;
+        const unsigned long long m = __ballot(f);
+        if ((threadIdx.x & 63) == 0) wcnt[w] = __popcll(m);
+        __syncthreads();
+        unsigned before = 0, tot = 0;
+#pragma unroll
+        for (int j = 0; j < nw; ++j) { const unsigned c = wcnt[j]; before += j < w ? c : 0u; tot += c; }
+        __syncthreads();   // wcnt is reused by the next call
+        total = tot;
+        return before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+    }
+    __device__ __forceinline__ unsigned sum(unsigned v) const {
+        unsigned t;
+        // every thread contributes its own value: reduce inside the wave first
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = v;
+        __syncthreads();
+        t = 0;
+#pragma unroll
+        for (int j = 0; j < kExactThreads / 64; ++j) t += wcnt[j];
+        __syncthreads();
+        return t;
+    }
+    template <bool MAX>
+    __device__ __forceinline__ double red(double v) const {
+        v = MAX ? wave_max_f64(v) : wave_min_f64(v);
+        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = v;
+        __syncthreads();
+        double t = wred[0];
+#pragma unroll
+        for (int j = 1; j < kExactThreads / 64; ++j) t = MAX ? fmax(t, wred[j]) : fmin(t, wred[j]);
+        __syncthreads();
+        return t;
+    }
+    __device__ __forceinline__ double min(double v) const { return red<false>(v); }
+    __device__ __forceinline__ double max(double v) const { return red<true>(v); }
+    __device__ __forceinline__ int bcast(int v) const {
+        if (threadIdx.x == 0) wcnt[kExactThreads / 64] = (unsigned)v;
+        __syncthreads();
+        const int r = (int)wcnt[kExactThreads / 64];
+        __syncthreads();
+        return r;
+    }
+};
+
+// computeMinMax over positions [lo, hi) of the node (nanoflann_two.hpp:1037-1052)
+template <class G>
+__device__ __forceinline__ void node_minmax(const G &g, const ExactTree &T, unsigned lo, unsigned hi, int dim, double &mn,
+                                            double &mx) {
     double a = DBL_MAX, b = -DBL_MAX;
-    for (unsigned i = lo + lane; i < hi; i += 64) {
+#pragma unroll 4
+    for (unsigned i = lo + g.tid(); i < hi; i += G::kN) {
         const double v = T.val(i, dim);
         a = fmin(a, v);
         b = fmax(b, v);
     }
-    mn = wave_min_f64(a);
-    mx = wave_max_f64(b);
+    mn = g.min(a);
+    mx = g.max(b);
 }
 
 // One Hoare partition of planeSplit on the node positions [lo, hi) (absolute positions in vind): elements with
 // pred = true end up in front.  STRICT selects the predicate of the first loop (val < cutval), else the second
 // (val <= cutval).  Returns the number of pred elements (lim - lo).
-template <bool STRICT>
-__device__ __forceinline__ unsigned hoare_partition(const ExactTree &T, unsigned lo, unsigned hi, int dim, double cutval) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = (1ull << lane) - 1ull;
+template <bool STRICT, class G>
+__device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree &T, unsigned lo, unsigned hi, int dim,
+                                                    double cutval) {
+    const unsigned tid = (unsigned)g.tid();
     auto pred = [&](unsigned i) {
         const double v = T.val(i, dim);
         return STRICT ? v < cutval : v <= cutval;
     };
-    unsigned cnt = 0;
-    for (unsigned base = lo; base < hi; base += 64) {
-        const unsigned i = base + lane;
-        cnt += __popcll(__ballot(i < hi && pred(i)));
-    }
+    unsigned mine = 0;
+#pragma unroll 4
+    for (unsigned i = lo + tid; i < hi; i += G::kN) mine += pred(i) ? 1u : 0u;
+    const unsigned cnt = g.sum(mine);
     const unsigned lim = lo + cnt;
     // misplaced on the left: positions in [lo, lim) with !pred, ascending  -> sa[lo + j]
     unsigned ml = 0;
-    for (unsigned base = lo; base < lim; base += 64) {
-        const unsigned i = base + lane;
+    for (unsigned base = lo; base < lim; base += G::kN) {
+        const unsigned i = base + tid;
         const bool f = i < lim && !pred(i);
-        const unsigned long long m = __ballot(f);
-        if (f) T.sa[lo + ml + __popcll(m & lt)] = i;
-        ml += __popcll(m);
+        unsigned tot;
+        const unsigned at = g.scan(f, tot);
+        if (f) T.sa[lo + ml + at] = i;
+        ml += tot;
     }
     // misplaced on the right: positions in [lim, hi) with pred, DESCENDING  -> sb[lo + j]
     unsigned mr = 0;
-    for (unsigned top = hi; top > lim; top = top > lim + 64 ? top - 64 : lim) {
-        const bool in = top >= lim + 1 + (unsigned)lane;  // position top - 1 - lane >= lim
-        const unsigned i = top - 1 - lane;
+    for (unsigned top = hi; top > lim; top = top > lim + G::kN ? top - G::kN : lim) {
+        const bool in = top >= lim + 1 + tid;  // position top - 1 - tid >= lim
+        const unsigned i = top - 1 - tid;
         const bool f = in && pred(i);
-        const unsigned long long m = __ballot(f);
-        if (f) T.sb[lo + mr + __popcll(m & lt)] = i;
-        mr += __popcll(m);
+        unsigned tot;
+        const unsigned at = g.scan(f, tot);
+        if (f) T.sb[lo + mr + at] = i;
+        mr += tot;
     }
-    __threadfence_block();  // the lists were written by other lanes
-    for (unsigned j = lane; j < ml; j += 64) {  // ml == mr: the j-th from the left swaps with the j-th from the right
+    g.sync();  // the lists were written by other threads of the group
+    for (unsigned j = tid; j < ml; j += G::kN) {  // ml == mr: the j-th from the left swaps with the j-th from the right
         const unsigned a = T.sa[lo + j], b = T.sb[lo + j];
         const unsigned ta = T.vind[a], tb = T.vind[b];
-        T.vind[a] = tb;
-        T.vind[b] = ta;
+        T.vind[a] = tb; T.vind[b] = ta;
+        float *p0 = T.plane(0), *p1 = T.plane(1), *p2 = T.plane(2);
+        const float xa = p0[a], xb = p0[b], ya = p1[a], yb = p1[b], za = p2[a], zb = p2[b];
+        p0[a] = xb; p0[b] = xa; p1[a] = yb; p1[b] = ya; p2[a] = zb; p2[b] = za;
     }
-    __threadfence_block();
+    g.sync();
     return cnt;
 }
 
-// divideTree for node `id` (one wavefront): a leaf is marked, an inner node is split and its two children are appended
-__device__ __forceinline__ void exact_process_node(const ExactTree &T, int id, int *n_nodes_lds, int *overflow) {
-    const int lane = threadIdx.x & 63;
+// divideTree for node `id` (by the group g): a leaf is marked, an inner node is split and its two children are appended
+template <class G>
+__device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &T, int id, int *n_nodes_lds, int *overflow) {
+    const int tid = g.tid();
     const unsigned l = T.left[id], r = T.right[id], count = r - l;
     if (count <= (unsigned)kExactLeaf) {
-        if (lane == 0) T.feat[id] = -1;
+        if (tid == 0) T.feat[id] = -1;
         return;
     }
-    double bb[3][2];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) { bb[d][0] = T.nbbox[(size_t)id * 6 + 2 * d]; bb[d][1] = T.nbbox[(size_t)id * 6 + 2 * d + 1]; }
+    // the node's box in six scalars: a private array indexed by the cut dimension would live in scratch (or be promoted
+    // to 48 B of LDS per thread)
+    const double b0l = T.nbbox[(size_t)id * 6 + 0], b0h = T.nbbox[(size_t)id * 6 + 1], b1l = T.nbbox[(size_t)id * 6 + 2],
+                 b1h = T.nbbox[(size_t)id * 6 + 3], b2l = T.nbbox[(size_t)id * 6 + 4], b2h = T.nbbox[(size_t)id * 6 + 5];
+#define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
+#define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
     // middleSplit_ (:1197-1245)
     const double EPS = 0.00001;
-    double max_span = bb[0][1] - bb[0][0];
+    double max_span = b0h - b0l;
+#pragma unroll
     for (int d = 1; d < 3; ++d) {
-        const double span = bb[d][1] - bb[d][0];
+        const double span = bhi(d) - blo(d);
         if (span > max_span) max_span = span;
     }
     double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
     int cutfeat = 0;
+#pragma unroll
     for (int d = 0; d < 3; ++d) {
-        const double span = bb[d][1] - bb[d][0];
+        const double span = bhi(d) - blo(d);
         if (span > (1 - EPS) * max_span) {
             double mn, mx;
-            node_minmax(T, l, r, d, mn, mx);
+            node_minmax(g, T, l, r, d, mn, mx);
             const double spread = mx - mn;
             if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
         }
     }
-    const double split_val = (bb[cutfeat][0] + bb[cutfeat][1]) / 2;
+    const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
     const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
     // planeSplit (:1256-1294)
-    const unsigned lim1 = hoare_partition<true>(T, l, r, cutfeat, cutval);
-    const unsigned lim2 = lim1 + hoare_partition<false>(T, l + lim1, r, cutfeat, cutval);
+    const unsigned lim1 = hoare_partition<true>(g, T, l, r, cutfeat, cutval);
+    const unsigned lim2 = lim1 + hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval);
     const unsigned half = count / 2;
     const unsigned idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
     // refined boxes of the children on the cut dimension (:1086,1096-1102)
     double dlo, dhi, t0, t1;
-    node_minmax(T, l, l + idx, cutfeat, t0, dlo);      // divlow  = left child's high
-    node_minmax(T, l + idx, r, cutfeat, dhi, t1);      // divhigh = right child's low
+    node_minmax(g, T, l, l + idx, cutfeat, t0, dlo);      // divlow  = left child's high
+    node_minmax(g, T, l + idx, r, cutfeat, dhi, t1);      // divhigh = right child's low
     int c = 0;
-    if (lane == 0) {
+    if (tid == 0) {
         c = atomicAdd(n_nodes_lds, 2);
         if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
     }
-    c = __shfl(c, 0);
+    c = g.bcast(c);
     if (c < 0) return;
-    if (lane == 0) {
+    if (tid == 0) {
         T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
         T.left[c] = l; T.right[c] = l + idx; T.left[c + 1] = l + idx; T.right[c + 1] = r;
     }
-    if (lane < 6) {
-        const int d = lane >> 1, hi = lane & 1;
-        double vl = bb[d][hi], vr = bb[d][hi];
+    if (tid < 6) {
+        const int d = tid >> 1, hi = tid & 1;
+        double vl = hi ? bhi(d) : blo(d), vr = vl;
         if (d == cutfeat && hi == 1) vl = cutval;  // left_bbox[cutfeat].high = cutval
         if (d == cutfeat && hi == 0) vr = cutval;  // right_bbox[cutfeat].low = cutval
-        T.nbbox[(size_t)c * 6 + lane] = vl;
-        T.nbbox[(size_t)(c + 1) * 6 + lane] = vr;
+        T.nbbox[(size_t)c * 6 + tid] = vl;
+        T.nbbox[(size_t)(c + 1) * 6 + tid] = vr;
     }
+#undef blo
+#undef bhi
 }
 
 // buildIndex for scene s; called by every thread of a kExactThreads block.  n = cloud.pts.size().
-__device__ __forceinline__ void exact_build_scene(const ExactTree &T, int n) {
+__device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = kExactThreads / 64;
     __shared__ int n_nodes_lds, overflow, head, tail;
     __shared__ double red[kExactThreads / 64][6];
-    for (int i = tid; i < n; i += kExactThreads) T.vind[i] = i;  // init_vind
+    __shared__ unsigned coop_cnt[kExactThreads / 64 + 1];
+    __shared__ double coop_red[kExactThreads / 64];
+    const BlockCoop gb{coop_cnt, coop_red};
+    const WaveCoop gw{};
+    for (int i = tid; i < n; i += kExactThreads) {  // init_vind + the coordinate planes in the same (identity) order
+        T.vind[i] = i;
+        T.plane(0)[i] = T.x[i]; T.plane(1)[i] = T.y[i]; T.plane(2)[i] = T.z[i];
+    }
     // computeBoundingBox (:1694-1720)
     double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
     for (int i = tid; i < n; i += kExactThreads) {
@@ -229,7 +333,16 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree &T, int n) {
     __syncthreads();
     while (head < tail) {  // one level of divideTree per round
         const int h = head, t = tail;
-        for (int id = h + w; id < t; id += nw) exact_process_node(T, id, &n_nodes_lds, &overflow);
+        // big nodes first, one after the other, by the whole workgroup (they only exist in the top levels: a level wider
+        // than 64 nodes is not searched for them -- a big node down there, on pathological data, is split by a wave)
+        const bool look = t - h <= 64;
+        if (look)
+            for (int id = h; id < t; ++id)
+                if (T.right[id] - T.left[id] > (unsigned)kExactBigNode) exact_process_node(gb, T, id, &n_nodes_lds, &overflow);
+        __threadfence_block();
+        __syncthreads();
+        for (int id = h + w; id < t; id += nw)
+            if (!look || T.right[id] - T.left[id] <= (unsigned)kExactBigNode) exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
         __threadfence_block();
         __syncthreads();
         if (tid == 0) { head = t; tail = overflow ? t : n_nodes_lds; }
@@ -330,6 +443,98 @@ __device__ __forceinline__ int exact_knn_thread(const ExactTree &T, double qx, d
     return count;
 }
 
+// findNeighbors for one query by ONE WAVEFRONT (every lane holds the same query): the same traversal, node data read once
+// per wave (uniform addresses), the <= 10 points of a leaf scored by lanes 0..9 from the vAcc_-ordered planes (one
+// contiguous run) and then offered to the result set ONE AT A TIME in leaf order, exactly as the sequential loop does
+// (:1733-1751) -- the order decides which of several equidistant points is kept.  The KNNResultSet lives in lanes
+// 0..k-1 (rd, ri sorted ascending); KNNResultSet::addPoint (:219-246) = count the entries <= dist (they form a prefix),
+// shift the rest up by one lane.  `st`: this wave's stack in LDS.  Returns the number of results, -1 = tree unavailable.
+struct ExactWaveStack {
+    int node[kExactMaxDepth], ik[kExactMaxDepth];
+    double a[kExactMaxDepth], b[kExactMaxDepth];
+};
+__device__ __forceinline__ int exact_knn_wave(const ExactTree &T, double qx, double qy, double qz, int k, double &rd, int &ri,
+                                              ExactWaveStack *st) {
+    const int lane = threadIdx.x & 63;
+    const int nn = *T.n_nodes;
+    rd = DBL_MAX;   // KNNResultSet::init (:196-202): dists[capacity - 1] = max; the other slots are never read before written
+    ri = -1;
+    if (nn <= 0) return nn < 0 ? -1 : 0;
+    int count = 0;
+    double dists[3] = {0.0, 0.0, 0.0};
+    double mind = 0.0;
+    const double q[3] = {qx, qy, qz};
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {  // computeInitialDistances (:1296-1315)
+        const double blo = T.root_bbox[2 * d], bhi = T.root_bbox[2 * d + 1];
+        if (q[d] < blo) { dists[d] = (q[d] - blo) * (q[d] - blo); mind += dists[d]; }
+        if (q[d] > bhi) { dists[d] = (q[d] - bhi) * (q[d] - bhi); mind += dists[d]; }
+    }
+    auto set_dist = [&](int idx, double v) {
+        dists[0] = idx == 0 ? v : dists[0];
+        dists[1] = idx == 1 ? v : dists[1];
+        dists[2] = idx == 2 ? v : dists[2];
+    };
+    int sp = 0, node = 0;
+    for (;;) {
+        for (int idx = T.feat[node]; idx >= 0; idx = T.feat[node]) {
+            const double val = idx == 0 ? qx : (idx == 1 ? qy : qz);
+            const double diff1 = val - T.low[node], diff2 = val - T.high[node];
+            int best, other;
+            double cut;
+            if ((diff1 + diff2) < 0) { best = T.child[node]; other = best + 1; cut = diff2 * diff2; }
+            else { other = T.child[node]; best = other + 1; cut = diff1 * diff1; }
+            if (sp >= kExactMaxDepth) return -1;
+            if (lane == 0) { st->node[sp] = other; st->ik[sp] = idx; st->a[sp] = cut; st->b[sp] = mind; }
+            ++sp;
+            node = best;
+        }
+        {   // leaf: worst distance cached at entry
+            const double worst = readlane_f64(rd, k - 1);
+            const unsigned lf = T.left[node], rt = T.right[node], cnt = rt - lf;
+            double dist = DBL_MAX;
+            int pidx = -1;
+            if ((unsigned)lane < cnt) {
+                const unsigned i = lf + lane;
+                pidx = (int)T.vind[i];
+                dist = sq_dist(qx, qy, qz, T.plane(0)[i], T.plane(1)[i], T.plane(2)[i]);
+            }
+            for (unsigned e = 0; e < cnt; ++e) {
+                const double de = readlane_f64(dist, (int)e);
+                if (!(de < worst)) continue;                       // (NaN never enters, as in the reference)
+                const int ae = __builtin_amdgcn_readlane(pidx, (int)e);
+                const int pos = __popcll(__ballot(lane < count && rd <= de));   // after the existing equals
+                const double up = __shfl_up(rd, 1);
+                const int upi = __shfl_up(ri, 1);
+                if (lane > pos && lane < k) { rd = up; ri = upi; }
+                if (lane == pos && pos < k) { rd = de; ri = ae; }
+                if (count < k) ++count;
+            }
+        }
+        __threadfence_block();   // lane 0's stack writes are read by the whole wave
+        bool go = false;
+        while (sp > 0) {
+            --sp;
+            const int ik = st->ik[sp], idx = ik & 3;
+            if (ik >> 2) { set_dist(idx, st->a[sp]); continue; }
+            const double cut = st->a[sp], dst = idx == 0 ? dists[0] : (idx == 1 ? dists[1] : dists[2]);
+            const double m2 = st->b[sp] + cut - dst;
+            if (m2 * 1.0f <= readlane_f64(rd, k - 1)) {
+                set_dist(idx, cut);
+                node = st->node[sp];
+                __threadfence_block();
+                if (lane == 0) { st->ik[sp] = idx | 4; st->a[sp] = dst; }
+                ++sp;
+                mind = m2;
+                go = true;
+                break;
+            }
+        }
+        if (!go) break;
+    }
+    return count;
+}
+
 }  // namespace amk
 
 // host side: the batch pointers of a handle whose reference-shaped tree exists (amk_common.h: amk_kd)
@@ -337,6 +542,7 @@ inline amk::ExactPtrs amk_exact_ptrs(amk_kd *kd) {
     amk::ExactPtrs ep;
     ep.x = kd->x.p; ep.y = kd->y.p; ep.z = kd->z.p; ep.cap = kd->cap;
     ep.vind = kd->ex_vind.p; ep.left = kd->ex_left.p; ep.right = kd->ex_right.p; ep.sa = kd->ex_sa.p; ep.sb = kd->ex_sb.p;
+    ep.pc = kd->ex_pc.p; ep.pstride = (size_t)kd->n_scenes * kd->cap;
     ep.feat = kd->ex_feat.p; ep.child = kd->ex_child.p; ep.n_nodes = kd->ex_nn.p;
     ep.low = kd->ex_low.p; ep.high = kd->ex_high.p; ep.nbbox = kd->ex_nbbox.p; ep.root_bbox = kd->ex_root.p;
     ep.max_nodes = kd->ex_max_nodes;

@@ -338,31 +338,33 @@ __global__ __launch_bounds__(amk::kExactThreads) void kd_exact_build_kernel(amk:
     amk::exact_build_scene(ep.scene(s), sizes[s]);
 }
 
-// one THREAD per (scene, query): nanoflann's own traversal.  Overwrites the outputs of the bucketed search (launched
-// before it on the same stream) wherever the tree is available; a scene whose tree is not (node capacity or traversal
-// depth exceeded on pathological data) keeps the bucketed index's answer.
-__global__ __launch_bounds__(64) void kd_exact_search_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes, int n_scenes,
-                                                             const double *__restrict__ queries, int n_queries, int k,
-                                                             int *__restrict__ out_idx, double *__restrict__ out_d2,
-                                                             float *__restrict__ out_pts, int *__restrict__ out_cnt) {
-    const size_t row = (size_t)blockIdx.x * 64 + threadIdx.x;
+// one WAVEFRONT per (scene, query): nanoflann's own traversal (kd_exact.h: exact_knn_wave).  Overwrites the outputs of the
+// bucketed search (launched before it on the same stream) wherever the tree is available; a scene whose tree is not (node
+// capacity or traversal depth exceeded on pathological data) keeps the bucketed index's answer.
+__global__ __launch_bounds__(256) void kd_exact_search_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes, int n_scenes,
+                                                              const double *__restrict__ queries, int n_queries, int k,
+                                                              int *__restrict__ out_idx, double *__restrict__ out_d2,
+                                                              float *__restrict__ out_pts, int *__restrict__ out_cnt) {
+    __shared__ amk::ExactWaveStack stacks[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + w;
     if (row >= (size_t)n_scenes * n_queries) return;
     const int s = (int)(row / n_queries);
     const amk::ExactTree T = ep.scene(s);
     const double *qp = queries + row * 3;
-    double rd[AMK_MAX_K];
-    int ri[AMK_MAX_K];
     const int size = sizes[s];
-    amk::ExactStackStorage stack;
-    const int got = amk::exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
+    double rd;
+    int ri;
+    const int got = amk::exact_knn_wave(T, qp[0], qp[1], qp[2], k, rd, ri, &stacks[w]);
     if (got < 0) return;
     const int cnt = size < k ? size : (size > k ? k : 0);  // kd_tree_two.h:119-124
-    if (out_cnt) out_cnt[row] = cnt;
-    for (int j = 0; j < k; ++j) {
+    if (out_cnt && lane == 0) out_cnt[row] = cnt;
+    if (lane < k) {
+        const int j = lane;
         const bool ok = j < cnt && j < got;
-        const int idx = ok ? ri[j] : -1;
+        const int idx = ok ? ri : -1;
         if (out_idx) out_idx[row * k + j] = idx;
-        if (out_d2) out_d2[row * k + j] = ok ? rd[j] : DBL_MAX;
+        if (out_d2) out_d2[row * k + j] = ok ? rd : DBL_MAX;
         if (out_pts) {
             float *o = out_pts + (row * k + j) * 3;
             o[0] = ok ? T.x[idx] : 0.f;
@@ -381,6 +383,7 @@ static int exact_build(amk_kd *kd, hipStream_t stream) {
         kd->ex_max_nodes = kd->cap / 2 + 64;  // ~0.29 nodes per point with 10-point leaves; more = pathological data
         const size_t pc = S * (size_t)kd->cap, nc = S * (size_t)kd->ex_max_nodes;
         AMK_HIP(kd->ex_vind.alloc(pc)); AMK_HIP(kd->ex_sa.alloc(pc)); AMK_HIP(kd->ex_sb.alloc(pc));
+        AMK_HIP(kd->ex_pc.alloc(3 * pc));
         AMK_HIP(kd->ex_left.alloc(nc)); AMK_HIP(kd->ex_right.alloc(nc)); AMK_HIP(kd->ex_feat.alloc(nc));
         AMK_HIP(kd->ex_child.alloc(nc)); AMK_HIP(kd->ex_low.alloc(nc)); AMK_HIP(kd->ex_high.alloc(nc));
         AMK_HIP(kd->ex_nbbox.alloc(nc * 6)); AMK_HIP(kd->ex_root.alloc(S * 6)); AMK_HIP(kd->ex_nn.alloc(S));
@@ -730,7 +733,7 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
         AMK_HIP(hipGetLastError());
         if (kd->tie_order && kd->ex_valid) {  // nanoflann's own traversal where its tree is available (and current)
             const size_t rows = (size_t)kd->n_scenes * n_queries;
-            hipLaunchKernelGGL(kd_exact_search_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, (hipStream_t)stream,
+            hipLaunchKernelGGL(kd_exact_search_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
                                exact_ptrs(kd), kd->size.p, kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts,
                                d_counts);
             AMK_HIP(hipGetLastError());

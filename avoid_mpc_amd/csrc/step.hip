@@ -122,14 +122,16 @@ __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridP
 }
 
 // Handles in AMK_TIES_NANOFLANN mode: the same raw results by nanoflann's own traversal of its own tree (kd_exact.h), one
-// THREAD per (scene, query), overwriting what step_knn_grid_kernel wrote wherever the tree is available.  With exact ties
+// WAVEFRONT per (scene, query), overwriting what step_knn_grid_kernel wrote wherever the tree is available.  With exact ties
 // (quantised edge clouds) this is what keeps the snapped edge point and the neighbour SET equal to the reference's.
-__global__ __launch_bounds__(64) void step_knn_exact_kernel(ExactPtrs eobs, ExactPtrs eedge, int use_obs, int use_edge,
-                                                            int n_scenes, const double *__restrict__ ref_path, int N, int K,
-                                                            float *__restrict__ knn_pts, double *__restrict__ knn_d2,
-                                                            float *__restrict__ edge_pt, double *__restrict__ edge_d2,
-                                                            const int *__restrict__ done) {
-    const int t = blockIdx.x * 64 + threadIdx.x;
+__global__ __launch_bounds__(256) void step_knn_exact_kernel(ExactPtrs eobs, ExactPtrs eedge, int use_obs, int use_edge,
+                                                             int n_scenes, const double *__restrict__ ref_path, int N, int K,
+                                                             float *__restrict__ knn_pts, double *__restrict__ knn_d2,
+                                                             float *__restrict__ edge_pt, double *__restrict__ edge_d2,
+                                                             const int *__restrict__ done) {
+    __shared__ ExactWaveStack stacks[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w;
     const int nq = N + 1;
     if (t >= n_scenes * nq) return;
     const int s = t / nq, q = t - s * nq;
@@ -139,20 +141,20 @@ __global__ __launch_bounds__(64) void step_knn_exact_kernel(ExactPtrs eobs, Exac
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const ExactTree T = is_edge ? eedge.scene(s) : eobs.scene(s);
     const int k = is_edge ? 1 : K;
-    double rd[AMK_MAX_K];
-    int ri[AMK_MAX_K];
-    ExactStackStorage stack;
-    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
+    double rd;
+    int ri;
+    const int got = exact_knn_wave(T, qp[0], qp[1], qp[2], k, rd, ri, &stacks[w]);
     if (got < 0) return;
-    for (int j = 0; j < k; ++j) {
+    if (lane < k) {
+        const int j = lane;
         const bool ok = j < got;
-        const float px = ok ? T.x[ri[j]] : 0.f, py = ok ? T.y[ri[j]] : 0.f, pz = ok ? T.z[ri[j]] : 0.f;
+        const float px = ok ? T.x[ri] : 0.f, py = ok ? T.y[ri] : 0.f, pz = ok ? T.z[ri] : 0.f;
         if (is_edge) {
-            edge_d2[s] = ok ? rd[j] : DBL_MAX;
+            edge_d2[s] = ok ? rd : DBL_MAX;
             edge_pt[3 * s + 0] = px; edge_pt[3 * s + 1] = py; edge_pt[3 * s + 2] = pz;
         } else {
             const size_t row = (size_t)s * N + q;
-            knn_d2[row * K + j] = ok ? rd[j] : DBL_MAX;
+            knn_d2[row * K + j] = ok ? rd : DBL_MAX;
             float *o = knn_pts + (row * K + j) * 3;
             o[0] = px; o[1] = py; o[2] = pz;
         }
@@ -361,7 +363,7 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                                d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
                                mpc->done.p);
             if (ex_obs || ex_edge)
-                hipLaunchKernelGGL(step_knn_exact_kernel, dim3((S * (N + 1) + 63) / 64), dim3(64), 0, stream, eobs, eedge, ex_obs,
+                hipLaunchKernelGGL(step_knn_exact_kernel, dim3((S * (N + 1) + 3) / 4), dim3(256), 0, stream, eobs, eedge, ex_obs,
                                    ex_edge, S, d_ref_path, N, K, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p,
                                    mpc->edge_d2.p, mpc->done.p);
         } else {

@@ -84,11 +84,13 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
 }
 
 // one THREAD per (frame, scene, query): the same raw results by the reference's traversal, where the frame has its tree
-__global__ __launch_bounds__(64) void step_knn_frames_exact_kernel(const FrameExact *__restrict__ fe, int n_scenes,
-                                                                   const double *__restrict__ ref_path, int N, int K,
-                                                                   FrameBufs fb, const int *__restrict__ done) {
+__global__ __launch_bounds__(256) void step_knn_frames_exact_kernel(const FrameExact *__restrict__ fe, int n_scenes,
+                                                                    const double *__restrict__ ref_path, int N, int K,
+                                                                    FrameBufs fb, const int *__restrict__ done) {
+    __shared__ ExactWaveStack stacks[4];
     const int f = blockIdx.y;
-    const int t = blockIdx.x * 64 + threadIdx.x;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int t = blockIdx.x * 4 + w;
     const int nq = N + 1;
     if (t >= n_scenes * nq) return;
     const int s = t / nq, q = t - s * nq;
@@ -98,21 +100,21 @@ __global__ __launch_bounds__(64) void step_knn_frames_exact_kernel(const FrameEx
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const ExactTree T = is_edge ? fe->edge[f].scene(s) : fe->obs[f].scene(s);
     const int k = is_edge ? 1 : K;
-    double rd[AMK_MAX_K];
-    int ri[AMK_MAX_K];
-    ExactStackStorage stack;
-    const int got = exact_knn_thread(T, qp[0], qp[1], qp[2], k, rd, ri, stack.view());
+    double rd;
+    int ri;
+    const int got = exact_knn_wave(T, qp[0], qp[1], qp[2], k, rd, ri, &stacks[w]);
     if (got < 0) return;
-    for (int j = 0; j < k; ++j) {
+    if (lane < k) {
+        const int j = lane;
         const bool ok = j < got;
-        const float px = ok ? T.x[ri[j]] : 0.f, py = ok ? T.y[ri[j]] : 0.f, pz = ok ? T.z[ri[j]] : 0.f;
+        const float px = ok ? T.x[ri] : 0.f, py = ok ? T.y[ri] : 0.f, pz = ok ? T.z[ri] : 0.f;
         if (is_edge) {
             const size_t o = (size_t)f * n_scenes + s;
-            fb.edge_d2[o] = ok ? rd[j] : DBL_MAX;
+            fb.edge_d2[o] = ok ? rd : DBL_MAX;
             fb.edge_pt[3 * o + 0] = px; fb.edge_pt[3 * o + 1] = py; fb.edge_pt[3 * o + 2] = pz;
         } else {
             const size_t row = ((size_t)f * n_scenes + s) * N + q;
-            fb.knn_d2[row * K + j] = ok ? rd[j] : DBL_MAX;
+            fb.knn_d2[row * K + j] = ok ? rd : DBL_MAX;
             float *o = fb.knn_pts + (row * K + j) * 3;
             o[0] = px; o[1] = py; o[2] = pz;
         }
@@ -383,7 +385,7 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path, N, K,
                            fb, mpc->done.p);
         if (any_exact)
-            hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 63) / 64, F), dim3(64), 0, stream, fe_dev, S,
+            hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 3) / 4, F), dim3(256), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);
         hipLaunchKernelGGL(any_exact ? step_merge_plan_pack_kernel<true> : step_merge_plan_pack_kernel<false>, dim3(S),
                            dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,

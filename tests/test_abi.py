@@ -73,19 +73,15 @@ def test_product_never_touches_the_oracle():
 
 def test_default_path_kernels_use_no_scratch_memory(lib):
     """A kernel that may touch scratch makes every hardware queue reserve it; with the bench's 20 streams / 32 queues a
-    scratch-using kernel on the default path exhausted the runtime's resources (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  Only
-    the thread-per-query kernels of the opt-in nanoflann tie-order mode may use scratch (their traversal stack); the solve
+    scratch-using kernel on the default path exhausted the runtime's resources (HSA_STATUS_ERROR_OUT_OF_RESOURCES).  No
+    kernel of the library uses scratch (the traversal stacks of the nanoflann tie-order mode live in LDS); the solve
     must also stay within 256 VGPRs (2 waves per SIMD).  Read from the compiler's own resource report, written next to
     the library by the build."""
     import json
     table = json.load(open(amk_build.RES))
     assert len(table) >= 30
-    allowed = ("kd_exact_search_kernel", "step_knn_exact_kernel", "step_knn_frames_exact_kernel")
-    for name, r in table.items():
-        if not any(a in name for a in allowed):
-            assert r["scratch_bytes_per_lane"] == 0, (name, r)
-        else:
-            assert r["scratch_bytes_per_lane"] <= 2048, (name, r)
+    for name, r in table.items():   # (round 2's thread-per-query traversal kernels kept their stack in scratch; they are wave-per-query now)
+        assert r["scratch_bytes_per_lane"] == 0, (name, r)
     solve = [r for n, r in table.items() if "mpc_solve_kernel" in n]
     assert solve and all(r["vgprs"] <= 256 for r in solve)
     # a 512-thread index-build block is two waves per SIMD: it must fit beside ONE fp64 solve wave of the bench's horizon
