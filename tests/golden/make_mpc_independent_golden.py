@@ -10,6 +10,10 @@ with the exact nlp_jac_g / nlp_hess_l of oracle/mpc_oracle_np.py (VERDICT r2 ite
         3 = the next step needed IPOPT's restoration phase, which is not emulated)
   tc.u / .f / .status / .nit / .viol           [64]   scipy.optimize.minimize(method="trust-constr") -- a trust-region
         interior-point method, nothing in common with this project's solver -- to gtol 1e-8
+  ipopt10w.u / .f / .status / .iters           [64]   (run with --warm) the 10-iteration emulation started AT the fixture's
+        converged point w* of the same problem: the reference's operating regime is a warm start from the previous solution
+        (mNlpW0 = sol, HighLvlMpc.cpp:129), with mu_init still 0.1 -- how far does the truncated solve end from the optimum
+        it was started at
 Data only (no source text).  Run:  python tests/golden/make_mpc_independent_golden.py   (about 40 minutes on 8 cores)
 """
 import os
@@ -55,9 +59,28 @@ def one(job):
                 utc=tc.x[10:14], ftc=tc.fun, sttc=tc.status, nittc=tc.nit, violtc=tc.constr_violation)
 
 
+def one_warm(job):
+    cfg, s = job
+    import ipopt_emul as IE
+    nlp = problem(cfg, s)
+    r = IE.solve(nlp, G[cfg + ".wstar"][s], max_iter=10)
+    return dict(u=r["x"][10:14], f=r["f"], st=r["status"], it=r["iters"])
+
+
 def main():
     path = os.path.join(ROOT, "tests", "golden", "mpc_independent_golden.npz")
-    for cfg in sys.argv[1:] or ["C1", "C2", "C5"]:   # saved after every size
+    if "--warm" in sys.argv:
+        out = dict(np.load(path))
+        for cfg in ("C1", "C2", "C5"):
+            with ProcessPoolExecutor(int(os.environ.get("NPROC", "8"))) as ex:
+                res = list(ex.map(one_warm, [(cfg, s) for s in range(64)], chunksize=1))
+            out.update({cfg + ".ipopt10w.u": np.array([r["u"] for r in res]), cfg + ".ipopt10w.f": np.array([r["f"] for r in res]),
+                        cfg + ".ipopt10w.status": np.array([r["st"] for r in res]), cfg + ".ipopt10w.iters": np.array([r["it"] for r in res])})
+            d = np.abs(out[cfg + ".ipopt10w.u"] - G[cfg + ".wstar"][:, 10:14]).max(1)
+            print(cfg, "warm-started ipopt10: |du| median %.3g p90 %.3g max %.3g" % (np.median(d), np.quantile(d, .9), d.max()), flush=True)
+        np.savez_compressed(path, **out)
+        return
+    for cfg in [a for a in sys.argv[1:] if not a.startswith("-")] or ["C1", "C2", "C5"]:   # saved after every size
         jobs = [(cfg, s) for s in range(64)]
         with ProcessPoolExecutor(int(os.environ.get("NPROC", "8"))) as ex:
             res = list(ex.map(one, jobs, chunksize=1))
