@@ -350,20 +350,21 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
         AMK_HIP(mpc->done.alloc(S));
     }
-    if (mpc->mf_frames < F) {
-        AMK_HIP(mpc->mf_knn_pts.alloc((size_t)F * S * N * K * 3));
-        AMK_HIP(mpc->mf_knn_d2.alloc((size_t)F * S * N * K));
-        AMK_HIP(mpc->mf_edge_pt.alloc((size_t)F * S * 3));
-        AMK_HIP(mpc->mf_edge_d2.alloc((size_t)F * S));
-        mpc->mf_frames = F;
+    if (mpc->mf_frames < F) {   // sized ONCE for the largest map (AMK_MAX_FRAMES): a map that gains a keyframe between two calls
+        const size_t FM = AMK_MAX_FRAMES;   // must not free a buffer an earlier call's kernels may still be reading
+        AMK_HIP(mpc->mf_knn_pts.alloc(FM * S * N * K * 3));
+        AMK_HIP(mpc->mf_knn_d2.alloc(FM * S * N * K));
+        AMK_HIP(mpc->mf_edge_pt.alloc(FM * S * 3));
+        AMK_HIP(mpc->mf_edge_d2.alloc(FM * S));
+        mpc->mf_frames = AMK_MAX_FRAMES;
     }
     const FrameBufs fb{mpc->mf_knn_pts.p, mpc->mf_knn_d2.p, mpc->mf_edge_pt.p, mpc->mf_edge_d2.p};
     // frames in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build / amk_kd_push_keyframe)
     bool any_exact = false;
     FrameExact *fe_dev = nullptr;
     {
-        mpc->mf_exact_host.assign(sizeof(FrameExact), 0);
-        FrameExact *h = reinterpret_cast<FrameExact *>(mpc->mf_exact_host.data());
+        std::vector<char> cur(sizeof(FrameExact), 0);
+        FrameExact *h = reinterpret_cast<FrameExact *>(cur.data());
         for (int f = 0; f < F; ++f) {
             h->use_obs[f] = obstacle[f]->tie_order && obstacle[f]->ex_valid;
             h->use_edge[f] = edge[f]->tie_order && edge[f]->ex_valid;
@@ -372,8 +373,17 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
             any_exact |= h->use_obs[f] || h->use_edge[f];
         }
         if (any_exact) {
+            // The table lives in device memory (too large for the kernel-argument segment).  It is uploaded only when the
+            // frame list or a frame's mode changed -- a host event (AddVertex / keyframe push) -- and then synchronously after
+            // a device-wide wait: earlier calls on other streams may still be reading the old table.  The steady state issues
+            // no copy at all, so a step over an unchanged exact-mode map is graph-capturable like the other step paths; the
+            // call that follows a change of the map is not.
             if (!mpc->mf_exact.p) AMK_HIP(mpc->mf_exact.alloc(sizeof(FrameExact)));
-            AMK_HIP(hipMemcpyAsync(mpc->mf_exact.p, h, sizeof(FrameExact), hipMemcpyHostToDevice, stream));
+            if (mpc->mf_exact_host != cur) {
+                AMK_HIP(hipDeviceSynchronize());
+                AMK_HIP(hipMemcpy(mpc->mf_exact.p, h, sizeof(FrameExact), hipMemcpyHostToDevice));
+                mpc->mf_exact_host = cur;
+            }
             fe_dev = reinterpret_cast<FrameExact *>(mpc->mf_exact.p);
         }
     }

@@ -20,7 +20,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_LDS_IDX_ACTIVE SQ_LD
 find $OUT -name "*.csv" -o -name "*.db" | head -40
 tail -3 $OUT/bench.err
 # 5. the collective path on one GPU: bench.py under torch.distributed.run with one rank (one ncclAllGather per sweep, amk_shard_gather)
-python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 256 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_torchrun_1rank.json 2>> $OUT/bench.err
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-parity > $OUT/bench_torchrun_1rank.json 2>> $OUT/bench.err
 # 6. other BASELINE sizes and launch shapes (not the headline)
 python bench.py --points 200000 --T 1.0 --steps 64 --warmup 4 --streams 8 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_c5size.json 2>> $OUT/bench.err
 python bench.py --points 5000 --T 0.33 --K 3 --steps 512 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_c1size.json 2>> $OUT/bench.err
@@ -28,5 +28,8 @@ python bench.py --steps 64 --warmup 4 --scenes 1 --streams 1 --no-cpu-baseline -
 python bench.py --steps 32 --warmup 4 --scenes 2048 --streams 1 --no-cpu-baseline --no-parity --steady-steps 0 > $OUT/bench_s2048_streams1.json 2>> $OUT/bench.err
 python bench.py --ipm-max-iter 40 --no-cpu-baseline --no-parity > $OUT/bench_cap40.json 2>> $OUT/bench.err
 python tools/experiments/ms_parts.py > $OUT/ms_parts.txt 2>> $OUT/bench.err
+python tools/experiments/exact_mode_cost.py > $OUT/exact_mode_cost.txt 2>> $OUT/bench.err
+for c in a b; do for qd in 1 8; do QD=$qd python tools/experiments/rccl_presence.py $c 2>/dev/null | grep "^case . *: [0-9]" | sed "s/^/QD=$qd /" >> $OUT/rccl_presence.txt; done; done
+cat $OUT/exact_mode_cost.txt $OUT/rccl_presence.txt
 cat $OUT/ms_parts.txt
 ls $OUT
