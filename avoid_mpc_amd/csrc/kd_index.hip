@@ -223,7 +223,7 @@ __global__ __launch_bounds__(512) void kd_scan_kernel(
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */;
     const int g = (j % bps) * wpb + w;
     if (s >= n_scenes || g >= groups) return;
     const int lane = threadIdx.x & 63;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void kd_grid_search_kernel(amk::GridPtrs gpt, 
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= n_queries) return;
     const size_t row = (size_t)s * n_queries + q;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void kd_tie_flags_kernel(amk::GridPtrs gpt, co
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= n_queries) return;
     const size_t row = (size_t)s * n_queries + q;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void kd_exact_search_kernel(amk::ExactPtrs ep,
                                                               int *__restrict__ out_idx, double *__restrict__ out_d2,
                                                               float *__restrict__ out_pts, int *__restrict__ out_cnt) {
     __shared__ amk::ExactWaveStack stacks[4];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const size_t row = (size_t)blockIdx.x * 4 + w;
     if (row >= (size_t)n_scenes * n_queries) return;
     const int s = (int)(row / n_queries);

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict_
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;  // all blocks of a scene share one XCD's L2; its waves one CU's L1
-    const int w = threadIdx.x >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */;
     const int g = (j % bps) * wpb + w;
     if (s >= n_scenes || g >= groups || done[s]) return;
     const int lane = threadIdx.x & 63;
@@ -81,6 +81,9 @@ __global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict_
 // Same outputs through the bucketed indices (kd_grid.h), both trees in one launch: wavefront q < N answers
 // the K-NN of reference point q in the obstacle index, wavefront q == N the 1-NN of reference point 0 in
 // the edge index (the Edge-KD-tree query of PlanWapionts, :270).
+// <= 64 VGPRs (tests/test_abi.py): a CU that holds its 8 solve waves (2 x 224 registers per SIMD, 158.6 of 160 KB of LDS) still
+// has 64 registers per SIMD and 5 KB of LDS free -- exactly one block of this kernel (one wave per SIMD, 4.1 KB), which then runs
+// in the issue slots the latency-bound solves leave empty instead of waiting for a CU to drain.
 __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridPtrs gedge, int n_scenes,
                                                             const double *__restrict__ ref_path, int N, int K,
                                                             float *__restrict__ knn_pts, double *__restrict__ knn_d2,
@@ -92,7 +95,9 @@ __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridP
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // wave-uniform by construction; telling the compiler so moves the scene pointers, the grid geometry and the query into
+    // SGPRs (scalar loads) -- 14 VGPRs less, which is what lets the kernel fit in 64
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= nq || done[s]) return;
     const bool is_edge = q == N;
@@ -130,7 +135,7 @@ __global__ __launch_bounds__(256) void step_knn_exact_kernel(ExactPtrs eobs, Exa
                                                              float *__restrict__ edge_pt, double *__restrict__ edge_d2,
                                                              const int *__restrict__ done) {
     __shared__ ExactWaveStack stacks[4];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + w;
     const int nq = N + 1;
     if (t >= n_scenes * nq) return;

@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= nq || done[s]) return;
     const bool is_edge = q == N;
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void step_knn_frames_exact_kernel(const FrameE
                                                                     FrameBufs fb, const int *__restrict__ done) {
     __shared__ ExactWaveStack stacks[4];
     const int f = blockIdx.y;
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
     const int t = blockIdx.x * 4 + w;
     const int nq = N + 1;
     if (t >= n_scenes * nq) return;
