@@ -11,6 +11,8 @@
 //                          ProcessWaypoints padding/needReplan, early exit, GetRefStates      (:216-257,333-335)
 //   mpc_solve_kernel       Solve + refill of the reference path                                (:337-342)
 // The multi-frame map (keyframes, PtIsInFrame fast path, per-frame merge) is step_frames.hip.
+#include <type_traits>
+
 #include "kd_exact.h"
 #include "mpc_handle.h"
 
@@ -167,8 +169,8 @@ __global__ __launch_bounds__(256) void step_knn_exact_kernel(ExactPtrs eobs, Exa
 }
 
 // PlanWapionts (:259-281) for reference point 0; called by the one wavefront that owns scene s.
-template <bool EXACT>
-__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, ExactPtrs eobs,
+template <bool EXACT, bool GRID>
+__device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, ExactPtrs eobs,
                                                           const float *__restrict__ X, const float *__restrict__ Y,
                                                           const float *__restrict__ Z, int cap,
                                                           const int *__restrict__ sizes_obs,
@@ -196,25 +198,31 @@ __device__ __forceinline__ void plan_scene(int s, GridPtrs gpt, int use_grid, Ex
             const double ex = (double)edge_pt[3 * s + 0], ey = (double)edge_pt[3 * s + 1], ez = (double)edge_pt[3 * s + 2];
             // the snapped point is what ProcessWaypoints queries next (:210-215): redo query 0
             const float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
-            __shared__ ScanLds<1> ws1;
-            __shared__ GridWaveLds wl1;
+            // GRID is a template parameter: the streaming-scan cross-check path (amk__kd_set_mode) brought its registers and
+            // LDS into the default kernel (93 VGPRs; 58 without it -- few enough to run beside the solves' waves)
+            __shared__ typename std::conditional<GRID, int, ScanLds<1>>::type ws1_store;
+            __shared__ typename std::conditional<GRID, GridWaveLds, int>::type wl1_store;
             __shared__ double q1[3];
             double gld = DBL_MAX;
             int gli = kNoIndex, glpos = 0;
             const GridScene gs = gpt.scene(s);
-            if (use_grid) {
-                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl1);
+            int sli = kNoIndex;
+            double sld = DBL_MAX;
+            if constexpr (GRID) {
+                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl1_store);
             } else {
+                ScanLds<1> &ws1 = ws1_store;
                 q1[0] = ex; q1[1] = ey; q1[2] = ez;  // every lane stores the same values
                 scan_cloud<1>(xs, ys, zs, size_o, pmax_obs[s], q1, 3, K, &ws1);
+                if (lane < K) { sli = ws1.li[0][lane]; sld = ws1.ld[0][lane]; }
             }
             if (lane < K) {
-                const int li = use_grid ? gli : ws1.li[0][lane];
+                const int li = GRID ? gli : sli;
                 const bool ok = li != kNoIndex;
-                knn_d2[(size_t)s * N * K + lane] = ok ? (use_grid ? gld : ws1.ld[0][lane]) : DBL_MAX;
+                knn_d2[(size_t)s * N * K + lane] = ok ? (GRID ? gld : sld) : DBL_MAX;
                 float *o = knn_pts + ((size_t)s * N * K + lane) * 3;
                 float nx = 0.f, ny = 0.f, nz = 0.f;
-                if (use_grid) {
+                if (GRID) {
                     const float4 rec = gs.pt[glpos];
                     nx = rec.x; ny = rec.y; nz = rec.z;
                 } else if (ok) {
@@ -300,9 +308,9 @@ __device__ __forceinline__ void pack_scene(int s, const int *__restrict__ sizes_
 // EXACT (obstacle handle in AMK_TIES_NANOFLANN mode) is a template parameter, not a flag: the traversal's stack lives in
 // scratch memory, and a kernel that MAY use scratch makes every hardware queue reserve it (with 32 queues in flight the
 // default path ran out of resources when the two shared one kernel).
-template <bool EXACT>
+template <bool EXACT, bool GRID>
 __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
-    GridPtrs gpt, int use_grid, ExactPtrs eobs, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
+    GridPtrs gpt, ExactPtrs eobs, const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z,
     int cap, const int *__restrict__ sizes_obs, const float *__restrict__ pmax_obs, const int *__restrict__ sizes_edge,
     int N, int K, int nref, int iter, int max_iter, double speed, double T, double safety_distance,
     const double *__restrict__ state_quad, const double *__restrict__ pos_x, double *__restrict__ ref_path,
@@ -311,7 +319,7 @@ __global__ __launch_bounds__(kWave) void step_plan_pack_kernel(
     int *__restrict__ flags) {
     const int s = blockIdx.x;
     if (done[s]) return;
-    plan_scene<EXACT>(s, gpt, use_grid, eobs, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
+    plan_scene<EXACT, GRID>(s, gpt, eobs, X, Y, Z, cap, sizes_obs, pmax_obs, sizes_edge, N, K, safety_distance, ref_path, knn_pts,
                knn_d2, edge_pt, edge_d2, flags);
     __threadfence_block();
     __syncthreads();
@@ -382,8 +390,10 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
                            mpc->edge_pt.p, mpc->edge_d2.p, mpc->done.p); }
         }
         if (!(g_diag_skip & 2)) { TimedLaunch tl(KC_PLAN, stream);
-        hipLaunchKernelGGL(ex_obs ? step_plan_pack_kernel<true> : step_plan_pack_kernel<false>, dim3(S), dim3(kWave), 0, stream,
-                           gobs, use_grid, eobs, obstacle->x.p,
+        auto plan_kernel = step_plan_pack_kernel<false, true>;
+        if (!use_grid) plan_kernel = step_plan_pack_kernel<false, false>;
+        else if (ex_obs) plan_kernel = step_plan_pack_kernel<true, true>;
+        hipLaunchKernelGGL(plan_kernel, dim3(S), dim3(kWave), 0, stream, gobs, eobs, obstacle->x.p,
                            obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
                            K, mpc->nref, iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
                            d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
