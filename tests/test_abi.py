@@ -53,6 +53,12 @@ def test_no_cpu_fallback(lib):
     assert not h.value
     assert lib.amk_mpc_create(0.66, 0.033, 8, 1, C.byref(h)) == 3
     assert not h.value
+    cfg = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, capi.StepParams(10.0, 0.2, 3, 0))
+    assert lib.amk_pipeline_create(C.byref(cfg), C.byref(h)) == 3 and not h.value
+    assert lib.amk_shard_create(b"\0" * 128, 0, 1, C.byref(h)) == 3 and not h.value
+    first, count = C.c_int(), C.c_int()   # the partition itself is host arithmetic
+    assert lib.amk_shard_scene_range(1, 3, 8, C.byref(first), C.byref(count)) == 0 and (first.value, count.value) == (3, 3)
+    assert lib.amk_shard_scene_range(2, 3, 8, C.byref(first), C.byref(count)) == 0 and (first.value, count.value) == (6, 2)
 
 
 def test_product_never_touches_the_oracle():

@@ -1,0 +1,92 @@
+"""GPU: amk_pipeline_* (several control steps in flight behind the C ABI): every submitted frame returns what the same frame
+returns through the separate calls (amk_kd_build x 2 + amk_step_batch) -- at queue depth 1 (one step per slot) and 3 (steps
+queued behind a running one on the same slot), with results read from the slot's buffers and from caller-supplied rows
+(d_u_out), warm start kept or reset; wait / query / drain; argument errors."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from avoid_mpc_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(torch, prm, n_frames, S, n):
+    from avoid_mpc_amd import fsm
+    out = []
+    for f in range(n_frames):
+        scenes = [synth.make_scene(n, 5000 + 17 * f + s, prm) for s in range(S)]
+        sq = np.stack([fsm.state_quads(sc["pos"], sc["vel"], sc["acc"], sc["yaw"], prm.decay, prm.max_iter) for sc in scenes])
+        out.append(dict(cl=torch.from_numpy(np.stack([sc["cloud"] for sc in scenes])).cuda(),
+                        ed=torch.from_numpy(np.stack([sc["edge"] for sc in scenes])).cuda(),
+                        sq=torch.from_numpy(sq).cuda(), px=torch.from_numpy(np.array([sc["pos"][0] for sc in scenes])).cuda(),
+                        ref=torch.from_numpy(np.stack([sc["ref_path"] for sc in scenes])).cuda()))
+    return out
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_pipeline_equals_the_separate_calls(depth):
+    import torch
+    from avoid_mpc_amd.host import KdBatch, MpcBatch, Pipeline, step_batch
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne, n_slots, n_frames = 6, 5000, 500, 2, 7
+    frames = _frames(torch, prm, n_frames, S, n)
+    # reference: the separate calls, fresh warm start per frame
+    want = []
+    kd_o, kd_e = KdBatch(S, n), KdBatch(S, ne)
+    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
+    for fr in frames:
+        kd_o.build(fr["cl"]); kd_e.build(fr["ed"]); mpc.reset_warm_start()
+        ref = fr["ref"].clone()
+        o = step_batch(kd_o, kd_e, mpc, prm, fr["sq"], fr["px"], ref)
+        torch.cuda.synchronize()
+        want.append(dict(u=o["u"].cpu().numpy().copy(), flags=o["flags"].cpu().numpy().copy(), x0=o["x0array"].cpu().numpy().copy(),
+                         ref=ref.cpu().numpy().copy()))
+    pl = Pipeline(n_slots, S, n, ne, prm, queue_depth=depth)
+    assert pl.lib.amk_pipeline_slots(pl.h) == n_slots
+    rows = torch.zeros((n_frames, S, 4), dtype=torch.float64, device="cuda")
+    slots = [pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"], u_out=rows[i]) for i, fr in enumerate(frames)]
+    assert slots == [i % n_slots for i in range(n_frames)]          # round robin
+    pl.drain()
+    assert all(pl.lib.amk_pipeline_query(pl.h, i) == 1 for i in range(n_slots))
+    got = rows.cpu().numpy()
+    for i in range(n_frames):
+        assert np.array_equal(got[i], want[i]["u"]), i               # same kernels, same inputs: identical bits
+    # the slots' own buffers hold the LAST frame each slot ran
+    for sl in range(n_slots):
+        last = max(i for i in range(n_frames) if i % n_slots == sl)
+        o = pl.outputs(sl)
+        assert np.array_equal(o["flags"], want[last]["flags"]) and np.array_equal(o["x0array"], want[last]["x0"])
+        assert np.array_equal(o["ref_path"], want[last]["ref"])
+    # without d_u_out the control lands in the slot's buffer; wait() on one slot
+    sl = pl.submit(frames[0]["cl"], frames[0]["ed"], frames[0]["sq"], frames[0]["px"], frames[0]["ref"])
+    pl.wait(sl)
+    assert np.array_equal(pl.outputs(sl)["u"], want[0]["u"])
+    # keep_warm_start: the second solve of the same frame starts from the first one's solution -> fewer iterations
+    sl = pl.submit(frames[0]["cl"], frames[0]["ed"], frames[0]["sq"], frames[0]["px"], frames[0]["ref"])
+    pl.wait(sl); cold = pl.outputs(sl)["flags"][:, 3].sum()
+    for _ in range(n_slots):   # the same slot again
+        sl2 = pl.submit(frames[0]["cl"], frames[0]["ed"], frames[0]["sq"], frames[0]["px"], frames[0]["ref"], keep_warm_start=True)
+    pl.wait(sl2)
+    assert sl2 == sl and pl.outputs(sl2)["flags"][:, 3].sum() < cold
+    pl.close()
+
+
+def test_pipeline_argument_errors():
+    import torch  # noqa: F401  (one HIP runtime per process)
+    lib = capi.load()
+    h = C.c_void_p()
+    sp = capi.StepParams(10.0, 0.2, 3, 0)
+    bad = capi.PipelineConfig(0, 4, 100, 10, 0.33, 0.033, 3, 0, sp)
+    assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
+    bad = capi.PipelineConfig(2, 4, 100, 10, 5.0, 0.033, 3, 0, sp)                       # N = 151 > AMK_MAX_HORIZON
+    assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED and not h.value
+    ok = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, sp)
+    assert lib.amk_pipeline_create(C.byref(ok), C.byref(h)) == 0
+    fr = capi.PipelineFrame()                                                            # all NULL
+    assert lib.amk_pipeline_submit(h, C.byref(fr), None) == capi.AMK_ERR_INVALID_ARG
+    assert lib.amk_pipeline_wait(h, 5) == capi.AMK_ERR_INVALID_ARG and lib.amk_pipeline_query(h, -1) == -1
+    assert lib.amk_pipeline_mpc(h, 2) is None and lib.amk_pipeline_kd(h, 0, 2) is None
+    assert lib.amk_pipeline_query(h, 0) == 1 and lib.amk_pipeline_drain(h) == 0           # idle slots count as finished
+    assert lib.amk_pipeline_destroy(h) == 0
