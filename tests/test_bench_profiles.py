@@ -1,0 +1,48 @@
+"""CPU: the committed bench line (profiles/r03_bench.json) carries the contract's fields, and every roofline fraction in it
+follows from the committed rocprofv3 summaries of the same commands (profiles/r03_kernel_stats_streams1.json, r03_pmc_*.json)
+within 10 % -- VERDICT r2 item 2 ("my recomputation from profiles/r03_* lands within 10 % of every frac")."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
+
+
+def test_bench_line_has_the_contract_fields_and_consistent_rooflines():
+    line = P("r03_bench.json")["default_run"]
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
+    assert "workload" in line["config"] and line["config"]["scenes_per_gpu"] == 256 and line["config"]["points"] == 50000
+    assert abs(line["value"] - 256 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-3
+    kt1 = P("r03_kernel_stats_streams1.json")["kernels"]
+    issue = P("r03_pmc_solve_issue.json")
+    traffic = P("r03_pmc_traffic.json")["kernels"]
+    within = lambda a, b, tol=0.10: abs(a - b) <= tol * abs(b)
+    # dominant kernel, HBM view: algorithmic bytes / rocprof's single-stream duration / 8 TB/s
+    h = line["roofline_hbm"]
+    assert within(h["avg_launch_us"], kt1["mpc_solve_kernel<20>"]["avg_us"])
+    assert within(h["frac"], h["alg_bytes_per_launch"] / (kt1["mpc_solve_kernel<20>"]["avg_us"] * 1e-6) / 8e12)
+    assert within(h["traffic"], traffic["mpc_solve_kernel<20>"]["hbm_bytes_per_launch_x2"], 0.02)
+    # dominant kernel, the bound the counters name: VALU issue slots
+    r = line["roofline"]
+    valu = issue["valu_instructions_per_wave_solve"]
+    solves_per_s = line["value"] * line["config"]["solves_per_step"]
+    assert within(r["frac"], solves_per_s * valu * 4 / (256 * 4 * 2.4e9), 0.02)
+    assert within(r["frac_at_saturation_solves_only"], issue["valu_issue_util_at_saturation"], 0.02)
+    assert r["frac"] < r["frac_at_saturation_solves_only"] < 1.0
+    # the HBM-bound kernel: one launch builds both trees of 256 frames
+    b = line["roofline_kd_build"]
+    assert b["alg_bytes_per_launch"] == 28 * 256 * 55000
+    assert within(b["avg_launch_us"], kt1["kd_build_kernel"]["avg_us"], 0.12)   # the event bracket holds ~8 us of dispatch
+    assert within(b["frac"], b["alg_bytes_per_launch"] / (kt1["kd_build_kernel"]["avg_us"] * 1e-6) / 8e12, 0.12)
+    assert within(b["traffic"], traffic["kd_build_kernel"]["hbm_bytes_per_launch_x2"], 0.02)
+    w = line["roofline_whole_step"]
+    assert within(w["frac"], line["value"] * 670544 / 8e12, 1e-3)
+    # parity and baseline blocks
+    fx = line["parity"]["fixtures"]
+    assert fx["ok"] and all(fx[c]["converged"] == 64 and fx[c]["du_max"] <= 1e-3 for c in ("C1", "C2", "C5"))
+    assert line["parity"]["timed_workload_vs_cpu_oracle"]["ok"]
+    cb = line["cpu_baseline"]
+    assert cb["cores"] >= 1 and cb["value"] > 0 and cb["kind"] == "port" and "sample" in cb
