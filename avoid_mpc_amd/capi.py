@@ -36,7 +36,7 @@ SYMBOLS = [
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
     "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_mpc_np", "amk_mpc_eval_gamma",
     "amk_mpc_eval_gamma_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
-    "amk_pipeline_create", "amk_pipeline_destroy", "amk_pipeline_slots", "amk_pipeline_mpc", "amk_pipeline_kd",
+    "amk_pipeline_create", "amk_pipeline_destroy", "amk_pipeline_slots", "amk_pipeline_gang", "amk_pipeline_mpc", "amk_pipeline_kd",
     "amk_pipeline_stream", "amk_pipeline_submit", "amk_pipeline_wait", "amk_pipeline_query", "amk_pipeline_drain",
     "amk_pipeline_outputs",
     "amk_shard_scene_range", "amk_shard_unique_id", "amk_shard_create", "amk_shard_destroy", "amk_shard_rank",
@@ -59,7 +59,7 @@ class PipelineConfig(C.Structure):
     """amk_pipeline_config"""
     _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
                 ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("queue_depth", C.c_int),
-                ("step", StepParams)]
+                ("gang", C.c_int), ("step", StepParams)]
 
 
 class PipelineFrame(C.Structure):
@@ -157,6 +157,7 @@ def load():
         "amk_pipeline_create": (i, [C.POINTER(PipelineConfig), C.POINTER(vp)]),
         "amk_pipeline_destroy": (i, [vp]),
         "amk_pipeline_slots": (i, [vp]),
+        "amk_pipeline_gang": (i, [vp]),
         "amk_pipeline_mpc": (vp, [vp, i]),
         "amk_pipeline_kd": (vp, [vp, i, i]),
         "amk_pipeline_stream": (vp, [vp, i]),

@@ -70,6 +70,14 @@ struct TimedLaunch {  // RAII: records an event before and after the enclosed la
 
 }  // namespace amk
 
+struct amk_kd;
+namespace amk {
+// kd_index.hip: the frames of a pipeline gang built by one launch (see there)
+int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes, const float *const *d_xyz,
+                  const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
+                  hipStream_t stream);
+}  // namespace amk
+
 // ------------------------------------------------------------------------------------------------
 // handle layouts (shared between kd_index.hip, mpc_solve.hip and step.hip)
 // ------------------------------------------------------------------------------------------------

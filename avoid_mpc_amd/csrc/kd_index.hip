@@ -64,6 +64,23 @@ extern "C" int amk__timing_collect(double *ms, int *counts) {
     return AMK_OK;
 }
 
+// Like amk__timing_collect, but keeps every launch: class, start and end in milliseconds after the first recorded launch
+// (tools/experiments/burst_timeline.py: who runs when, without a tracer slowing the host down).  Returns the number of launches.
+extern "C" int amk__timing_timeline(int max_recs, int *kclass, double *start_ms, double *end_ms) {
+    amk::Timing &t = amk::timing();
+    int n = 0;
+    for (auto &r : t.recs) {
+        float fa = 0.f, fb = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&fa, t.recs[0].a, r.a) != hipSuccess ||
+            hipEventElapsedTime(&fb, t.recs[0].a, r.b) != hipSuccess)
+            return AMK_ERR_HIP;
+        if (n < max_recs) { kclass[n] = r.kclass; start_ms[n] = fa; end_ms[n] = fb; ++n; }
+    }
+    for (auto &r : t.recs) { t.pool.push_back(r.a); t.pool.push_back(r.b); }
+    t.recs.clear();
+    return n;
+}
+
 using amk::kWave;
 
 // ------------------------------------------------------------------------------------------------
@@ -158,15 +175,20 @@ __device__ __forceinline__ void build_one_tree(const float *__restrict__ xyz, in
     const amk::RawSrc rs{src, point_stride, grp, size_out + s, pmax_out + s};
     amk::grid_build_scene(s, rs, cap, n, n, bbox_out, GP, cell_start, gparams);
 }
-struct BuildArgs2 { BuildArgs t[2]; };
+constexpr int kBuildMaxEntries = 2 * AMK_PIPELINE_MAX_GANG;   // (tree, frame) pairs of one launch
+struct BuildArgs2 { BuildArgs t[kBuildMaxEntries]; };
 __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildArgs2 args) {
     const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
     build_one_tree(a.xyz, a.point_stride, a.scene_stride, a.counts, a.max_points, a.cap, a.grp_all, a.grp_stride, a.size_out,
                    a.pmax_out, a.bbox_out, a.GP, a.cell_start, a.gparams);
 }
-static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride, const int *d_counts) {
-    return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p, kd->cap / kWave + 2,
-                     kd->size.p, kd->pmax.p, kd->bbox.p, kd->gpt.p, kd->cell_start.p, kd->gparams.p};
+// so: first scene of the handle this entry writes (a gang launch builds frame f into scenes [f * S, (f + 1) * S) of the handle)
+static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride, const int *d_counts,
+                            size_t so = 0) {
+    const int gs = kd->cap / kWave + 2;
+    return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p + so * gs, gs,
+                     kd->size.p + so, kd->pmax.p + so, kd->bbox.p + so * 6, kd->gpt.p + so * kd->cap,
+                     kd->cell_start.p + so * (amk::kGridMaxCells + 2), kd->gparams.p + so * amk::kGridParamDoubles};
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
@@ -664,7 +686,9 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
         const BuildArgs a = build_args(kd, d_xyz, point_stride, scene_stride, d_counts);
-        hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes, 1), dim3(kCompactThreads), 0, (hipStream_t)stream, BuildArgs2{{a, a}});
+        BuildArgs2 args{};
+        args.t[0] = a;
+        hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes, 1), dim3(kCompactThreads), 0, (hipStream_t)stream, args);
         kd->soa_valid = 0;
         kd->ex_valid = 0;   // the exact tree (if any) describes the previous cloud until exact_build has run
         kd->async_pending = 1;
@@ -683,7 +707,9 @@ int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts,
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
         const BuildArgs a = build_args(obstacle, d_xyz, point_stride, (long long)obstacle->max_points * point_stride, d_counts);
         const BuildArgs b = build_args(edge, d_edge_xyz, point_stride, (long long)edge->max_points * point_stride, d_edge_counts);
-        hipLaunchKernelGGL(kd_build_kernel, dim3(obstacle->n_scenes, 2), dim3(kCompactThreads), 0, (hipStream_t)stream, BuildArgs2{{a, b}});
+        BuildArgs2 args{};
+        args.t[0] = a; args.t[1] = b;
+        hipLaunchKernelGGL(kd_build_kernel, dim3(obstacle->n_scenes, 2), dim3(kCompactThreads), 0, (hipStream_t)stream, args);
         for (amk_kd *kd : {obstacle, edge}) {
             kd->soa_valid = 0;
             kd->ex_valid = 0;
@@ -698,6 +724,42 @@ int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts,
         }
     return AMK_OK;
 }
+
+// Internal (csrc/pipeline.hip, gang > 1): the frames of a gang in ONE launch -- frame f's two clouds are built into scenes
+// [f * frame_scenes, (f + 1) * frame_scenes) of the two handles (which hold n_frames * frame_scenes scenes); grid.y = (tree, frame).
+}  // extern "C"
+namespace amk {
+int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes, const float *const *d_xyz,
+                  const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
+                  hipStream_t stream) {
+    if (!obstacle || !edge || n_frames < 1 || n_frames > AMK_PIPELINE_MAX_GANG || point_stride < 3 ||
+        obstacle->n_scenes != n_frames * frame_scenes || edge->n_scenes != obstacle->n_scenes)
+        return AMK_ERR_INVALID_ARG;
+    {
+        amk::TimedLaunch tg(amk::KC_GRID, stream);
+        BuildArgs2 args{};
+        for (int f = 0; f < n_frames; ++f) {
+            const size_t so = (size_t)f * frame_scenes;
+            args.t[2 * f] = build_args(obstacle, d_xyz[f], point_stride, (long long)obstacle->max_points * point_stride, d_counts[f], so);
+            args.t[2 * f + 1] = build_args(edge, d_edge_xyz[f], point_stride, (long long)edge->max_points * point_stride, d_edge_counts[f], so);
+        }
+        hipLaunchKernelGGL(kd_build_kernel, dim3(frame_scenes, 2 * n_frames), dim3(kCompactThreads), 0, stream, args);
+        for (amk_kd *kd : {obstacle, edge}) {
+            kd->soa_valid = 0;
+            kd->ex_valid = 0;
+            kd->async_pending = 1;
+        }
+    }
+    AMK_HIP(hipGetLastError());
+    for (amk_kd *kd : {obstacle, edge})
+        if (kd->tie_order) {
+            const int st = exact_build(kd, stream);
+            if (st != AMK_OK) return st;
+        }
+    return AMK_OK;
+}
+}  // namespace amk
+extern "C" {
 
 // internal (tests): number of nodes of every scene's reference-shaped tree (-1: not available), after synchronising
 int amk__kd_exact_nodes(amk_kd *kd, int *h_nodes) {

@@ -2,12 +2,19 @@
 //
 // A control step of this library (index builds of a fresh depth frame + amk_step_batch) is a chain of dependent launches
 // whose dominant kernel is latency-bound: one stream fills ~1/8 of the chip.  Consecutive frames of
-// a fleet of robots (or the batches of a sweep) are independent, so the throughput configuration keeps n_slots steps in
+// a fleet of robots (or the batches of a sweep) are independent, so the throughput configuration keeps n_slots launches in
 // flight, each on its own HIP stream with its own handles -- until round 2 that orchestration lived only in bench.py.
-// A slot = {stream, obstacle index, edge index, MPC batch (warm start, workspace), reference-path buffer, outputs, event}.
+// A slot = {stream, obstacle index, edge index, MPC batch (warm start, workspace), input / output buffers, events}.
 // The reference has one robot and one step in flight (AM/src/mpc_obstacle_avoidance_node.cpp:8,
 // AvoidanceStateMachine.cpp:322-355); this is the batched counterpart of its per-frame sequence
 // FrameKDMap::AddVertex (FrameKDMap.cpp:34-52) -> AvoidanceStateMachine::Step.
+//
+// Gang (amk_pipeline_config.gang = G > 1): G consecutively submitted frames share ONE set of launches -- the slot's handles
+// hold G x n_scenes scenes, frame g occupies scenes [g S, (g + 1) S).  More than ~28 streams collapse on this runtime (32
+// hardware queues), so a gang is how MORE scenes are kept in flight than 20-odd slots of one frame hold: on the bench
+// workload (256-scene frames) 16 slots x 2 frames reach 505 k scene-steps/s in the steady state against 460 k for 20 x 1
+// (DESIGN.md section 7).  A frame is only STAGED by submit() until its gang is full; wait() / drain() launch a partly
+// filled gang.
 #include "mpc_handle.h"
 
 #include <cstdlib>
@@ -16,24 +23,33 @@
 
 struct amk_pipeline {
     amk_pipeline_config cfg;
+    struct Staged {  // a frame of the open gang
+        const float *cloud, *edge;
+        const int *cloud_counts, *edge_counts;
+        const double *state_quad, *pos_x;   // read directly when gang == 1, copied at submit otherwise
+        double *u_out;
+        int keep_warm_start;
+    };
     struct Slot {
         hipStream_t stream = nullptr;
-        std::vector<hipEvent_t> done;   // ring of queue_depth events: done[k % depth] marks the end of the slot's k-th step
-        long long count = 0;            // steps submitted on this slot
-        long long waited = 0;           // steps known to have finished
+        std::vector<hipEvent_t> done;   // ring of queue_depth events: done[k % depth] marks the end of the slot's k-th launch
+        long long count = 0;            // gang launches issued on this slot
+        long long waited = 0;           // launches known to have finished
         amk_kd *obstacle = nullptr, *edge = nullptr;
         amk_mpc *mpc = nullptr;
-        amk::DevBuf<double> ref_path, u, x0array;
+        amk::DevBuf<double> ref_path, u, x0array, state_quad, pos_x;   // [G S][...]: the gang's contiguous inputs / outputs
         amk::DevBuf<int> flags;
+        std::vector<Staged> open;       // frames staged since the last launch (< gang)
+        int point_stride = 3;
     };
-    int depth = 1;
+    int depth = 1, gang = 1;
     std::vector<Slot> slots;
     int next = 0;
     long long submitted = 0;
 };
 
 namespace {
-// Waits for a slot's step.  hipEventSynchronize parks the thread on an HSA signal; with AMK_PIPELINE_SPIN=1 the thread polls
+// Waits for a slot's launch.  hipEventSynchronize parks the thread on an HSA signal; with AMK_PIPELINE_SPIN=1 the thread polls
 // hipEventQuery instead (diagnostics: tools/experiments/rccl_presence.py).
 int wait_event(hipEvent_t ev) {
     static const bool spin = [] { const char *e = std::getenv("AMK_PIPELINE_SPIN"); return e && e[0] == '1'; }();
@@ -47,13 +63,59 @@ int wait_event(hipEvent_t ev) {
         if (e != hipErrorNotReady) return amk::hip_fail(e);
     }
 }
+
+// Launches the slot's open gang: both index builds of every staged frame in one launch, one control step over all of them.
+// A gang that is not full (wait / drain before the G-th submit) runs its missing frames as copies of the last staged one:
+// their scenes are computed and ignored (a one-off at the end of a sweep; the handles' kernels always cover G S scenes).
+int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
+    if (s.open.empty()) return AMK_OK;
+    const amk_pipeline_config &c = p->cfg;
+    const int G = p->gang, S = c.n_scenes, N = amk_mpc_horizon(s.mpc), mi = c.step.mpc_max_iter;
+    const int filled = (int)s.open.size();
+    hipStream_t st = s.stream;
+    for (int g = filled; g < G; ++g) {   // pad
+        AMK_HIP(hipMemcpyAsync(s.state_quad.p + (size_t)g * S * mi * 10, s.state_quad.p + (size_t)(filled - 1) * S * mi * 10,
+                               sizeof(double) * S * mi * 10, hipMemcpyDeviceToDevice, st));
+        AMK_HIP(hipMemcpyAsync(s.pos_x.p + (size_t)g * S, s.pos_x.p + (size_t)(filled - 1) * S, sizeof(double) * S,
+                               hipMemcpyDeviceToDevice, st));
+        AMK_HIP(hipMemcpyAsync(s.ref_path.p + (size_t)g * S * N * 10, s.ref_path.p + (size_t)(filled - 1) * S * N * 10,
+                               sizeof(double) * S * N * 10, hipMemcpyDeviceToDevice, st));
+    }
+    const float *cl[AMK_PIPELINE_MAX_GANG], *ed[AMK_PIPELINE_MAX_GANG];
+    const int *cc[AMK_PIPELINE_MAX_GANG], *ec[AMK_PIPELINE_MAX_GANG];
+    for (int g = 0; g < G; ++g) {
+        const amk_pipeline::Staged &f = s.open[g < filled ? g : filled - 1];
+        cl[g] = f.cloud; ed[g] = f.edge; cc[g] = f.cloud_counts; ec[g] = f.edge_counts;
+        // fresh frame: zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
+        if (!f.keep_warm_start)
+            AMK_HIP(hipMemsetAsync(s.mpc->w0.p + (size_t)g * S * s.mpc->nx, 0, sizeof(double) * (size_t)S * s.mpc->nx, st));
+    }
+    int rc;
+    // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
+    if (G == 1) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
+    else rc = amk::kd_build_gang(s.obstacle, s.edge, G, S, cl, cc, ed, ec, s.point_stride, st);
+    if (rc != AMK_OK) return rc;
+    double *u = (G == 1 && s.open[0].u_out) ? s.open[0].u_out : s.u.p;
+    const double *sq = G == 1 ? s.open[0].state_quad : s.state_quad.p, *px = G == 1 ? s.open[0].pos_x : s.pos_x.p;
+    if ((rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st)) != AMK_OK)
+        return rc;
+    if (G > 1)
+        for (int g = 0; g < filled; ++g)
+            if (s.open[g].u_out)
+                AMK_HIP(hipMemcpyAsync(s.open[g].u_out, s.u.p + (size_t)g * S * 4, sizeof(double) * S * 4, hipMemcpyDeviceToDevice, st));
+    AMK_HIP(hipEventRecord(s.done[s.count % p->depth], st));
+    ++s.count;
+    s.open.clear();
+    return AMK_OK;
+}
 }  // namespace
 
 extern "C" {
 
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
     if (!cfg || !out || cfg->n_slots <= 0 || cfg->n_slots > AMK_PIPELINE_MAX_SLOTS || cfg->n_scenes <= 0 ||
-        cfg->max_points <= 0 || cfg->max_edge_points <= 0)
+        cfg->max_points <= 0 || cfg->max_edge_points <= 0 || cfg->gang < 0 || cfg->gang > AMK_PIPELINE_MAX_GANG ||
+        cfg->step.mpc_max_iter < 1 || cfg->step.mpc_max_iter > AMK_MAX_OUTER_ITER)
         return AMK_ERR_INVALID_ARG;
     *out = nullptr;
     if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
@@ -61,7 +123,9 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
     p->cfg = *cfg;
     p->depth = cfg->queue_depth > 0 ? cfg->queue_depth : AMK_PIPELINE_DEFAULT_DEPTH;
     if (p->depth > AMK_PIPELINE_MAX_DEPTH) p->depth = AMK_PIPELINE_MAX_DEPTH;
+    p->gang = cfg->gang > 0 ? cfg->gang : 1;
     p->slots.resize(cfg->n_slots);
+    const int GS = p->gang * cfg->n_scenes;
     int st = AMK_OK;
     for (auto &s : p->slots) {
         hipError_t e;
@@ -76,12 +140,16 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
             st = amk::hip_fail(e);
             break;
         }
-        if ((st = amk_kd_create(cfg->n_scenes, cfg->max_points, &s.obstacle)) != AMK_OK) break;
-        if ((st = amk_kd_create(cfg->n_scenes, cfg->max_edge_points, &s.edge)) != AMK_OK) break;
-        if ((st = amk_mpc_create(cfg->T, cfg->dt, cfg->nearest_point_num, cfg->n_scenes, &s.mpc)) != AMK_OK) break;
-        const size_t S = cfg->n_scenes, N = amk_mpc_horizon(s.mpc);
+        if ((st = amk_kd_create(GS, cfg->max_points, &s.obstacle)) != AMK_OK) break;
+        if ((st = amk_kd_create(GS, cfg->max_edge_points, &s.edge)) != AMK_OK) break;
+        if ((st = amk_mpc_create(cfg->T, cfg->dt, cfg->nearest_point_num, GS, &s.mpc)) != AMK_OK) break;
+        const size_t S = GS, N = amk_mpc_horizon(s.mpc);
         if ((e = s.ref_path.alloc(S * N * 10)) != hipSuccess || (e = s.u.alloc(S * 4)) != hipSuccess ||
             (e = s.x0array.alloc(S * N * 14)) != hipSuccess || (e = s.flags.alloc(S * 4)) != hipSuccess) {
+            st = amk::hip_fail(e);
+            break;
+        }
+        if (p->gang > 1 && ((e = s.state_quad.alloc(S * cfg->step.mpc_max_iter * 10)) != hipSuccess || (e = s.pos_x.alloc(S)) != hipSuccess)) {
             st = amk::hip_fail(e);
             break;
         }
@@ -110,6 +178,7 @@ int amk_pipeline_destroy(amk_pipeline *p) {
 }
 
 int amk_pipeline_slots(const amk_pipeline *p) { return p ? (int)p->slots.size() : -1; }
+int amk_pipeline_gang(const amk_pipeline *p) { return p ? p->gang : -1; }
 
 amk_mpc *amk_pipeline_mpc(amk_pipeline *p, int slot) {
     return (p && slot >= 0 && slot < (int)p->slots.size()) ? p->slots[slot].mpc : nullptr;
@@ -122,46 +191,56 @@ void *amk_pipeline_stream(amk_pipeline *p, int slot) {
     return (p && slot >= 0 && slot < (int)p->slots.size()) ? (void *)p->slots[slot].stream : nullptr;
 }
 
-int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *slot_out) {
+int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticket_out) {
     if (!p || !f || !f->d_cloud || !f->d_edge || !f->d_state_quad || !f->d_pos_x || !f->d_ref_path_init)
         return AMK_ERR_INVALID_ARG;
-    const int si = p->next;
+    const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
-    // Flow control.  A slot's steps are ordered by its stream, so queuing the next step behind a running one is safe (same
-    // handles, same workspaces, in order); submit() only blocks when `depth` steps of this slot are still unfinished --
-    // the event about to be re-recorded belongs to the step submitted `depth` submits ago.  depth 1 = at most one step per
-    // slot on the device (every step then pays the host's reaction time between its predecessor's end and its own start).
-    if (s.count - s.waited >= p->depth) {
+    const amk_pipeline_config &c = p->cfg;
+    const int N = amk_mpc_horizon(s.mpc), mi = c.step.mpc_max_iter;
+    const size_t S = c.n_scenes;
+    const int stride = f->point_stride ? f->point_stride : 3;
+    if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
+    // Flow control.  A slot's launches are ordered by its stream, so queuing the next one behind a running one is safe (same
+    // handles, same workspaces, in order); submit() only blocks when `depth` launches of this slot are still unfinished --
+    // the event about to be re-recorded belongs to the launch issued `depth` launches ago.  depth 1 = at most one launch per
+    // slot on the device (every launch then pays the host's reaction time between its predecessor's end and its own start).
+    if (s.open.empty() && s.count - s.waited >= p->depth) {
         const int ws = wait_event(s.done[s.count % p->depth]);
         if (ws != AMK_OK) return ws;
         s.waited = s.count - p->depth + 1;
     }
-    const amk_pipeline_config &c = p->cfg;
-    const int N = amk_mpc_horizon(s.mpc);
-    const size_t S = c.n_scenes;
-    const int stride = f->point_stride ? f->point_stride : 3;
-    // fresh frame: mRefPath after GetInitPath, zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
-    AMK_HIP(hipMemcpyAsync(s.ref_path.p, f->d_ref_path_init, sizeof(double) * S * N * 10, hipMemcpyDeviceToDevice, s.stream));
-    int st = AMK_OK;
-    if (!f->keep_warm_start && (st = amk_mpc_reset_warm_start(s.mpc, s.stream)) != AMK_OK) return st;
-    // FrameKDMap::AddVertex: obstacle index and edge index of the frame (FrameKDMap.cpp:44-47)
-    if ((st = amk_kd_build_pair(s.obstacle, f->d_cloud, f->d_cloud_counts, s.edge, f->d_edge, f->d_edge_counts, stride, s.stream)) != AMK_OK)
-        return st;
-    double *u = f->d_u_out ? f->d_u_out : s.u.p;
-    if ((st = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, f->d_state_quad, f->d_pos_x, s.ref_path.p, u, s.x0array.p,
-                             s.flags.p, s.stream)) != AMK_OK)
-        return st;
-    AMK_HIP(hipEventRecord(s.done[s.count % p->depth], s.stream));
-    ++s.count;
-    p->next = (si + 1) % (int)p->slots.size();
+    const int g = (int)s.open.size();
+    s.point_stride = stride;
+    // the frame's small inputs go into the gang's contiguous buffers (stream-ordered: behind the slot's previous launch):
+    // mRefPath after GetInitPath, which the step refills, and -- with a gang -- mVecStateQuad and mPos.x
+    if (p->gang > 1) {
+        AMK_HIP(hipMemcpyAsync(s.state_quad.p + (size_t)g * S * mi * 10, f->d_state_quad, sizeof(double) * S * mi * 10,
+                               hipMemcpyDeviceToDevice, s.stream));
+        AMK_HIP(hipMemcpyAsync(s.pos_x.p + (size_t)g * S, f->d_pos_x, sizeof(double) * S, hipMemcpyDeviceToDevice, s.stream));
+    }
+    AMK_HIP(hipMemcpyAsync(s.ref_path.p + (size_t)g * S * N * 10, f->d_ref_path_init, sizeof(double) * S * N * 10,
+                           hipMemcpyDeviceToDevice, s.stream));
+    s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
+                                           f->d_u_out, f->keep_warm_start});
+    if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
-    if (slot_out) *slot_out = si;
+    if ((int)s.open.size() == p->gang) {
+        const int st = launch_gang(p, s);
+        if (st != AMK_OK) return st;
+        p->next = (si + 1) % ns;
+    }
     return AMK_OK;
 }
 
-int amk_pipeline_wait(amk_pipeline *p, int slot) {
-    if (!p || slot < 0 || slot >= (int)p->slots.size()) return AMK_ERR_INVALID_ARG;
-    auto &s = p->slots[slot];
+int amk_pipeline_wait(amk_pipeline *p, int ticket) {
+    if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return AMK_ERR_INVALID_ARG;
+    auto &s = p->slots[ticket % (int)p->slots.size()];
+    if (!s.open.empty()) {   // a partly filled gang: launch it now
+        const int st = launch_gang(p, s);
+        if (st != AMK_OK) return st;
+        if (&s == &p->slots[p->next]) p->next = (p->next + 1) % (int)p->slots.size();
+    }
     if (s.waited < s.count) {   // the newest event implies all earlier ones (in-order stream)
         const int ws = wait_event(s.done[(s.count - 1) % p->depth]);
         if (ws != AMK_OK) return ws;
@@ -170,9 +249,10 @@ int amk_pipeline_wait(amk_pipeline *p, int slot) {
     return AMK_OK;
 }
 
-int amk_pipeline_query(amk_pipeline *p, int slot) {  // 1 = finished (or idle), 0 = still running
-    if (!p || slot < 0 || slot >= (int)p->slots.size()) return -1;
-    auto &s = p->slots[slot];
+int amk_pipeline_query(amk_pipeline *p, int ticket) {  // 1 = finished (or idle), 0 = still running or staged, -1 error
+    if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return -1;
+    auto &s = p->slots[ticket % (int)p->slots.size()];
+    if (!s.open.empty()) return 0;
     if (s.waited >= s.count) return 1;
     const hipError_t e = hipEventQuery(s.done[(s.count - 1) % p->depth]);
     if (e == hipSuccess) { s.waited = s.count; return 1; }
@@ -188,13 +268,15 @@ int amk_pipeline_drain(amk_pipeline *p) {
     return AMK_OK;
 }
 
-int amk_pipeline_outputs(amk_pipeline *p, int slot, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path) {
-    if (!p || slot < 0 || slot >= (int)p->slots.size()) return AMK_ERR_INVALID_ARG;
-    auto &s = p->slots[slot];
-    if (d_u) *d_u = s.u.p;
-    if (d_x0array) *d_x0array = s.x0array.p;
-    if (d_flags) *d_flags = s.flags.p;
-    if (d_ref_path) *d_ref_path = s.ref_path.p;
+int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path) {
+    if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return AMK_ERR_INVALID_ARG;
+    const int ns = (int)p->slots.size(), g = ticket / ns;
+    auto &s = p->slots[ticket % ns];
+    const size_t S = p->cfg.n_scenes, N = amk_mpc_horizon(s.mpc), o = (size_t)g * S;
+    if (d_u) *d_u = s.u.p + o * 4;
+    if (d_x0array) *d_x0array = s.x0array.p + o * N * 14;
+    if (d_flags) *d_flags = s.flags.p + o * 4;
+    if (d_ref_path) *d_ref_path = s.ref_path.p + o * N * 10;
     return AMK_OK;
 }
 

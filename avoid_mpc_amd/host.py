@@ -231,19 +231,23 @@ class MpcBatch:
 
 
 class Pipeline:
-    """amk_pipeline: n_slots control steps in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs}."""
+    """amk_pipeline: n_slots launches in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs};
+    gang = frames (of n_scenes scenes) that share one set of launches -- the slot's handles then hold gang * n_scenes scenes."""
 
-    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0):
+    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0):
         self.lib = capi.load()
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
-                                  int(prm.K), int(queue_depth), capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
+                                  int(prm.K), int(queue_depth), int(gang),
+                                  capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
         self.N = self.lib.amk_mpc_horizon(self.lib.amk_pipeline_mpc(h, 0))
-        self._mpc = [MpcBatch(prm.T, prm.dt, prm.K, n_scenes, handle=self.lib.amk_pipeline_mpc(h, i)) for i in range(n_slots)]
-        self._kd = [(KdBatch(n_scenes, max_points, handle=self.lib.amk_pipeline_kd(h, i, 0)),
-                     KdBatch(n_scenes, max_edge_points, handle=self.lib.amk_pipeline_kd(h, i, 1))) for i in range(n_slots)]
+        self.gang = self.lib.amk_pipeline_gang(h)
+        hs = n_scenes * self.gang   # scenes of a slot's handles
+        self._mpc = [MpcBatch(prm.T, prm.dt, prm.K, hs, handle=self.lib.amk_pipeline_mpc(h, i)) for i in range(n_slots)]
+        self._kd = [(KdBatch(hs, max_points, handle=self.lib.amk_pipeline_kd(h, i, 0)),
+                     KdBatch(hs, max_edge_points, handle=self.lib.amk_pipeline_kd(h, i, 1))) for i in range(n_slots)]
         for m in self._mpc:
             m.configure(prm)
 
@@ -262,8 +266,9 @@ class Pipeline:
 
     def submit(self, clouds, edges, state_quad, pos_x, ref_path_init, cloud_counts=None, edge_counts=None, u_out=None,
                keep_warm_start=False):
-        """One fresh frame + control step on the next slot; returns the slot index at once (blocks only when that slot's
-        previous step is still running).  All tensors are device tensors that must stay alive until the slot finished."""
+        """One fresh frame + control step on the next slot; returns its ticket at once (blocks only when that slot's queue
+        is full).  ticket % n_slots = slot; with a gang the frame is staged until the gang is full (or wait / drain).
+        All tensors are device tensors that must stay alive until the frame finished."""
         assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
         fr = capi.PipelineFrame(clouds.data_ptr(), cloud_counts.data_ptr() if cloud_counts is not None else None,
                                 edges.data_ptr(), edge_counts.data_ptr() if edge_counts is not None else None,
@@ -273,16 +278,16 @@ class Pipeline:
         capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
         return slot.value
 
-    def wait(self, slot):
-        capi.check(self.lib.amk_pipeline_wait(self.h, int(slot)), "amk_pipeline_wait")
+    def wait(self, ticket):
+        capi.check(self.lib.amk_pipeline_wait(self.h, int(ticket)), "amk_pipeline_wait")
 
     def drain(self):
         capi.check(self.lib.amk_pipeline_drain(self.h), "amk_pipeline_drain")
 
-    def outputs(self, slot):
-        """Host copies of the slot's results (after wait): dict(u [S,4], x0array [S,N,14], flags [S,4], ref_path [S,N,10])."""
+    def outputs(self, ticket):
+        """Host copies of the frame's results (after wait): dict(u [S,4], x0array [S,N,14], flags [S,4], ref_path [S,N,10])."""
         ptr = [C.c_void_p() for _ in range(4)]
-        capi.check(self.lib.amk_pipeline_outputs(self.h, int(slot), *[C.byref(p) for p in ptr]), "amk_pipeline_outputs")
+        capi.check(self.lib.amk_pipeline_outputs(self.h, int(ticket), *[C.byref(p) for p in ptr]), "amk_pipeline_outputs")
         S, N = self.S, self.N
         shapes = [((S, 4), np.float64), ((S, N, 14), np.float64), ((S, 4), np.int32), ((S, N, 10), np.float64)]
         out = {}

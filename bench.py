@@ -200,6 +200,8 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--streams", type=int, default=20,
                     help="independent steps in flight (each on its own HIP stream with its own frames and handles)")
+    ap.add_argument("--gang", type=int, default=1,
+                    help="steps (frames) that share one set of launches on a slot (amk_pipeline_config.gang)")
     ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1 without, 8 with a process group)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
@@ -242,6 +244,8 @@ def main():
     prm = synth.MpcParams(T=args.T, K=args.K)
     S, n, ne, N = args.scenes, args.points, args.points // 10, prm.N
     nslots = max(1, args.streams)
+    gang = max(1, args.gang)
+    nframes = nslots * gang   # distinct frame sets: every step in flight (or staged) owns its inputs
 
     class Frames:
         """The inputs one in-flight step owns: its frames (obstacle + edge clouds of S scenes) and odometry.  Consecutive
@@ -249,7 +253,7 @@ def main():
         MPC batch + outputs); while one step sits in its latency-bound solve another streams its clouds."""
 
         def __init__(self, i):
-            seed = 100000 + (rank * nslots + i) * S
+            seed = 100000 + (rank * nframes + i) * S
             self.clouds, self.edges = synth.make_clouds_torch(n, S, seed, dev)
             sq = np.zeros((S, prm.max_iter, 10)); ref0 = np.zeros((S, N, 10)); posx = np.zeros(S)
             for s in range(S):
@@ -266,14 +270,14 @@ def main():
     # the process the host sees a finished step ~0.3 ms late (cause not found: tools/experiments/rccl_presence.py) and a slot
     # that waits for the host idles: 287 k steps/s at depth 1, 384 k at 3, 402 k at 8 -- so the next steps are queued ahead
     qdepth = args.queue_depth if args.queue_depth > 0 else (8 if collective else 1)
-    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=qdepth)
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=qdepth, gang=gang)
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
         pl.mpc(i).set_precision(args.precision)
         if args.ipm_max_iter is not None:
             pl.mpc(i).set_solver_options(1e-4, args.ipm_max_iter)
-    slots = [Frames(i) for i in range(nslots)]
-    max_rows = max(args.steps, args.steady_steps if args.steps < args.steady_steps else 0, nslots, args.warmup, 64)
+    slots = [Frames(i) for i in range(nframes)]
+    max_rows = max(args.steps, args.steady_steps if args.steps < args.steady_steps else 0, nframes, args.warmup, 64)
     u_sweep = torch.zeros((max_rows, S, 4), dtype=torch.float64, device=dev)   # the sweep's controls, one row per step
     sh = None
     if collective:   # RCCL through the library's own binding (amk_shard_*); torch.distributed only carries the 128-byte id
@@ -287,6 +291,7 @@ def main():
     # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
     # value is then NOT the metric (the JSON line says so)
     DIAG_SKIP = os.environ.get("AMK_BENCH_SKIP", "")
+    assert not (DIAG_SKIP in ("build", "step") and gang > 1), "AMK_BENCH_SKIP=build|step drives the slots' handles directly: --gang 1"
     diag_streams = [torch.cuda.ExternalStream(lib.amk_pipeline_stream(pl.h, i), device=dev) for i in range(nslots)] \
         if DIAG_SKIP in ("build", "step") else None
     diag_ref = [fr.ref0.clone() for fr in slots] if diag_streams else None
@@ -294,13 +299,13 @@ def main():
     diag_fl = torch.empty((S, 4), dtype=torch.int32, device=dev) if diag_streams else None
 
     def one_step(row, frames=None):
-        i = step_no[0] % nslots
+        """Submits one step (a fresh frame of S scenes); returns its ticket (= slot when gang == 1)."""
+        i = step_no[0] % nframes
         fr = slots[i if frames is None else frames]
         step_no[0] += 1
         fr.last_row = row
         if diag_streams is None:
-            pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row])
-            return
+            return pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row])
         st = diag_streams[i]
         with torch.cuda.stream(st):
             diag_ref[i].copy_(fr.ref0, non_blocking=True)
@@ -310,11 +315,6 @@ def main():
             if DIAG_SKIP != "step":
                 step_batch(pl.kd(i, 0), pl.kd(i, 1), pl.mpc(i), prm, fr.sq, fr.posx, diag_ref[i], stream=st,
                            out=dict(u=u_sweep[row], x0array=diag_x0, flags=diag_fl))
-
-    def one_step_and_slot(row, frames=None):
-        i = step_no[0] % nslots
-        one_step(row, frames)
-        return i
 
     def barrier():
         torch.cuda.synchronize()
@@ -355,7 +355,7 @@ def main():
         torch.cuda.synchronize()
         return float(t.item())
 
-    for j in range(nslots):                # untimed priming: every slot allocates its workspace once
+    for j in range(nframes):               # untimed priming: every slot allocates its workspace once
         one_step(j)
     barrier()
     if DIAG_SKIP in ("knn", "plan", "solve", "knn+plan"):   # diagnostics: kernel classes left out of the step from here on
@@ -374,7 +374,7 @@ def main():
     lib.amk__timing_enable(0)
     dt = max_over_ranks(dt)
 
-    flags = np.concatenate([pl.outputs(i)["flags"] for i in range(nslots)]) if diag_streams is None else np.zeros((1, 4), np.int32)
+    flags = np.concatenate([pl.outputs(t)["flags"] for t in range(nframes)]) if diag_streams is None else np.zeros((1, 4), np.int32)
     solves = float(flags[:, 1].mean()); ipm_iters = float(flags[:, 3].mean())
     steady = None
     if args.steps < args.steady_steps:     # the timed region above is mostly ramp-up / drain of the in-flight slots
@@ -390,13 +390,15 @@ def main():
     if rank == 0 and diag_streams is None:
         lib.amk__timing_enable(2)
         reps = 6   # always the frames of in-flight slot 0 = the scenes of `bench.py --streams 1` (the committed rocprof trace)
-        for j in range(reps):
-            pl.wait(one_step_and_slot(j, frames=0))
+        for j in range(reps):   # one LAUNCH at a time: the `gang` steps that share it (frames 0 .. gang-1), then wait
+            for g in range(gang):
+                t = one_step(j * gang + g, frames=g)
+            pl.wait(t)
         torch.cuda.synchronize()
         ms1 = (C.c_double * 8)(); cnt1 = (C.c_int * 8)()
         capi.check(lib.amk__timing_collect(ms1, cnt1), "timing")
         lib.amk__timing_enable(0)
-        lone = {KCLASS[i]: {"avg_launch_us": round(1e3 * ms1[i] / cnt1[i], 2), "launches_per_step": cnt1[i] / reps}
+        lone = {KCLASS[i]: {"avg_launch_us": round(1e3 * ms1[i] / cnt1[i], 2), "launches_per_step": cnt1[i] / (reps * gang)}
                 for i in range(8) if cnt1[i] and KCLASS[i]}
     breakdown = None
     if args.breakdown and world == 1:   # (extra steps on one rank would unbalance the collectives)
@@ -426,8 +428,8 @@ def main():
         total_scenes = S * world * args.steps
         value = total_scenes / dt
         step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
-        alg_launch = solve_alg_bytes(N, prm.K) * S
-        build_alg = 28 * S * (n + ne)            # 12 B read + 16 B written per point; ONE launch builds the obstacle and the edge index (amk_kd_build_pair)
+        alg_launch = solve_alg_bytes(N, prm.K) * S * gang
+        build_alg = 28 * S * gang * (n + ne)            # 12 B read + 16 B written per point; ONE launch builds the obstacle and the edge index (amk_kd_build_pair)
         inflight_solve_ms = ms[5] / max(cnt[5], 1)
         inflight_build_ms = ms[7] / max(cnt[7], 1)
         solve_us = lone["mpc_solve_kernel"]["avg_launch_us"] if lone else None
@@ -486,7 +488,8 @@ def main():
                        "horizon": N, "K": prm.K, "mpc_max_iter": prm.max_iter,
                        "ipm_max_iter": args.ipm_max_iter if args.ipm_max_iter is not None else capi.AMK_MPC_DEFAULT_MAX_ITER,
                        "ipm_tol": 1e-4, "solves_per_step": round(solves, 3), "ipm_iters_per_step": round(ipm_iters, 2),
-                       "streams_in_flight": nslots, "distinct_frames_bytes": int(nslots * S * 12 * (n + ne)),
+                       "streams_in_flight": nslots, "steps_per_launch": gang, "scenes_per_launch": S * gang,
+                       "distinct_frames_bytes": int(nframes * S * 12 * (n + ne)),
                        "hw_queues": int(os.environ["GPU_MAX_HW_QUEUES"]),
                        "tie_order": "nanoflann" if args.tie_order else "lowest index",
                        "host_submit_ms_per_step": round(1e3 * t_enq / args.steps, 4), "timed_region_phases_s": timed_phases,

@@ -299,6 +299,7 @@ typedef struct amk_pipeline amk_pipeline;
 #define AMK_PIPELINE_MAX_SLOTS 64
 #define AMK_PIPELINE_DEFAULT_DEPTH 3
 #define AMK_PIPELINE_MAX_DEPTH 64
+#define AMK_PIPELINE_MAX_GANG 4
 typedef struct amk_pipeline_config {
     int n_slots;            /* independent steps in flight                                                              */
     int n_scenes;           /* scenes per step (S of every handle)                                                      */
@@ -310,6 +311,12 @@ typedef struct amk_pipeline_config {
                             /* A slot's steps run in order on its stream; with depth >= 2 the next step is already queued   */
                             /* when one ends (no host round trip between them).  Results of a step must be read -- wait(),  */
                             /* outputs() -- before a later submit() on the same slot overwrites them, or go to d_u_out.      */
+    int gang;               /* frames per launch (0 / 1 = every frame has its own launches; <= AMK_PIPELINE_MAX_GANG).       */
+                            /* G > 1: a slot's handles hold G x n_scenes scenes and G consecutive submit()s share one set   */
+                            /* of launches (both index builds of all G frames in one launch, one amk_step_batch); a frame   */
+                            /* is staged until its gang is full -- wait() / drain() launch a partly filled gang.  Results   */
+                            /* are those of separate launches, bit for bit (scenes are independent).  On the bench workload */
+                            /* 2 x 256-scene frames per launch on 10 slots beat 1 per launch on 20.   */
     amk_step_params step;
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
@@ -329,16 +336,19 @@ typedef struct amk_pipeline_frame {
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out);
 int amk_pipeline_destroy(amk_pipeline *p);
 int amk_pipeline_slots(const amk_pipeline *p);
+int amk_pipeline_gang(const amk_pipeline *p);       /* frames per launch (>= 1)                                            */
 /* The slot's handles, to configure them (weights, limits, tie order, precision ...) and its stream.                       */
 amk_mpc *amk_pipeline_mpc(amk_pipeline *p, int slot);
 amk_kd *amk_pipeline_kd(amk_pipeline *p, int slot, int which /* 0 obstacle, 1 edge */);
 void *amk_pipeline_stream(amk_pipeline *p, int slot);
-int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *frame, int *slot_out);
-int amk_pipeline_wait(amk_pipeline *p, int slot);   /* until that slot's step has finished                                */
-int amk_pipeline_query(amk_pipeline *p, int slot);  /* 1 finished / idle, 0 running, -1 error                             */
-int amk_pipeline_drain(amk_pipeline *p);            /* wait for every slot                                                */
-/* Device pointers of the slot's results (valid after wait): u [S][4], x0array [S][N][14], flags [S][4], ref_path [S][N][10] */
-int amk_pipeline_outputs(amk_pipeline *p, int slot, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path);
+/* submit() hands back a ticket = position_in_gang * n_slots + slot (without a gang: the slot index, as before);
+ * ticket % n_slots is the slot, for amk_pipeline_mpc / _kd / _stream.                                                    */
+int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *frame, int *ticket_out);
+int amk_pipeline_wait(amk_pipeline *p, int ticket);   /* until that frame's step has finished (launches an open gang)     */
+int amk_pipeline_query(amk_pipeline *p, int ticket);  /* 1 finished / idle, 0 running or staged, -1 error                 */
+int amk_pipeline_drain(amk_pipeline *p);              /* wait for every slot                                              */
+/* Device pointers of the frame's results (valid after wait): u [S][4], x0array [S][N][14], flags [S][4], ref_path [S][N][10] */
+int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Scenes sharded over the GPUs of a node (one process per GPU), RCCL over xGMI                 */

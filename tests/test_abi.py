@@ -53,7 +53,7 @@ def test_no_cpu_fallback(lib):
     assert not h.value
     assert lib.amk_mpc_create(0.66, 0.033, 8, 1, C.byref(h)) == 3
     assert not h.value
-    cfg = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, capi.StepParams(10.0, 0.2, 3, 0))
+    cfg = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 0, capi.StepParams(10.0, 0.2, 3, 0))
     assert lib.amk_pipeline_create(C.byref(cfg), C.byref(h)) == 3 and not h.value
     assert lib.amk_shard_create(b"\0" * 128, 0, 1, C.byref(h)) == 3 and not h.value
     first, count = C.c_int(), C.c_int()   # the partition itself is host arithmetic

@@ -73,16 +73,81 @@ def test_pipeline_equals_the_separate_calls(depth):
     pl.close()
 
 
+@pytest.mark.parametrize("gang,n_frames", [(2, 8), (3, 7)])
+def test_pipeline_gang_equals_the_separate_calls(gang, n_frames):
+    """gang frames per launch: every frame still returns what its own launches return, bit for bit -- also the frames of a
+    gang that wait() / drain() had to launch partly filled; tickets address the frame's part of the slot's buffers."""
+    import torch
+    from avoid_mpc_amd.host import KdBatch, MpcBatch, Pipeline, step_batch
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne, n_slots = 5, 3000, 300, 2
+    frames = _frames(torch, prm, n_frames, S, n)
+    counts = [torch.full((S,), n - 7 * i, dtype=torch.int32, device="cuda") for i in range(n_frames)]   # ragged over frames
+    want = []
+    kd_o, kd_e = KdBatch(S, n), KdBatch(S, ne)
+    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
+    for fr, cnt in zip(frames, counts):
+        kd_o.build(fr["cl"], counts=cnt); kd_e.build(fr["ed"]); mpc.reset_warm_start()
+        ref = fr["ref"].clone()
+        o = step_batch(kd_o, kd_e, mpc, prm, fr["sq"], fr["px"], ref)
+        torch.cuda.synchronize()
+        want.append(dict(u=o["u"].cpu().numpy().copy(), flags=o["flags"].cpu().numpy().copy(), x0=o["x0array"].cpu().numpy().copy(),
+                         ref=ref.cpu().numpy().copy()))
+    pl = Pipeline(n_slots, S, n, ne, prm, queue_depth=2, gang=gang)
+    assert pl.gang == gang and pl.mpc(0).S == gang * S
+    rows = torch.zeros((n_frames, S, 4), dtype=torch.float64, device="cuda")
+    tickets = [pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"], cloud_counts=cnt, u_out=rows[i])
+               for i, (fr, cnt) in enumerate(zip(frames, counts))]
+    # G consecutive frames on one slot, then the next slot; ticket = position in the gang * n_slots + slot
+    assert tickets == [(i % gang) * n_slots + (i // gang) % n_slots for i in range(n_frames)]
+    if n_frames % gang:
+        assert pl.lib.amk_pipeline_query(pl.h, tickets[-1]) == 0      # staged, not launched yet
+    pl.drain()
+    assert all(pl.lib.amk_pipeline_query(pl.h, t) == 1 for t in tickets)
+    got = rows.cpu().numpy()
+    for i in range(n_frames):
+        assert np.array_equal(got[i], want[i]["u"]), i
+    # the frame's part of the slot's buffers: the last frame that ran at that ticket
+    for t in set(tickets):
+        last = max(i for i in range(n_frames) if tickets[i] == t)
+        if any(tickets[j] % n_slots == t % n_slots for j in range(last + 1, n_frames) if j // gang != last // gang):
+            continue                                                   # a later gang of the slot overwrote it
+        o = pl.outputs(t)
+        assert np.array_equal(o["u"], want[last]["u"]) and np.array_equal(o["flags"], want[last]["flags"])
+        assert np.array_equal(o["x0array"], want[last]["x0"]) and np.array_equal(o["ref_path"], want[last]["ref"])
+    # wait() on a staged frame launches its gang (padded with copies of it)
+    t = pl.submit(frames[1]["cl"], frames[1]["ed"], frames[1]["sq"], frames[1]["px"], frames[1]["ref"], cloud_counts=counts[1])
+    pl.wait(t)
+    assert np.array_equal(pl.outputs(t)["u"], want[1]["u"])
+    # keep_warm_start is per frame: frame A keeps the slot's solution at its position, frame B at the same launch starts cold
+    a, b = frames[2], frames[3]
+    for _ in range(n_slots):   # run (a, b, ...) cold on every slot so that position 0 and 1 hold a's and b's solutions
+        ta = pl.submit(a["cl"], a["ed"], a["sq"], a["px"], a["ref"], cloud_counts=counts[2])
+        tb = pl.submit(b["cl"], b["ed"], b["sq"], b["px"], b["ref"], cloud_counts=counts[3])
+        pl.wait(tb)
+    cold_a, cold_b = pl.outputs(ta)["flags"][:, 3].sum(), pl.outputs(tb)["flags"][:, 3].sum()
+    for _ in range(n_slots):
+        ta2 = pl.submit(a["cl"], a["ed"], a["sq"], a["px"], a["ref"], cloud_counts=counts[2], keep_warm_start=True)
+        tb2 = pl.submit(b["cl"], b["ed"], b["sq"], b["px"], b["ref"], cloud_counts=counts[3])
+        pl.wait(tb2)
+    assert (ta2, tb2) == (ta, tb)
+    assert pl.outputs(ta2)["flags"][:, 3].sum() < cold_a and pl.outputs(tb2)["flags"][:, 3].sum() == cold_b
+    assert np.array_equal(pl.outputs(tb2)["u"], want[3]["u"])
+    pl.close()
+
+
 def test_pipeline_argument_errors():
     import torch  # noqa: F401  (one HIP runtime per process)
     lib = capi.load()
     h = C.c_void_p()
     sp = capi.StepParams(10.0, 0.2, 3, 0)
-    bad = capi.PipelineConfig(0, 4, 100, 10, 0.33, 0.033, 3, 0, sp)
+    bad = capi.PipelineConfig(0, 4, 100, 10, 0.33, 0.033, 3, 0, 0, sp)
     assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
-    bad = capi.PipelineConfig(2, 4, 100, 10, 5.0, 0.033, 3, 0, sp)                       # N = 151 > AMK_MAX_HORIZON
+    bad = capi.PipelineConfig(2, 4, 100, 10, 5.0, 0.033, 3, 0, 0, sp)                       # N = 151 > AMK_MAX_HORIZON
     assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED and not h.value
-    ok = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, sp)
+    bad = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 5, sp)                      # gang > AMK_PIPELINE_MAX_GANG
+    assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
+    ok = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 0, sp)
     assert lib.amk_pipeline_create(C.byref(ok), C.byref(h)) == 0
     fr = capi.PipelineFrame()                                                            # all NULL
     assert lib.amk_pipeline_submit(h, C.byref(fr), None) == capi.AMK_ERR_INVALID_ARG
