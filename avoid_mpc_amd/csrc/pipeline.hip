@@ -11,10 +11,10 @@
 //
 // Gang (amk_pipeline_config.gang = G > 1): G consecutively submitted frames share ONE set of launches -- the slot's handles
 // hold G x n_scenes scenes, frame g occupies scenes [g S, (g + 1) S).  More than ~28 streams collapse on this runtime (32
-// hardware queues), so a gang is how MORE scenes are kept in flight than 20-odd slots of one frame hold: on the bench
-// workload (256-scene frames) 16 slots x 2 frames reach 505 k scene-steps/s in the steady state against 460 k for 20 x 1
-// (DESIGN.md section 7).  A frame is only STAGED by submit() until its gang is full; wait() / drain() launch a partly
-// filled gang.
+// hardware queues), so a gang is how MORE scenes are kept in flight than 20-odd slots of one frame hold, in fewer and
+// fuller launches: on the bench workload (256-scene frames) 10 slots x 4 frames reach 519 k scene-steps/s in the steady
+// state against 466 k for 20 x 1, and 410-422 k against 378 k over a 20-frame burst (same box).
+// A frame is only STAGED by submit() until its gang is full; wait() / drain() launch a partly filled gang.
 #include "mpc_handle.h"
 
 #include <cstdlib>
@@ -261,6 +261,12 @@ int amk_pipeline_query(amk_pipeline *p, int ticket) {  // 1 = finished (or idle)
 
 int amk_pipeline_drain(amk_pipeline *p) {
     if (!p) return AMK_ERR_INVALID_ARG;
+    for (auto &s : p->slots) {   // every open gang first: a launch must not wait for the slots before it to finish
+        if (s.open.empty()) continue;
+        const int st = launch_gang(p, s);
+        if (st != AMK_OK) return st;
+        if (&s == &p->slots[p->next]) p->next = (p->next + 1) % (int)p->slots.size();
+    }
     for (int i = 0; i < (int)p->slots.size(); ++i) {
         const int st = amk_pipeline_wait(p, i);
         if (st != AMK_OK) return st;

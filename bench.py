@@ -198,10 +198,12 @@ def main():
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--T", type=float, default=0.66)
     ap.add_argument("--K", type=int, default=8)
-    ap.add_argument("--streams", type=int, default=20,
-                    help="independent steps in flight (each on its own HIP stream with its own frames and handles)")
-    ap.add_argument("--gang", type=int, default=1,
-                    help="steps (frames) that share one set of launches on a slot (amk_pipeline_config.gang)")
+    ap.add_argument("--streams", type=int, default=10,
+                    help="pipeline slots = independent launches in flight (each on its own HIP stream with its own handles)")
+    ap.add_argument("--gang", type=int, default=4,
+                    help="steps (frames) that share one set of launches on a slot (amk_pipeline_config.gang): streams x gang steps "
+                         "are in flight or staged.  10 x 4 against the 20 x 1 of rounds 2-3a, same box: 519 k vs 466 k scene-steps/s "
+                         "steady, 410-422 k vs 378 k over the driver's 20 steps")
     ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1 without, 8 with a process group)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
@@ -317,6 +319,8 @@ def main():
                            out=dict(u=u_sweep[row], x0array=diag_x0, flags=diag_fl))
 
     def barrier():
+        if diag_streams is None:
+            pl.drain()   # (launches a gang that the steps so far left partly filled)
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -496,7 +500,9 @@ def main():
                        "parallelism": (f"scenes sharded over {world} GPU(s); one ncclAllGather (amk_shard_gather) of the sweep's "
                                        f"controls, {args.steps} x {S} x 4 doubles per rank, inside the timed region" if collective
                                        else "single GPU, no process group"),
-                       "orchestration": "amk_pipeline_* (C ABI): submit() per step, drain() at the end", "queue_depth_per_slot": qdepth},
+                       "orchestration": f"amk_pipeline_* (C ABI): submit() per step, drain() at the end; {nslots} slots x gang {gang} "
+                                        f"(= {gang} consecutive steps share one set of launches of {S * gang} scenes)",
+                       "queue_depth_per_slot": qdepth},
             "roofline": {"bound": "valu-issue (dependent fp64 / LDS latency at 2 waves per SIMD; neither HBM nor MFMA)",
                          "kernel": f"mpc_solve_kernel<{N}>",
                          "achieved": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),

@@ -73,7 +73,7 @@ def test_pipeline_equals_the_separate_calls(depth):
     pl.close()
 
 
-@pytest.mark.parametrize("gang,n_frames", [(2, 8), (3, 7)])
+@pytest.mark.parametrize("gang,n_frames", [(2, 8), (3, 7), (8, 19)])
 def test_pipeline_gang_equals_the_separate_calls(gang, n_frames):
     """gang frames per launch: every frame still returns what its own launches return, bit for bit -- also the frames of a
     gang that wait() / drain() had to launch partly filled; tickets address the frame's part of the slot's buffers."""
@@ -145,7 +145,7 @@ def test_pipeline_argument_errors():
     assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
     bad = capi.PipelineConfig(2, 4, 100, 10, 5.0, 0.033, 3, 0, 0, sp)                       # N = 151 > AMK_MAX_HORIZON
     assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED and not h.value
-    bad = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 5, sp)                      # gang > AMK_PIPELINE_MAX_GANG
+    bad = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 9, sp)                      # gang > AMK_PIPELINE_MAX_GANG
     assert lib.amk_pipeline_create(C.byref(bad), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
     ok = capi.PipelineConfig(2, 4, 100, 10, 0.33, 0.033, 3, 0, 0, sp)
     assert lib.amk_pipeline_create(C.byref(ok), C.byref(h)) == 0
