@@ -184,13 +184,13 @@ def test_argument_errors(torch_cuda):
 
 
 def test_points_outside_the_sampled_box_and_nan_runs(torch_cuda, oracle):
-    """amk_kd_build takes its grid box from every 16th point of a large cloud: far outliers at unsampled positions are
+    """amk_kd_build takes its grid box from a sample of a large cloud (runs of 64 points, one run in 16): far outliers at unsampled positions are
     clamped into boundary cells and must still be found (or correctly ignored); runs of NaN-x points shift the cloud
     indices of everything behind them."""
     rng = np.random.default_rng(21)
     n = 40000
     pts = rng.uniform([-5, -5, 0], [5, 5, 3], (n, 3)).astype(np.float32)
-    out = np.arange(n)[np.arange(n) % 16 != 0][::97][:300]          # never a sampled position
+    out = np.arange(n)[np.arange(n) % 1024 >= 64][::97][:300]        # never a sampled position
     pts[out] = rng.uniform(-60, 60, (len(out), 3)).astype(np.float32)
     q = np.concatenate([rng.uniform([-6, -6, -1], [6, 6, 4], (40, 3)), pts[out[:12]].astype(np.float64) + 0.25,
                         rng.uniform(-70, 70, (12, 3))])                # (a NaN query is undefined in the reference too)
