@@ -389,7 +389,7 @@ def main():
     # bracketed by HIP events on its launch stream.  Nothing else is resident, so submit-to-complete is the kernel's duration
     # (+ a few us of launch latency) -- the number `rocprofv3 --kernel-trace` of `bench.py --streams 1` reports
     # (profiles/r03_kernel_stats_streams1.md; same scenes: the frames of in-flight slot 0).  In the timed region above the same events also contain the wait for CUs the
-    # other 19 steps occupy, which is why that figure is reported separately as in_flight_submit_to_complete_ms.
+    # other launches in flight occupy, which is why that figure is reported separately as in_flight_submit_to_complete_ms.
     lone = None
     if rank == 0 and diag_streams is None:
         lib.amk__timing_enable(2)
@@ -448,7 +448,7 @@ def main():
         tj = prof.get("traffic")
         if tj:   # PMC passes cannot run inside this process: reuse the committed rocprofv3 result of the same command
             m = tj.get("_meta", {})
-            if (m.get("scenes_per_gpu"), m.get("points"), m.get("horizon"), m.get("K")) == (S, n, N, prm.K):
+            if (m.get("scenes_per_gpu"), m.get("gang", 1), m.get("points"), m.get("horizon"), m.get("K")) == (S, gang, n, N, prm.K):
                 kk = tj["kernels"].get(f"mpc_solve_kernel<{N}>"); kb = tj["kernels"].get("kd_build_kernel")
                 traffic = round(kk["hbm_bytes_per_launch_x2"]) if kk else None
                 build_traffic = round(kb["hbm_bytes_per_launch_x2"]) if kb else None

@@ -32,9 +32,10 @@ def test_bench_line_has_the_contract_fields_and_consistent_rooflines():
     assert within(r["frac"], solves_per_s * valu * 4 / (256 * 4 * 2.4e9), 0.02)
     assert within(r["frac_at_saturation_solves_only"], issue["valu_issue_util_at_saturation"], 0.02)
     assert r["frac"] < r["frac_at_saturation_solves_only"] < 1.0
-    # the HBM-bound kernel: one launch builds both trees of 256 frames
+    # the HBM-bound kernel: one launch builds both trees of the 256 scenes of every step of a gang
     b = line["roofline_kd_build"]
-    assert b["alg_bytes_per_launch"] == 28 * 256 * 55000
+    G = line["config"]["steps_per_launch"]
+    assert b["alg_bytes_per_launch"] == 28 * 256 * G * 55000 and line["config"]["scenes_per_launch"] == 256 * G
     assert within(b["avg_launch_us"], kt1["kd_build_kernel"]["avg_us"], 0.12)   # the event bracket holds ~8 us of dispatch
     assert within(b["frac"], b["alg_bytes_per_launch"] / (kt1["kd_build_kernel"]["avg_us"] * 1e-6) / 8e12, 0.12)
     assert within(b["traffic"], traffic["kd_build_kernel"]["hbm_bytes_per_launch_x2"], 0.02)

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Turns the raw outputs of tools/prof/r03_profile.sh (gpurun_out/<tag>/...) into the summaries committed under profiles/:
   profiles/r03_bench.json                 the bench line (default run) + the 20-step line
-  profiles/r03_kernel_stats.md            rocprofv3 --kernel-trace --stats of `bench.py --steps 256` (20 steps in flight)
+  profiles/r03_kernel_stats.md            rocprofv3 --kernel-trace --stats of `bench.py --steps 256` (10 slots x 4 steps per launch in flight)
   profiles/r03_kernel_stats_streams1.md   the same with --streams 1: clean per-kernel durations
   profiles/r03_pmc_traffic.{json,md}      HBM bytes per launch (FETCH_SIZE x2 + WRITE_SIZE, separate passes)
   profiles/r03_pmc_solve_issue.{json,md}  what bounds mpc_solve_kernel: VALU issue / LDS / wait fractions (SQ counters)
-usage: tools/prof/r03_collect.py <tag>"""
+usage: tools/prof/r03_collect.py <tag> [--profiles-only]"""
 import collections
 import csv
 import io
@@ -36,14 +36,18 @@ def counters(path):
     return {k: {c: v / len(n[k]) for c, v in acc[k].items()} for k in acc}, {k: len(v) for k, v in n.items()}
 
 
-bench = last_json(os.path.join(src, "bench.json"))
-b20 = last_json(os.path.join(src, "bench_20steps.json"))
-json.dump({"default_run": bench, "driver_style_20_steps": b20,
-           "streams_1": last_json(os.path.join(src, "bench_streams1.json")),
-           "ipm_cap_40_same_box": last_json(os.path.join(src, "bench_cap40.json")),
-           "torchrun_1_rank": last_json(os.path.join(src, "bench_torchrun_1rank.json")),
-           "under_rocprofv3_kernel_trace": last_json(os.path.join(src, "bench_under_rocprof.json"))},
-          open(os.path.join(dst, "r03_bench.json"), "w"), indent=1)
+PROFILES_ONLY = "--profiles-only" in sys.argv   # on the GPU box, before the bench lines are taken: they quote these summaries
+if not PROFILES_ONLY:
+    bench = last_json(os.path.join(src, "bench.json"))
+    b20 = last_json(os.path.join(src, "bench_20steps.json"))
+    json.dump({"default_run": bench, "driver_style_20_steps": b20,
+               "streams_1": last_json(os.path.join(src, "bench_streams1.json")),
+               "ipm_cap_40_same_box": last_json(os.path.join(src, "bench_cap40.json")),
+               "streams_20_gang_1_same_box": last_json(os.path.join(src, "bench_20x1.json")),
+               "streams_20_gang_1_20_steps_same_box": last_json(os.path.join(src, "bench_20x1_20steps.json")),
+               "torchrun_1_rank": last_json(os.path.join(src, "bench_torchrun_1rank.json")),
+               "under_rocprofv3_kernel_trace": last_json(os.path.join(src, "bench_under_rocprof.json"))},
+              open(os.path.join(dst, "r03_bench.json"), "w"), indent=1)
 hdr = ("rocprofv3 --kernel-trace --stats -- python bench.py %s (tools/prof/r03_profile.sh, raw .db under gpurun_out/%s; "
        "summary by tools/rocprof_summary.py).  Torch kernels in the list generate the synthetic frames (setup, untimed).\n\n")
 for sub, name, args in (("kt20", "r03_kernel_stats.md", "--steps 256 --no-cpu-baseline --no-parity --steady-steps 0"),
@@ -66,16 +70,17 @@ sys.argv = ["pmc_traffic.py", os.path.join(src, "pmc_fetch", "f_counter_collecti
 exec(open(os.path.join(ROOT, "tools", "pmc_traffic.py")).read())
 sys.stdout = sys.__stdout__
 tj = json.load(open(os.path.join(dst, "r03_pmc_traffic.json.tmp"))); os.remove(os.path.join(dst, "r03_pmc_traffic.json.tmp"))
-cfg = bench["config"]
+cfg = last_json(os.path.join(src, "bench_streams1.json"))["config"]   # the command of the PMC passes
 n, ne, S = cfg["points"], cfg["points"] // 10, cfg["scenes_per_gpu"]
 tj = {k: v for k, v in tj.items() if any(t in k for t in ("mpc_", "kd_", "step_"))}
-json.dump({"_meta": {"scenes_per_gpu": S, "points": n, "horizon": cfg["horizon"], "K": cfg["K"], "streams": 1,
+G = cfg.get("steps_per_launch", 1)
+json.dump({"_meta": {"scenes_per_gpu": S, "gang": G, "scenes_per_launch": S * G, "points": n, "horizon": cfg["horizon"], "K": cfg["K"], "streams": 1,
                      "units": "FETCH_SIZE / WRITE_SIZE in KiB (MI355X_MICROARCH.md, HBM section); x2 = gfx950 wide-read correction",
-                     "algorithmic_bytes_per_launch": {"kd_build_kernel (one launch: obstacle + edge index)": 28 * S * (n + ne)}},
+                     "algorithmic_bytes_per_launch": {"kd_build_kernel (one launch: obstacle + edge index of every frame of the gang)": 28 * S * G * (n + ne)}},
            "kernels": tj}, open(os.path.join(dst, "r03_pmc_traffic.json"), "w"), indent=1)
 open(os.path.join(dst, "r03_pmc_traffic.md"), "w").write(
-    "HBM traffic per launch, `bench.py --steps 8 --warmup 2 --streams 1` under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
-    "(separate passes; raw CSVs under gpurun_out/%s).\n\n" % tag + "\n".join(l for l in out.getvalue().splitlines()
+    "HBM traffic per launch (%d scenes = %d steps of %d), `bench.py --steps 8 --warmup 2 --streams 1` under rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE "
+    "(separate passes; raw CSVs under gpurun_out/%s).\n\n" % (S * G, G, S, tag) + "\n".join(l for l in out.getvalue().splitlines()
                                                                              if l.startswith("|") and ("launch" in l or "---" in l or any(t in l for t in ("mpc_", "kd_", "step_")))) + "\n")
 ca, na = counters(os.path.join(src, "pmc_sq_a", "a_counter_collection.csv"))
 cb, nb = counters(os.path.join(src, "pmc_sq_b", "b_counter_collection.csv"))
@@ -83,7 +88,7 @@ k = [x for x in ca if x.startswith("mpc_solve_kernel")][0]
 a, b = ca[k], cb[k]
 waves = b["SQ_WAVES"]
 issue = {
-    "kernel": k, "source": f"rocprofv3 --pmc (two passes of 8 SQ counters), bench.py --streams 1, gpurun_out/{tag}/pmc_sq_a|b; per-launch averages over {na[k]} launches",
+    "kernel": k, "source": f"rocprofv3 --pmc (two passes of 8 SQ counters), bench.py --streams 1 --gang 1, gpurun_out/{tag}/pmc_sq_a|b; per-launch averages over {na[k]} launches",
     "waves_per_launch": waves,
     "valu_instructions_per_wave_solve": b["SQ_INSTS_VALU"] / waves, "lds_instructions_per_wave_solve": b["SQ_INSTS_LDS"] / waves,
     "salu_instructions_per_wave_solve": b["SQ_INSTS_SALU"] / waves,
@@ -118,7 +123,7 @@ issue["bound"] = ("dependent-operation latency at limited occupancy: a wave alon
                       issue["wave_time_stretch_at_saturation"]))
 json.dump(issue, open(os.path.join(dst, "r03_pmc_solve_issue.json"), "w"), indent=1)
 with open(os.path.join(dst, "r03_pmc_solve_issue.md"), "w") as f:
-    f.write("What bounds `mpc_solve_kernel` (SQ counters, single stream: one wave per CU).\n\n| quantity | value |\n|---|---|\n")
+    f.write("What bounds `mpc_solve_kernel` (SQ counters, `bench.py --streams 1 --gang 1`: 256-scene launches, one wave per CU).\n\n| quantity | value |\n|---|---|\n")
     for kk, v in issue.items():
         f.write(f"| {kk} | {v if isinstance(v, str) else round(v, 4)} |\n")
     f.write("\nRaw per-launch counter averages:\n\n| counter | value |\n|---|---|\n")
