@@ -26,7 +26,8 @@ struct amk_pipeline {
     struct Staged {  // a frame of the open gang
         const float *cloud, *edge;
         const int *cloud_counts, *edge_counts;
-        const double *state_quad, *pos_x;   // read directly when gang == 1, copied at submit otherwise
+        const double *state_quad, *pos_x;   // read directly when gang == 1, gathered at launch otherwise
+        const double *ref_path_init;
         double *u_out;
         int keep_warm_start;
     };
@@ -49,6 +50,38 @@ struct amk_pipeline {
 };
 
 namespace {
+// The small inputs of the frames of a gang into the slot's contiguous buffers, and their fresh warm starts, in ONE launch
+// (as 3 copies + 1 memset per frame they were 16 tiny dispatches in front of every launch of a gang of 4, each of which
+// queued behind whatever the other slots were dispatching: 7 % of the summed kernel time with 10 launches in flight).
+struct GatherArgs {
+    const double *sq[AMK_PIPELINE_MAX_GANG], *px[AMK_PIPELINE_MAX_GANG], *ref[AMK_PIPELINE_MAX_GANG];
+    int keep_warm_start[AMK_PIPELINE_MAX_GANG];
+    double *sq_dst, *px_dst, *ref_dst, *w0;   // [G][n_*]; sq_dst / px_dst NULL: not copied (gang 1 reads the caller's)
+    int n_sq, n_px, n_ref, n_w0;              // doubles per frame
+};
+__global__ __launch_bounds__(256) void pipeline_gather_kernel(const GatherArgs a) {
+    const int g = blockIdx.y;
+    const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
+    if (a.sq_dst) {
+        for (int i = t0; i < a.n_sq; i += stride) a.sq_dst[(size_t)g * a.n_sq + i] = a.sq[g][i];
+        for (int i = t0; i < a.n_px; i += stride) a.px_dst[(size_t)g * a.n_px + i] = a.px[g][i];
+    }
+    for (int i = t0; i < a.n_ref; i += stride) a.ref_dst[(size_t)g * a.n_ref + i] = a.ref[g][i];
+    if (!a.keep_warm_start[g])
+        for (int i = t0; i < a.n_w0; i += stride) a.w0[(size_t)g * a.n_w0 + i] = 0.0;
+}
+// ... and the controls of every frame to where its caller wants them
+struct ScatterArgs {
+    double *dst[AMK_PIPELINE_MAX_GANG];   // NULL: stays in the slot's buffer only
+    const double *u;
+    int n_u;
+};
+__global__ __launch_bounds__(256) void pipeline_scatter_kernel(const ScatterArgs a) {
+    const int g = blockIdx.y;
+    if (!a.dst[g]) return;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_u; i += gridDim.x * 256) a.dst[g][i] = a.u[(size_t)g * a.n_u + i];
+}
+
 // Waits for a slot's launch.  hipEventSynchronize parks the thread on an HSA signal; with AMK_PIPELINE_SPIN=1 the thread polls
 // hipEventQuery instead (diagnostics: tools/experiments/rccl_presence.py).
 int wait_event(hipEvent_t ev) {
@@ -73,22 +106,25 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     const int G = p->gang, S = c.n_scenes, N = amk_mpc_horizon(s.mpc), mi = c.step.mpc_max_iter;
     const int filled = (int)s.open.size();
     hipStream_t st = s.stream;
-    for (int g = filled; g < G; ++g) {   // pad
-        AMK_HIP(hipMemcpyAsync(s.state_quad.p + (size_t)g * S * mi * 10, s.state_quad.p + (size_t)(filled - 1) * S * mi * 10,
-                               sizeof(double) * S * mi * 10, hipMemcpyDeviceToDevice, st));
-        AMK_HIP(hipMemcpyAsync(s.pos_x.p + (size_t)g * S, s.pos_x.p + (size_t)(filled - 1) * S, sizeof(double) * S,
-                               hipMemcpyDeviceToDevice, st));
-        AMK_HIP(hipMemcpyAsync(s.ref_path.p + (size_t)g * S * N * 10, s.ref_path.p + (size_t)(filled - 1) * S * N * 10,
-                               sizeof(double) * S * N * 10, hipMemcpyDeviceToDevice, st));
-    }
     const float *cl[AMK_PIPELINE_MAX_GANG], *ed[AMK_PIPELINE_MAX_GANG];
     const int *cc[AMK_PIPELINE_MAX_GANG], *ec[AMK_PIPELINE_MAX_GANG];
+    GatherArgs ga{};
     for (int g = 0; g < G; ++g) {
-        const amk_pipeline::Staged &f = s.open[g < filled ? g : filled - 1];
+        const amk_pipeline::Staged &f = s.open[g < filled ? g : filled - 1];   // (a missing frame: the last one again)
         cl[g] = f.cloud; ed[g] = f.edge; cc[g] = f.cloud_counts; ec[g] = f.edge_counts;
-        // fresh frame: zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
-        if (!f.keep_warm_start)
-            AMK_HIP(hipMemsetAsync(s.mpc->w0.p + (size_t)g * S * s.mpc->nx, 0, sizeof(double) * (size_t)S * s.mpc->nx, st));
+        ga.sq[g] = f.state_quad; ga.px[g] = f.pos_x; ga.ref[g] = f.ref_path_init;
+        // fresh frame: mRefPath after GetInitPath, zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
+        ga.keep_warm_start[g] = f.keep_warm_start;
+    }
+    ga.sq_dst = G > 1 ? s.state_quad.p : nullptr; ga.px_dst = G > 1 ? s.pos_x.p : nullptr;
+    ga.ref_dst = s.ref_path.p; ga.w0 = s.mpc->w0.p;
+    ga.n_sq = S * mi * 10; ga.n_px = S; ga.n_ref = S * N * 10; ga.n_w0 = S * s.mpc->nx;
+    {
+        const int longest = ga.n_w0 > ga.n_ref ? ga.n_w0 : ga.n_ref;
+        int bx = (longest + 1023) / 1024;
+        bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
+        hipLaunchKernelGGL(pipeline_gather_kernel, dim3(bx, G), dim3(256), 0, st, ga);
+        AMK_HIP(hipGetLastError());
     }
     int rc;
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
@@ -99,10 +135,16 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     const double *sq = G == 1 ? s.open[0].state_quad : s.state_quad.p, *px = G == 1 ? s.open[0].pos_x : s.pos_x.p;
     if ((rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st)) != AMK_OK)
         return rc;
-    if (G > 1)
-        for (int g = 0; g < filled; ++g)
-            if (s.open[g].u_out)
-                AMK_HIP(hipMemcpyAsync(s.open[g].u_out, s.u.p + (size_t)g * S * 4, sizeof(double) * S * 4, hipMemcpyDeviceToDevice, st));
+    if (G > 1) {
+        ScatterArgs sa{};
+        bool any = false;
+        for (int g = 0; g < filled; ++g) { sa.dst[g] = s.open[g].u_out; any = any || sa.dst[g]; }
+        sa.u = s.u.p; sa.n_u = S * 4;
+        if (any) {
+            hipLaunchKernelGGL(pipeline_scatter_kernel, dim3((sa.n_u + 255) / 256 > 16 ? 16 : (sa.n_u + 255) / 256, G), dim3(256), 0, st, sa);
+            AMK_HIP(hipGetLastError());
+        }
+    }
     AMK_HIP(hipEventRecord(s.done[s.count % p->depth], st));
     ++s.count;
     s.open.clear();
@@ -196,9 +238,6 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
         return AMK_ERR_INVALID_ARG;
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
-    const amk_pipeline_config &c = p->cfg;
-    const int N = amk_mpc_horizon(s.mpc), mi = c.step.mpc_max_iter;
-    const size_t S = c.n_scenes;
     const int stride = f->point_stride ? f->point_stride : 3;
     if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
     // Flow control.  A slot's launches are ordered by its stream, so queuing the next one behind a running one is safe (same
@@ -212,17 +251,9 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     }
     const int g = (int)s.open.size();
     s.point_stride = stride;
-    // the frame's small inputs go into the gang's contiguous buffers (stream-ordered: behind the slot's previous launch):
-    // mRefPath after GetInitPath, which the step refills, and -- with a gang -- mVecStateQuad and mPos.x
-    if (p->gang > 1) {
-        AMK_HIP(hipMemcpyAsync(s.state_quad.p + (size_t)g * S * mi * 10, f->d_state_quad, sizeof(double) * S * mi * 10,
-                               hipMemcpyDeviceToDevice, s.stream));
-        AMK_HIP(hipMemcpyAsync(s.pos_x.p + (size_t)g * S, f->d_pos_x, sizeof(double) * S, hipMemcpyDeviceToDevice, s.stream));
-    }
-    AMK_HIP(hipMemcpyAsync(s.ref_path.p + (size_t)g * S * N * 10, f->d_ref_path_init, sizeof(double) * S * N * 10,
-                           hipMemcpyDeviceToDevice, s.stream));
+    // staged: the frame's inputs are read when its gang is launched (they stay the caller's until then)
     s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
-                                           f->d_u_out, f->keep_warm_start});
+                                           f->d_ref_path_init, f->d_u_out, f->keep_warm_start});
     if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
     if ((int)s.open.size() == p->gang) {
