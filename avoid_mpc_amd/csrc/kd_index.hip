@@ -737,7 +737,7 @@ int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes
                   const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
                   hipStream_t stream) {
     if (!obstacle || !edge || n_frames < 1 || n_frames > AMK_PIPELINE_MAX_GANG || point_stride < 3 ||
-        obstacle->n_scenes != n_frames * frame_scenes || edge->n_scenes != obstacle->n_scenes)
+        obstacle->n_scenes < n_frames * frame_scenes || edge->n_scenes != obstacle->n_scenes)
         return AMK_ERR_INVALID_ARG;
     {
         amk::TimedLaunch tg(amk::KC_GRID, stream);

@@ -7,6 +7,8 @@
 struct amk_mpc {
     double T = 0, dt = 0;
     int N = 0, K = 0, S = 0, nx = 0, nref = 0;
+    int run_scenes = 0;       // internal (amk_pipeline, a gang that is not full): launches cover scenes [0, run_scenes); 0 = all S
+    int launch_scenes() const { return run_scenes > 0 && run_scenes < S ? run_scenes : S; }
     double h_prm[amk::PRM_LEN];
     amk::SolveOpts opt;
     size_t lds_bytes = 0;     // fp64 scratchpad; the fp32 kernels take half

@@ -304,7 +304,7 @@ int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_
                  double *d_ref_path, int *d_step_flags, hipStream_t stream) {
     TimedLaunch tl(KC_SOLVE, stream);
 #define AMK_LAUNCH_SOLVE(KERNEL, NT, LDS)                                                                            \
-    hipLaunchKernelGGL(KERNEL<NT>, dim3(m->S), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
+    hipLaunchKernelGGL(KERNEL<NT>, dim3(m->launch_scenes()), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
                        d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, d_step_flags,         \
                        m->plan_coef.p, m->plan_meta.p, m->ybuf.p, m->gains.p)
     if (m->precision == 32) {  // fp32 arithmetic, half the scratchpad

@@ -98,8 +98,7 @@ int wait_event(hipEvent_t ev) {
 }
 
 // Launches the slot's open gang: both index builds of every staged frame in one launch, one control step over all of them.
-// A gang that is not full (wait / drain before the G-th submit) runs its missing frames as copies of the last staged one:
-// their scenes are computed and ignored (a one-off at the end of a sweep; the handles' kernels always cover G S scenes).
+// A gang that is not full (wait / drain before the G-th submit) runs on the leading scenes of the slot's handles only.
 int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     if (s.open.empty()) return AMK_OK;
     const amk_pipeline_config &c = p->cfg;
@@ -109,8 +108,8 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     const float *cl[AMK_PIPELINE_MAX_GANG], *ed[AMK_PIPELINE_MAX_GANG];
     const int *cc[AMK_PIPELINE_MAX_GANG], *ec[AMK_PIPELINE_MAX_GANG];
     GatherArgs ga{};
-    for (int g = 0; g < G; ++g) {
-        const amk_pipeline::Staged &f = s.open[g < filled ? g : filled - 1];   // (a missing frame: the last one again)
+    for (int g = 0; g < filled; ++g) {
+        const amk_pipeline::Staged &f = s.open[g];
         cl[g] = f.cloud; ed[g] = f.edge; cc[g] = f.cloud_counts; ec[g] = f.edge_counts;
         ga.sq[g] = f.state_quad; ga.px[g] = f.pos_x; ga.ref[g] = f.ref_path_init;
         // fresh frame: mRefPath after GetInitPath, zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
@@ -123,25 +122,27 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         const int longest = ga.n_w0 > ga.n_ref ? ga.n_w0 : ga.n_ref;
         int bx = (longest + 1023) / 1024;
         bx = bx < 1 ? 1 : (bx > 64 ? 64 : bx);
-        hipLaunchKernelGGL(pipeline_gather_kernel, dim3(bx, G), dim3(256), 0, st, ga);
+        hipLaunchKernelGGL(pipeline_gather_kernel, dim3(bx, filled), dim3(256), 0, st, ga);
         AMK_HIP(hipGetLastError());
     }
     int rc;
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
     if (G == 1) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
-    else rc = amk::kd_build_gang(s.obstacle, s.edge, G, S, cl, cc, ed, ec, s.point_stride, st);
+    else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st);
     if (rc != AMK_OK) return rc;
     double *u = (G == 1 && s.open[0].u_out) ? s.open[0].u_out : s.u.p;
     const double *sq = G == 1 ? s.open[0].state_quad : s.state_quad.p, *px = G == 1 ? s.open[0].pos_x : s.pos_x.p;
-    if ((rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st)) != AMK_OK)
-        return rc;
+    s.mpc->run_scenes = filled * S;
+    rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
+    s.mpc->run_scenes = 0;
+    if (rc != AMK_OK) return rc;
     if (G > 1) {
         ScatterArgs sa{};
         bool any = false;
         for (int g = 0; g < filled; ++g) { sa.dst[g] = s.open[g].u_out; any = any || sa.dst[g]; }
         sa.u = s.u.p; sa.n_u = S * 4;
         if (any) {
-            hipLaunchKernelGGL(pipeline_scatter_kernel, dim3((sa.n_u + 255) / 256 > 16 ? 16 : (sa.n_u + 255) / 256, G), dim3(256), 0, st, sa);
+            hipLaunchKernelGGL(pipeline_scatter_kernel, dim3((sa.n_u + 255) / 256 > 16 ? 16 : (sa.n_u + 255) / 256, filled), dim3(256), 0, st, sa);
             AMK_HIP(hipGetLastError());
         }
     }
@@ -256,7 +257,8 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
                                            f->d_ref_path_init, f->d_u_out, f->keep_warm_start});
     if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
-    if ((int)s.open.size() == p->gang) {
+    const bool launch = (int)s.open.size() == p->gang;
+    if (launch) {
         const int st = launch_gang(p, s);
         if (st != AMK_OK) return st;
         p->next = (si + 1) % ns;

@@ -342,15 +342,17 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     if (obstacle->n_scenes != mpc->S || edge->n_scenes != mpc->S) return AMK_ERR_INVALID_ARG;
     if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
-    const int S = mpc->S, N = mpc->N, K = mpc->K;
+    const int N = mpc->N, K = mpc->K;
     if (!mpc->done.p) {
-        AMK_HIP(mpc->knn_pts.alloc((size_t)S * N * K * 3));
-        AMK_HIP(mpc->knn_d2.alloc((size_t)S * N * K));
-        AMK_HIP(mpc->edge_pt.alloc((size_t)S * 3));
-        AMK_HIP(mpc->edge_d2.alloc(S));
-        AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
-        AMK_HIP(mpc->done.alloc(S));
+        const size_t Sa = mpc->S;
+        AMK_HIP(mpc->knn_pts.alloc(Sa * N * K * 3));
+        AMK_HIP(mpc->knn_d2.alloc(Sa * N * K));
+        AMK_HIP(mpc->edge_pt.alloc(Sa * 3));
+        AMK_HIP(mpc->edge_d2.alloc(Sa));
+        AMK_HIP(mpc->ref_states.alloc(Sa * mpc->nref));
+        AMK_HIP(mpc->done.alloc(Sa));
     }
+    const int S = mpc->launch_scenes();   // (amk_pipeline: a gang that is not full runs its leading scenes only)
     { TimedLaunch tl(KC_BEGIN, stream);
     hipLaunchKernelGGL(step_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u); }
     int qpw, groups, wpb;
