@@ -88,13 +88,13 @@ struct amk_kd {
     amk::DevBuf<float> x, y, z;  // [S][cap] filtered points (order preserved), NaN padded -- made ON DEMAND from the
                                  // bucket records (ensure_soa, kd_index.hip): the build does not write them
     int soa_valid = 0;           // host flag: x/y/z match the current index
-    amk::DevBuf<int> grp;        // [S][cap/64 + 2] kept points before every 64-point group of the caller's cloud
     amk::DevBuf<int> size;       // [S] cloud.pts.size() after the NaN-x filter
     amk::DevBuf<float> pmax;     // [S] max |coordinate| of the kept points (bounds the fp32 pre-filter error)
     // bucketed index (kd_grid.h): bucket-contiguous copy of the points, their cloud indices, bucket starts
     amk::DevBuf<float4> gpt;         // [S][cap]  (x, y, z, cloud index)
     amk::DevBuf<float> bbox;         // [S][6]    min xyz, max xyz of the finite points
-    amk::DevBuf<int> cell_start;     // [S][kGridMaxCells + 2]
+    amk::DevBuf<int> cell_start;     // [S][ntiles][kGridMaxCells + 2]  bucket starts of every tile of the record array (kd_grid.h)
+    int ntiles = 1;                  // ceil(max_points / kTilePoints)
     amk::DevBuf<double> gparams;     // [S][8]
     int mode = 0;                    // 0: grid search (default), 1: streaming scan (cross-check)
     // opt-in "nanoflann tie order" (amk_kd_set_tie_order, kd_exact.h): the reference's own tree, built beside the bucketed index

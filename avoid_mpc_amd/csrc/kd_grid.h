@@ -59,164 +59,86 @@ __device__ __forceinline__ int cell_of(double p, double bbmin, double inv_h, int
     return (int)c;
 }
 
-// Where the build reads its points.  SoaSrc: the compacted planes (the keyframe sweep rebuilds from them).
-// RawSrc: the caller's AoS cloud, straight (amk_kd_build): the NaN-x filter of KDTreeTwo::InitializeNew
-// (kd_tree_two.h:96-101) is applied on the fly and a kept point's cloud index is the number of kept points before it
-// = base of its 64-point group (a small table made by the pre-pass) + kept lanes below it in the wave.  No
-// index-ordered copy of the cloud is written: that copy cost a third of the build (197 vs 294 us in flight).
-struct SoaSrc {
-    static constexpr bool kFilter = false;
-    const float *xs, *ys, *zs;
-    int *grp = nullptr;
-    int *size_out = nullptr;
-    float *pmax_out = nullptr;
-    __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const { x = xs[i]; y = ys[i]; z = zs[i]; }
-    __device__ __forceinline__ int group_base(int) const { return 0; }
-};
-struct RawSrc {
-    static constexpr bool kFilter = true;
-    const float *p;
-    int stride;
-    int *grp;        // kept points per 64-point group (histogram pass), then before group g (exclusive prefix)
-    int *size_out;   // [1] number of kept points
-    float *pmax_out; // [1] max |coordinate| of the kept points
-    __device__ __forceinline__ void load(int i, float &x, float &y, float &z) const {
-        const float *q = p + (size_t)i * stride;
-#ifdef AMK_BUILD_NT_LOADS  // experiments: streaming hint on the cloud reads (do they evict the solves' L2-resident scratch?)
-        x = __builtin_nontemporal_load(q); y = __builtin_nontemporal_load(q + 1); z = __builtin_nontemporal_load(q + 2);
-#else
-        x = q[0]; y = q[1]; z = q[2];
-#endif
+// Grid geometry of a scene: ~kGridPointsPerCell points per cell, <= kGridMaxCells cells, cubic cells of edge h; one thread.
+// bbox need not contain every point (amk_kd_build passes the box of a sample): a point outside is clamped into a boundary
+// cell, which every rule of the search tolerates (boundary faces are never used as bounds).
+__device__ __forceinline__ void grid_geometry(const float *bbox6, int npoints, double *geo, double *gp) {
+    double lo[3], hi[3], ext[3], emax = 0.0;
+    for (int a = 0; a < 3; ++a) {
+        float m0 = bbox6[a], m1 = bbox6[3 + a];
+        if (!(m1 >= m0)) { m0 = 0.f; m1 = 0.f; }  // no finite point at all
+        lo[a] = m0; hi[a] = m1;
+        ext[a] = (double)m1 - (double)m0;
+        emax = fmax(emax, ext[a]);
     }
-    __device__ __forceinline__ int group_base(int g) const { return grp[g]; }
-};
+    const double efloor = fmax(emax * 1e-6, 1e-30);
+    double vol = 1.0;
+    for (int a = 0; a < 3; ++a) vol *= fmax(ext[a], efloor);
+    double target = fmin(fmax((double)npoints / (double)kGridPointsPerCell, 1.0), (double)kGridMaxCells);
+    double h = cbrt(vol / target);
+    if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
+    int g[3];
+    for (int it = 0; it < 64; ++it) {
+        long long prod = 1;
+        for (int a = 0; a < 3; ++a) {
+            double c = ceil(fmax(ext[a], efloor) / h);
+            g[a] = (int)fmin(fmax(c, 1.0), 1024.0);
+            prod *= g[a];
+        }
+        if (prod <= kGridMaxCells) break;
+        h *= 1.26;
+    }
+    if ((long long)g[0] * g[1] * g[2] > kGridMaxCells) { g[0] = g[1] = g[2] = 1; }
+    geo[0] = lo[0]; geo[1] = lo[1]; geo[2] = lo[2];
+    geo[3] = h; geo[4] = 1.0 / h;
+    geo[5] = g[0]; geo[6] = g[1]; geo[7] = g[2];
+    for (int a = 0; a < kGridParamDoubles; ++a) gp[a] = geo[a];
+}
 
-// the index of scene s; called by every thread of a kGridBuildThreads block.  nvis points are visited; for a filtering
-// source the number kept (n) is found by the histogram pass, which also leaves the group table, size and pmax.
-// bbox need not contain every point (amk_kd_build passes the box of a strided sample): a point outside is clamped
-// into a boundary cell, which every rule of the search tolerates (boundary faces are never used as bounds).
-template <class Src>
-__device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, int nvis, int n,
-                                                 const float *__restrict__ bbox, float4 *__restrict__ GP,
-                                                 int *__restrict__ cell_start, double *__restrict__ gparams) {
+// The index of scene s from the compacted SoA planes (the keyframe sweep rebuilds from them after its in-place
+// compaction; amk_kd_build itself uses grid_build_tiles_scene below): a two-pass counting sort -- histogram, exclusive
+// scan, scatter -- that writes ONE tile (tile 0 holds every point, the other tiles of the handle are left empty).  Called
+// by every thread of a kGridBuildThreads block.
+__device__ __forceinline__ void grid_build_scene(int s, const float *__restrict__ xs, const float *__restrict__ ys,
+                                                 const float *__restrict__ zs, int cap, int n, const float *__restrict__ bbox,
+                                                 float4 *__restrict__ GP, int *__restrict__ cell_start, int ntiles,
+                                                 double *__restrict__ gparams) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float4 *gpt4 = GP + (size_t)s * cap;  // bucket-contiguous points: (x, y, z, cloud index as int bits)
-    int *cs = cell_start + (size_t)s * (kGridMaxCells + 2);
+    int *cs = cell_start + (size_t)s * ntiles * (kGridMaxCells + 2);
     double *gp = gparams + (size_t)s * kGridParamDoubles;
 
     __shared__ int hist[kGridMaxCells + 2];
     __shared__ int wsum[kGridBuildThreads / 64];
-    __shared__ float wmax[kGridBuildThreads / 64];
     __shared__ double geo[kGridParamDoubles];
 
-    // 1. bounding box of the finite points: reduced by the compaction kernel (bbox[s][6] = min xyz, max xyz)
+    // 1. bounding box of the finite points: reduced by the caller (bbox[s][6] = min xyz, max xyz)
     // 2. grid geometry: ~kGridPointsPerCell points per cell, <= kGridMaxCells cells, cubic cells of edge h
-    if (tid == 0) {
-        double lo[3], hi[3], ext[3], emax = 0.0;
-        for (int a = 0; a < 3; ++a) {
-            float m0 = bbox[6 * s + a], m1 = bbox[6 * s + 3 + a];
-            if (!(m1 >= m0)) { m0 = 0.f; m1 = 0.f; }  // no finite point at all
-            lo[a] = m0; hi[a] = m1;
-            ext[a] = (double)m1 - (double)m0;
-            emax = fmax(emax, ext[a]);
-        }
-        const double efloor = fmax(emax * 1e-6, 1e-30);
-        double vol = 1.0;
-        for (int a = 0; a < 3; ++a) vol *= fmax(ext[a], efloor);
-        double target = fmin(fmax((double)(Src::kFilter ? nvis : n) / (double)kGridPointsPerCell, 1.0), (double)kGridMaxCells);
-        double h = cbrt(vol / target);
-        if (!(h > 0.0) || !(h < 1e300)) h = 1.0;
-        int g[3];
-        for (int it = 0; it < 64; ++it) {
-            long long prod = 1;
-            for (int a = 0; a < 3; ++a) {
-                double c = ceil(fmax(ext[a], efloor) / h);
-                g[a] = (int)fmin(fmax(c, 1.0), 1024.0);
-                prod *= g[a];
-            }
-            if (prod <= kGridMaxCells) break;
-            h *= 1.26;
-        }
-        if ((long long)g[0] * g[1] * g[2] > kGridMaxCells) { g[0] = g[1] = g[2] = 1; }
-        geo[0] = lo[0]; geo[1] = lo[1]; geo[2] = lo[2];
-        geo[3] = h; geo[4] = 1.0 / h;
-        geo[5] = g[0]; geo[6] = g[1]; geo[7] = g[2];
-        for (int a = 0; a < kGridParamDoubles; ++a) gp[a] = geo[a];
-    }
+    if (tid == 0) grid_geometry(bbox + 6 * s, n, geo, gp);
     __syncthreads();
     const double b0 = geo[0], b1 = geo[1], b2 = geo[2], inv_h = geo[4];
     const int g0 = (int)geo[5], g1 = (int)geo[6], g2 = (int)geo[7];
     const int ncell = g0 * g1 * g2;  // + one trash bucket (index ncell) for non-finite points
     for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) hist[i] = 0;
     __syncthreads();
-    // 3. histogram.  Both point passes load kGridUnroll points per thread before touching them: with one
-    // 1024-thread block per CU the loop is bound by load latency, not bandwidth, unless several loads are in flight.
     auto cell_id = [&](float x, float y, float z) {
         return finite3(x, y, z)
                    ? (cell_of(z, b2, inv_h, g2) * g1 + cell_of(y, b1, inv_h, g1)) * g0 + cell_of(x, b0, inv_h, g0)
                    : ncell;
     };
-    float amax = 0.f;  // max |coordinate| over the kept points (fmaxf drops NaNs)
-    for (int i0 = tid; i0 < nvis; i0 += kGridUnroll * kGridBuildThreads) {
+    // 3. histogram.  Both point passes load kGridUnroll points per thread before touching them: the loop is bound by
+    // load latency, not bandwidth, unless several loads are in flight.
+    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
         float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            src.load(i < nvis ? i : i0, x[j], y[j], z[j]);
+            const int ii = i < n ? i : i0;
+            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
         }
 #pragma unroll
-        for (int j = 0; j < kGridUnroll; ++j) {
-            const int i = i0 + j * kGridBuildThreads;
-            const bool keep = i < nvis && (!Src::kFilter || !(x[j] != x[j]));
-            if (Src::kFilter) {
-                const unsigned long long m = __ballot(keep);
-                if (lane == 0 && i < nvis) src.grp[i >> 6] = __popcll(m);  // lane 0 holds the wave's smallest i
-                if (keep) amax = fmaxf(amax, fmaxf(fabsf(x[j]), fmaxf(fabsf(y[j]), fabsf(z[j]))));
-            }
-            if (keep) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
-        }
-    }
-    if (Src::kFilter) {  // group bases (exclusive prefix, in place), number kept, max |coordinate|
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
-        if (lane == 0) wmax[w] = amax;
-        __threadfence_block();
-        __syncthreads();  // the group counts are this block's own stores
-        const int ng = (nvis + 63) / 64;
-        const int per = (ng + kGridBuildThreads - 1) / kGridBuildThreads;
-        const int g0b = tid * per;
-        int loc = 0;
-        for (int j = 0; j < per; ++j)
-            if (g0b + j < ng) loc += src.grp[g0b + j];
-        int incl = loc;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int v = __shfl_up(incl, off);
-            if (lane >= off) incl += v;
-        }
-        if (lane == 63) wsum[w] = incl;
-        __syncthreads();
-        int wbase = 0, total = 0;
-        for (int j = 0; j < kGridBuildThreads / 64; ++j) {
-            const int t = wsum[j];
-            wbase += j < w ? t : 0;
-            total += t;
-        }
-        int run = wbase + incl - loc;
-        for (int j = 0; j < per; ++j)
-            if (g0b + j < ng) {
-                const int c = src.grp[g0b + j];
-                src.grp[g0b + j] = run;
-                run += c;
-            }
-        n = total;
-        if (tid == 0) {
-            float mx = 0.f;
-            for (int j = 0; j < kGridBuildThreads / 64; ++j) mx = fmaxf(mx, wmax[j]);
-            *src.size_out = total;
-            *src.pmax_out = mx;
-        }
-        __threadfence_block();
+        for (int j = 0; j < kGridUnroll; ++j)
+            if (i0 + j * kGridBuildThreads < n) atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
     }
     __syncthreads();
     // 4. exclusive scan of hist[0 .. ncell] -> bucket starts (global) and scatter cursors (LDS)
@@ -246,52 +168,196 @@ __device__ __forceinline__ void grid_build_scene(int s, const Src src, int cap, 
             }
         if (tid == 0) cs[ncell + 1] = n;
     }
+    for (int tt = 1; tt < ntiles; ++tt)   // the handle's other tiles: empty runs behind the records
+        for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) cs[(size_t)tt * (kGridMaxCells + 2) + i] = n;
     __syncthreads();
     // 5. scatter into bucket-contiguous order (order inside a bucket is irrelevant: results are ordered by
     // (distance, original index))
-    for (int i0 = tid; i0 < nvis; i0 += kGridUnroll * kGridBuildThreads) {
+    for (int i0 = tid; i0 < n; i0 += kGridUnroll * kGridBuildThreads) {
         float x[kGridUnroll], y[kGridUnroll], z[kGridUnroll];
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            src.load(i < nvis ? i : i0, x[j], y[j], z[j]);
+            const int ii = i < n ? i : i0;
+            x[j] = xs[ii]; y[j] = ys[ii]; z[j] = zs[ii];
         }
 #pragma unroll
         for (int j = 0; j < kGridUnroll; ++j) {
             const int i = i0 + j * kGridBuildThreads;
-            const bool keep = i < nvis && (!Src::kFilter || !(x[j] != x[j]));
-            int idx = i;
-            if (Src::kFilter) {  // cloud index = kept points before this one (i >> 6 is the same for the whole wave)
-                const unsigned long long m = __ballot(keep);
-                idx = src.group_base((i < nvis ? i : i0) >> 6) + __popcll(m & ((1ull << lane) - 1ull));
-            }
-            if (keep) {
-#if defined(AMK_BUILD_DIAG) && AMK_BUILD_DIAG == 1   // experiments: everything but the record store
+            if (i < n) {
                 const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
-                if (pos == 0x7fffffff) gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
-#elif defined(AMK_BUILD_DIAG) && AMK_BUILD_DIAG == 2  // experiments: records stored in input order (coalesced)
-                const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
-                gpt4[pos >= 0 ? i : 0] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
-#else
-                const int pos = atomicAdd(&hist[cell_id(x[j], y[j], z[j])], 1);
-#ifdef AMK_BUILD_NT_STORES
-                __builtin_nontemporal_store(make_float4(x[j], y[j], z[j], __int_as_float(idx)), &gpt4[pos]);
-#else
-                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));  // one 16-byte store per point
-#endif
-#endif
+                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(i));  // one 16-byte store per point
             }
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// one-pass build: tile-major records
+// ------------------------------------------------------------------------------------------------
+// The two-pass counting sort above reads the cloud twice and scatters every record over the scene's whole 800 KB region
+// (measured: 1.64 x the algorithmic bytes, 0.29 of the HBM peak).  Here the cloud is cut into TILES of kTilePoints
+// consecutive points; a tile is loaded ONCE into registers, counted and ranked in LDS, and its records are written into
+// the tile's own window of the record array (bucket-contiguous inside the window, windows packed one after the other) --
+// 128 KB that stay in L2 until every line is full.  The index becomes a list of tiles, each with its own table of bucket
+// starts: cell c of the scene = one run of records per tile, [cs[t][c], cs[t][c + 1]) for t < ntiles; the searches
+// enumerate (row, tile) pairs where they enumerated rows.  Tiles beyond the cloud's last one hold empty runs.
+constexpr int kTileP = 10;                                     // points per thread and tile (in registers from load to store)
+constexpr int kTilePoints = kGridBuildThreads * kTileP;        // 8192
+__host__ __device__ constexpr int grid_tiles(int max_points) { return max_points <= 0 ? 1 : (max_points + kTilePoints - 1) / kTilePoints; }
+
+__device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__restrict__ src, int stride, int cap, int nvis,
+                                                       const float *__restrict__ bbox, float4 *__restrict__ GP,
+                                                       int *__restrict__ cell_start, int ntiles, double *__restrict__ gparams,
+                                                       int *__restrict__ size_out, float *__restrict__ pmax_out) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NW = kGridBuildThreads / 64;
+    float4 *gpt4 = GP + (size_t)s * cap;
+    int *cs_all = cell_start + (size_t)s * ntiles * (kGridMaxCells + 2);
+    double *gp = gparams + (size_t)s * kGridParamDoubles;
+    __shared__ int hist[kGridMaxCells + 2];
+    __shared__ int wsum[NW];
+    __shared__ int wcnt[kTileP * NW + 1];   // kept points per (round j, wave), then before it; [kTileP * NW] = kept in the tile
+    __shared__ float wmax[NW];
+    __shared__ double geo[kGridParamDoubles];
+    if (tid == 0) grid_geometry(bbox + 6 * s, nvis, geo, gp);
+    __syncthreads();
+    const double b0 = geo[0], b1 = geo[1], b2 = geo[2], inv_h = geo[4];
+    const int g0 = (int)geo[5], g1 = (int)geo[6], g2 = (int)geo[7];
+    const int ncell = g0 * g1 * g2;  // + one trash bucket (index ncell) for non-finite points
+    float amax = 0.f;                // max |coordinate| over the kept points (fmaxf drops NaNs)
+    int kept_before = 0;             // kept points of the tiles before this one = first record of this tile's window
+    int t = 0;
+    for (int i0 = 0; i0 < nvis; i0 += kTilePoints, ++t) {
+        int *cs = cs_all + (size_t)t * (kGridMaxCells + 2);
+        float x[kTileP], y[kTileP], z[kTileP];
+        // point i0 + j * threads + tid: consecutive lanes read consecutive points, through ONE per-lane offset and a
+        // wave-uniform base per round (scalar registers) instead of kTileP address pairs; the round that straddles the end of
+        // the cloud clamps its index, rounds behind it load nothing (NaN x = not kept)
+        // (one wave-uniform base per round + a 32-bit lane offset would save the address pairs, but the rounds then sit in
+        // uniform branches and their loads no longer overlap: 172 us against 115 for the build alone)
+#pragma unroll
+        for (int j = 0; j < kTileP; ++j) {
+            const int i = i0 + j * kGridBuildThreads + tid;
+            const float *q = src + (size_t)(i < nvis ? i : i0) * stride;
+            x[j] = q[0]; y[j] = q[1]; z[j] = q[2];
+        }
+        for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) hist[i] = 0;
+        unsigned cell2[kTileP / 2];   // the points' cells, two 16-bit ids per register (<= 1025)
+        unsigned keepbits = 0;
+#pragma unroll
+        for (int j = 0; j < kTileP; ++j) {
+            const int i = i0 + j * kGridBuildThreads + tid;
+            const bool keep = i < nvis && !(x[j] != x[j]);   // the NaN-x filter of KDTreeTwo::InitializeNew (kd_tree_two.h:96-101)
+            const unsigned long long m = __ballot(keep);
+            if (lane == 0) wcnt[j * NW + w] = __popcll(m);
+            keepbits |= keep ? 1u << j : 0u;
+            if (keep) amax = fmaxf(amax, fmaxf(fabsf(x[j]), fmaxf(fabsf(y[j]), fabsf(z[j]))));
+            unsigned c = finite3(x[j], y[j], z[j])
+                             ? (cell_of(z[j], b2, inv_h, g2) * g1 + cell_of(y[j], b1, inv_h, g1)) * g0 + cell_of(x[j], b0, inv_h, g0)
+                             : ncell;
+            asm volatile("" : "+v"(c));   // one point's fp64 temporaries at a time: the tile's point registers leave no room for more
+            cell2[j / 2] = (j & 1) ? (cell2[j / 2] | c << 16) : c;
+        }
+        __syncthreads();
+        // count per cell; meanwhile wave 0 turns the per-(round, wave) counts into "kept before" (the cloud index of a kept
+        // point = kept points before it in the caller's order = kept_before + before its (round, wave) + kept lanes below it)
+#pragma unroll
+        for (int j = 0; j < kTileP; ++j)
+            if (keepbits >> j & 1) atomicAdd(&hist[cell2[j / 2] >> (16 * (j & 1)) & 0xffffu], 1);
+        if (w == 0) {
+            constexpr int PER = (kTileP * NW + 63) / 64;
+            int loc[PER], sum = 0;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int k = lane * PER + e;
+                loc[e] = k < kTileP * NW ? wcnt[k] : 0;
+                sum += loc[e];
+            }
+            int incl = sum;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            int run = incl - sum;
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int k = lane * PER + e;
+                if (k < kTileP * NW) wcnt[k] = run;
+                run += loc[e];
+            }
+            if (lane == 63) wcnt[kTileP * NW] = incl;
+        }
+        __syncthreads();
+        // exclusive scan of hist[0 .. ncell]: bucket starts of this tile (global table) and scatter cursors (LDS)
+        const int kept_tile = wcnt[kTileP * NW];
+        {
+            const int per = (ncell + 1 + kGridBuildThreads - 1) / kGridBuildThreads;
+            const int c0 = tid * per;
+            int loc = 0;
+            for (int j = 0; j < per; ++j)
+                if (c0 + j <= ncell) loc += hist[c0 + j];
+            int incl = loc;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int v = __shfl_up(incl, off);
+                if (lane >= off) incl += v;
+            }
+            if (lane == 63) wsum[w] = incl;
+            __syncthreads();
+            int wbase = 0;
+            for (int j = 0; j < w; ++j) wbase += wsum[j];
+            int run = kept_before + wbase + incl - loc;
+            for (int j = 0; j < per; ++j)
+                if (c0 + j <= ncell) {
+                    const int c = hist[c0 + j];
+                    hist[c0 + j] = run;
+                    cs[c0 + j] = run;
+                    run += c;
+                }
+            if (tid == 0) cs[ncell + 1] = kept_before + kept_tile;
+        }
+        __syncthreads();
+        // records into the tile's window (order inside a bucket is irrelevant: results are ordered by (distance, index))
+#pragma unroll
+        for (int j = 0; j < kTileP; ++j) {
+            const bool keep = keepbits >> j & 1;
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                const int idx = kept_before + wcnt[j * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
+                const int pos = atomicAdd(&hist[cell2[j / 2] >> (16 * (j & 1)) & 0xffffu], 1);
+                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
+            }
+            asm volatile("" ::: "memory");   // one record's register quadruple at a time
+        }
+        kept_before += kept_tile;
+        __syncthreads();   // hist / wcnt are rewritten by the next tile
+    }
+    // tiles the cloud does not reach: empty runs
+    for (int tt = t; tt < ntiles; ++tt) {
+        int *cs = cs_all + (size_t)tt * (kGridMaxCells + 2);
+        for (int i = tid; i <= ncell + 1; i += kGridBuildThreads) cs[i] = kept_before;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) amax = fmaxf(amax, __shfl_xor(amax, off));
+    if (lane == 0) wmax[w] = amax;
+    __syncthreads();
+    if (tid == 0) {
+        float mx = 0.f;
+        for (int j = 0; j < NW; ++j) mx = fmaxf(mx, wmax[j]);
+        *size_out = kept_before;
+        *pmax_out = mx;
     }
 }
 
 static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
     const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP,
-    int *__restrict__ cell_start, double *__restrict__ gparams) {
-    const int s = blockIdx.x, n = sizes[s];
-    const SoaSrc src{X + (size_t)s * cap, Y + (size_t)s * cap, Z + (size_t)s * cap};
-    grid_build_scene(s, src, cap, n, n, bbox, GP, cell_start, gparams);
+    int *__restrict__ cell_start, int ntiles, double *__restrict__ gparams) {
+    const int s = blockIdx.x;
+    grid_build_scene(s, X + (size_t)s * cap, Y + (size_t)s * cap, Z + (size_t)s * cap, cap, sizes[s], bbox, GP, cell_start, ntiles,
+                     gparams);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -299,8 +365,9 @@ static __global__ __launch_bounds__(kGridBuildThreads) void kd_grid_build_kernel
 // ------------------------------------------------------------------------------------------------
 struct GridScene {
     const float4 *pt;           // bucket-contiguous points (x, y, z, index in the NaN-x-filtered cloud)
-    const int *cs;              // bucket starts, [ncell + 2]
+    const int *cs;              // bucket starts of every tile, [nt][kGridMaxCells + 2] (entries [0, ncell + 1] used)
     const double *gp;           // geometry
+    int nt;                     // tiles: cell c = the runs [cs[t][c], cs[t][c + 1]) for t < nt
 };
 
 struct GridPtrs {  // the batch: what a kernel needs to find scene s
@@ -308,11 +375,13 @@ struct GridPtrs {  // the batch: what a kernel needs to find scene s
     const int *cs;
     const double *gp;
     int cap;
+    int nt;
     __device__ __forceinline__ GridScene scene(int s) const {
         GridScene g;
         g.pt = pt + (size_t)s * cap;
-        g.cs = cs + (size_t)s * (kGridMaxCells + 2);
+        g.cs = cs + (size_t)s * nt * (kGridMaxCells + 2);
         g.gp = gp + (size_t)s * kGridParamDoubles;
+        g.nt = nt;
         return g;
     }
 };
@@ -368,13 +437,15 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
     int rp = -1;  // everything within Chebyshev radius rp of the query's cell has been seen
     for (int r = 0;; ) {
-        const int side = 2 * r + 1, nrows = side * side;
-        for (int row0 = 0; row0 < nrows; row0 += 64) {
-            // lane -> one (iy, iz) row of the shell (rp, r]: the whole run of cells x in [cx - r, cx + r] if the
-            // row lies outside the box already seen, else the two end runs left and right of that box
-            const int j = row0 + lane;
+        const int side = 2 * r + 1, nitems = side * side * gs.nt;
+        for (int row0 = 0; row0 < nitems; row0 += 64) {
+            // lane -> one (iy, iz) row of the shell (rp, r] in one tile: the whole run of cells x in [cx - r, cx + r] if
+            // the row lies outside the box already seen, else the two end runs left and right of that box
+            const int item = row0 + lane;
             int sA = 0, lA = 0, sB = 0, lB = 0;
-            if (j < nrows) {
+            if (item < nitems) {
+                const int j = item / gs.nt;
+                const int *cst = gs.cs + (size_t)(item - j * gs.nt) * (kGridMaxCells + 2);
                 const int dy = j % side - r, dz = j / side - r;
                 const int iy = c[1] + dy, iz = c[2] + dz;
                 if (iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2]) {
@@ -395,18 +466,18 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     }
                     if (dy < -rp || dy > rp || dz < -rp || dz > rp) {
                         if (x0 <= x1) {
-                            sA = gs.cs[rowbase + x0];
-                            lA = gs.cs[rowbase + x1 + 1] - sA;
+                            sA = cst[rowbase + x0];
+                            lA = cst[rowbase + x1 + 1] - sA;
                         }
                     } else {
                         const int a1 = min(c[0] - rp - 1, x1), b0 = max(c[0] + rp + 1, x0);
                         if (x0 <= a1) {
-                            sA = gs.cs[rowbase + x0];
-                            lA = gs.cs[rowbase + a1 + 1] - sA;
+                            sA = cst[rowbase + x0];
+                            lA = cst[rowbase + a1 + 1] - sA;
                         }
                         if (b0 <= x1) {
-                            sB = gs.cs[rowbase + b0];
-                            lB = gs.cs[rowbase + x1 + 1] - sB;
+                            sB = cst[rowbase + b0];
+                            lB = cst[rowbase + x1 + 1] - sB;
                         }
                     }
                 }
@@ -518,19 +589,21 @@ __device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx
                 const int rowbase = (iz * g[1] + iy) * g[0];
                 const bool face = (dy == -r || dy == r || dz == -r || dz == r);
                 const int x0 = c[0] - r, x1 = c[0] + r;
-                for (int part = 0; part < 2; ++part) {
+                for (int pt = 0; pt < 2 * gs.nt; ++pt) {   // (part, tile)
+                    const int part = pt & 1;
+                    const int *cst = gs.cs + (size_t)(pt >> 1) * (kGridMaxCells + 2);
                     int s0, s1;
                     if (face) {
-                        if (part == 1) break;
+                        if (part == 1) continue;
                         const int a0 = max(x0, 0), a1 = min(x1, g[0] - 1);
                         if (a0 > a1) break;
-                        s0 = gs.cs[rowbase + a0];
-                        s1 = gs.cs[rowbase + a1 + 1];
+                        s0 = cst[rowbase + a0];
+                        s1 = cst[rowbase + a1 + 1];
                     } else {
                         const int ix = part == 0 ? x0 : x1;
                         if (ix < 0 || ix >= g[0] || (part == 1 && r == 0)) continue;
-                        s0 = gs.cs[rowbase + ix];
-                        s1 = gs.cs[rowbase + ix + 1];
+                        s0 = cst[rowbase + ix];
+                        s1 = cst[rowbase + ix + 1];
                     }
                     for (int pos = s0; pos < s1; ++pos) {
                         const float4 p4 = gs.pt[pos];

@@ -143,9 +143,9 @@ __device__ __forceinline__ void sample_bbox_scene(int s, const float *__restrict
 }
 
 // InitializeNew for scene s = blockIdx.x in one launch: the sampled bounding box, then the bucketed index straight
-// from the caller's cloud (two passes over it, the second L2/MALL-warm).  The index-ordered SoA planes are NOT written: whoever
-// needs them (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand
-// (ensure_soa).
+// from the caller's cloud in ONE pass over it (grid_build_tiles_scene: the cloud in tiles of 5120 points, each loaded once,
+// its records written into the tile's own window).  The index-ordered SoA planes are NOT written: whoever needs them
+// (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand (ensure_soa).
 static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
 struct BuildArgs {   // one tree's InitializeNew
     const float *xyz;
@@ -153,46 +153,35 @@ struct BuildArgs {   // one tree's InitializeNew
     long long scene_stride;
     const int *counts;
     int max_points, cap;
-    int *grp_all;
-    int grp_stride;
     int *size_out;
     float *pmax_out, *bbox_out;
     float4 *GP;
     int *cell_start;
+    int ntiles;
     double *gparams;
 };
 // grid = (scenes, trees): blockIdx.y selects the tree.  FrameKDMap::AddVertex builds TWO trees per depth frame (obstacle +
 // edge cloud, FrameKDMap.cpp:44-47): amk_kd_build_pair issues them as one launch, so the small edge build (24 us alone,
 // mostly latency) runs in the shadow of the obstacle build instead of behind it.
-__device__ __forceinline__ void build_one_tree(const float *__restrict__ xyz, int point_stride, long long scene_stride,
-                                               const int *__restrict__ counts, int max_points, int cap,
-                                               int *__restrict__ grp_all, int grp_stride, int *__restrict__ size_out,
-                                               float *__restrict__ pmax_out, float *__restrict__ bbox_out,
-                                               float4 *__restrict__ GP, int *__restrict__ cell_start,
-                                               double *__restrict__ gparams) {
-    const int s = blockIdx.x;
-    const float *src = xyz + (long long)s * scene_stride;
-    int n = counts ? counts[s] : max_points;
-    n = n < 0 ? 0 : (n > max_points ? max_points : n);
-    int *grp = grp_all + (size_t)s * grp_stride;
-    sample_bbox_scene(s, src, point_stride, n, bbox_out);
-    const amk::RawSrc rs{src, point_stride, grp, size_out + s, pmax_out + s};
-    amk::grid_build_scene(s, rs, cap, n, n, bbox_out, GP, cell_start, gparams);
-}
 constexpr int kBuildMaxEntries = 2 * AMK_PIPELINE_MAX_GANG;   // (tree, frame) pairs of one launch
 struct BuildArgs2 { BuildArgs t[kBuildMaxEntries]; };
 __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildArgs2 args) {
     const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
-    build_one_tree(a.xyz, a.point_stride, a.scene_stride, a.counts, a.max_points, a.cap, a.grp_all, a.grp_stride, a.size_out,
-                   a.pmax_out, a.bbox_out, a.GP, a.cell_start, a.gparams);
+    const int s = blockIdx.x;
+    const float *src = a.xyz + (long long)s * a.scene_stride;
+    int n = a.counts ? a.counts[s] : a.max_points;
+    n = n < 0 ? 0 : (n > a.max_points ? a.max_points : n);
+    sample_bbox_scene(s, src, a.point_stride, n, a.bbox_out);
+    amk::grid_build_tiles_scene(s, src, a.point_stride, a.cap, n, a.bbox_out, a.GP, a.cell_start, a.ntiles, a.gparams,
+                                a.size_out + s, a.pmax_out + s);
 }
 // so: first scene of the handle this entry writes (a gang launch builds frame f into scenes [f * S, (f + 1) * S) of the handle)
 static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride, const int *d_counts,
                             size_t so = 0) {
-    const int gs = kd->cap / kWave + 2;
-    return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap, kd->grp.p + so * gs, gs,
+    return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap,
                      kd->size.p + so, kd->pmax.p + so, kd->bbox.p + so * 6, kd->gpt.p + so * kd->cap,
-                     kd->cell_start.p + so * (amk::kGridMaxCells + 2), kd->gparams.p + so * amk::kGridParamDoubles};
+                     kd->cell_start.p + so * kd->ntiles * (amk::kGridMaxCells + 2), kd->ntiles,
+                     kd->gparams.p + so * amk::kGridParamDoubles};
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
@@ -554,7 +543,7 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
         AMK_HIP(keyframe->flags.alloc((size_t)S * keyframe->cap));
         AMK_HIP(keyframe->sweep_cnt.alloc((size_t)S * 2));
     }
-    const amk::GridPtrs cur{current->gpt.p, current->cell_start.p, current->gparams.p, current->cap};
+    const amk::GridPtrs cur{current->gpt.p, current->cell_start.p, current->gparams.p, current->cap, current->ntiles};
     {   // the key frame's points are the queries and are compacted in place: they must exist in index order
         const int st = ensure_soa(keyframe, stream);
         if (st != AMK_OK) return st;
@@ -570,7 +559,7 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
     // the bucketed index of every scene is rebuilt (a no-op in effect for the untouched ones)
     hipLaunchKernelGGL(amk::kd_grid_build_kernel, dim3(S), dim3(amk::kGridBuildThreads), 0, stream, keyframe->x.p,
                        keyframe->y.p, keyframe->z.p, keyframe->cap, keyframe->size.p, keyframe->bbox.p, keyframe->gpt.p,
-                       keyframe->cell_start.p, keyframe->gparams.p);
+                       keyframe->cell_start.p, keyframe->ntiles, keyframe->gparams.p);
     keyframe->async_pending = 1;
     AMK_HIP(hipGetLastError());
     keyframe->ex_valid = 0;   // a rebuilt keyframe's old tree describes another cloud
@@ -664,10 +653,9 @@ int amk_kd_create(int n_scenes, int max_points, amk_kd **out) {
     }
     if ((e = hipMemset(kd->size.p, 0, sizeof(int) * n_scenes)) != hipSuccess ||
         (e = kd->gpt.alloc(tot)) != hipSuccess || (e = kd->bbox.alloc((size_t)n_scenes * 6)) != hipSuccess ||
-        (e = kd->cell_start.alloc((size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
+        (e = kd->cell_start.alloc((size_t)n_scenes * (kd->ntiles = amk::grid_tiles(max_points)) * (amk::kGridMaxCells + 2))) != hipSuccess ||
         (e = kd->gparams.alloc((size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess ||
-        (e = kd->grp.alloc((size_t)n_scenes * (kd->cap / kWave + 2))) != hipSuccess ||
-        (e = hipMemset(kd->cell_start.p, 0, sizeof(int) * (size_t)n_scenes * (amk::kGridMaxCells + 2))) != hipSuccess ||
+        (e = hipMemset(kd->cell_start.p, 0, sizeof(int) * (size_t)n_scenes * kd->ntiles * (amk::kGridMaxCells + 2))) != hipSuccess ||
         (e = hipMemset(kd->gparams.p, 0, sizeof(double) * (size_t)n_scenes * amk::kGridParamDoubles)) != hipSuccess) {
         delete kd;
         return amk::hip_fail(e);
@@ -792,7 +780,7 @@ int amk_kd_search(amk_kd *kd, const double *d_queries, int n_queries, int k, int
     if (!kd || !d_queries || n_queries <= 0 || k <= 0) return AMK_ERR_INVALID_ARG;
     if (k > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
     if (kd->mode == 0) {
-        const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap};
+        const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap, kd->ntiles};
         const int blocks = (kd->n_scenes + 7) / 8 * 8 * ((n_queries + 3) / 4);
         hipLaunchKernelGGL(kd_grid_search_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p,
                            kd->n_scenes, d_queries, n_queries, k, d_indices, d_sqdist, d_pts, d_counts);
@@ -829,7 +817,7 @@ int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int 
                      void *stream) {
     if (!kd || !d_queries || !d_tie_flags || n_queries <= 0 || k <= 0 || query_stride < 3) return AMK_ERR_INVALID_ARG;
     if (k + 1 > AMK_MAX_K || n_queries > AMK_MAX_QUERIES) return AMK_ERR_UNSUPPORTED;
-    const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap};
+    const amk::GridPtrs gpt{kd->gpt.p, kd->cell_start.p, kd->gparams.p, kd->cap, kd->ntiles};
     const int blocks = (kd->n_scenes + 7) / 8 * 8 * ((n_queries + 3) / 4);
     hipLaunchKernelGGL(kd_tie_flags_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, gpt, kd->size.p, kd->n_scenes,
                        d_queries, query_stride, n_queries, k, d_tie_flags);

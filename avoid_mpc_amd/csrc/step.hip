@@ -365,8 +365,8 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
         if (st == AMK_OK) st = amk__kd_ensure_soa(edge, stream_);
         if (st != AMK_OK) return st;
     }
-    const GridPtrs gobs{obstacle->gpt.p, obstacle->cell_start.p, obstacle->gparams.p, obstacle->cap};
-    const GridPtrs gedge{edge->gpt.p, edge->cell_start.p, edge->gparams.p, edge->cap};
+    const GridPtrs gobs{obstacle->gpt.p, obstacle->cell_start.p, obstacle->gparams.p, obstacle->cap, obstacle->ntiles};
+    const GridPtrs gedge{edge->gpt.p, edge->cell_start.p, edge->gparams.p, edge->cap, edge->ntiles};
     // handles in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build)
     const int ex_obs = use_grid && obstacle->tie_order && obstacle->ex_valid, ex_edge = use_grid && edge->tie_order && edge->ex_valid;
     const ExactPtrs eobs = ex_obs ? amk_exact_ptrs(obstacle) : ExactPtrs{}, eedge = ex_edge ? amk_exact_ptrs(edge) : ExactPtrs{};

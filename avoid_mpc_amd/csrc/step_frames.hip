@@ -336,8 +336,8 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
     for (int f = 0; f < F; ++f) {
         if (!obstacle[f] || !edge[f] || obstacle[f]->n_scenes != S || edge[f]->n_scenes != S) return AMK_ERR_INVALID_ARG;
         if (obstacle[f]->mode != 0 || edge[f]->mode != 0) return AMK_ERR_UNSUPPORTED;  // bucketed indices only
-        fs.obs[f] = GridPtrs{obstacle[f]->gpt.p, obstacle[f]->cell_start.p, obstacle[f]->gparams.p, obstacle[f]->cap};
-        fs.edge[f] = GridPtrs{edge[f]->gpt.p, edge[f]->cell_start.p, edge[f]->gparams.p, edge[f]->cap};
+        fs.obs[f] = GridPtrs{obstacle[f]->gpt.p, obstacle[f]->cell_start.p, obstacle[f]->gparams.p, obstacle[f]->cap, obstacle[f]->ntiles};
+        fs.edge[f] = GridPtrs{edge[f]->gpt.p, edge[f]->cell_start.p, edge[f]->gparams.p, edge[f]->cap, edge[f]->ntiles};
         fs.size_obs[f] = obstacle[f]->size.p;
         fs.size_edge[f] = edge[f]->size.p;
     }
