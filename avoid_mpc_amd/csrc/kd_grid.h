@@ -197,12 +197,16 @@ __device__ __forceinline__ void grid_build_scene(int s, const float *__restrict_
 // ------------------------------------------------------------------------------------------------
 // The two-pass counting sort above reads the cloud twice and scatters every record over the scene's whole 800 KB region
 // (measured: 1.64 x the algorithmic bytes, 0.29 of the HBM peak).  Here the cloud is cut into TILES of kTilePoints
-// consecutive points; a tile is loaded ONCE into registers, counted and ranked in LDS, and its records are written into
+// consecutive points (4096); a tile is loaded ONCE into registers, counted and ranked in LDS, and its records are written into
 // the tile's own window of the record array (bucket-contiguous inside the window, windows packed one after the other) --
-// 128 KB that stay in L2 until every line is full.  The index becomes a list of tiles, each with its own table of bucket
+// 64 KB that stay in L2 until every line is full.  The index becomes a list of tiles, each with its own table of bucket
 // starts: cell c of the scene = one run of records per tile, [cs[t][c], cs[t][c + 1]) for t < ntiles; the searches
 // enumerate (row, tile) pairs where they enumerated rows.  Tiles beyond the cloud's last one hold empty runs.
-constexpr int kTileP = 10;                                     // points per thread and tile (in registers from load to store)
+#ifndef AMK_TILE_P
+#define AMK_TILE_P 8    // same-box A/B of the step, k steps/s steady / over 20 steps: 6 (106 VGPRs, 17 tiles at 50 k points) 564 / 460,
+                        // 8 (122, 13 tiles) 566 / 452, 10 (141, 10 tiles) 558 / 442; 12 needs 159 VGPRs: no room beside a solve wave
+#endif
+constexpr int kTileP = AMK_TILE_P;                                     // points per thread and tile (in registers from load to store)
 constexpr int kTilePoints = kGridBuildThreads * kTileP;        // 8192
 __host__ __device__ constexpr int grid_tiles(int max_points) { return max_points <= 0 ? 1 : (max_points + kTilePoints - 1) / kTilePoints; }
 

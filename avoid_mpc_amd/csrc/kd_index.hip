@@ -143,7 +143,7 @@ __device__ __forceinline__ void sample_bbox_scene(int s, const float *__restrict
 }
 
 // InitializeNew for scene s = blockIdx.x in one launch: the sampled bounding box, then the bucketed index straight
-// from the caller's cloud in ONE pass over it (grid_build_tiles_scene: the cloud in tiles of 5120 points, each loaded once,
+// from the caller's cloud in ONE pass over it (grid_build_tiles_scene: the cloud in tiles of 4096 points, each loaded once,
 // its records written into the tile's own window).  The index-ordered SoA planes are NOT written: whoever needs them
 // (scan-mode searches, amk_kd_points_host, the keyframe sweep) gets them from the records on demand (ensure_soa).
 static_assert(kCompactThreads == amk::kGridBuildThreads, "one block shape for both halves of the build");
