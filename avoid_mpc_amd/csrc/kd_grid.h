@@ -207,7 +207,7 @@ __device__ __forceinline__ void grid_build_scene(int s, const float *__restrict_
                         // 8 (122, 13 tiles) 566 / 452, 10 (141, 10 tiles) 558 / 442; 12 needs 159 VGPRs: no room beside a solve wave
 #endif
 constexpr int kTileP = AMK_TILE_P;                                     // points per thread and tile (in registers from load to store)
-constexpr int kTilePoints = kGridBuildThreads * kTileP;        // 8192
+constexpr int kTilePoints = kGridBuildThreads * kTileP;        // 4096
 __host__ __device__ constexpr int grid_tiles(int max_points) { return max_points <= 0 ? 1 : (max_points + kTilePoints - 1) / kTilePoints; }
 
 __device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__restrict__ src, int stride, int cap, int nvis,
