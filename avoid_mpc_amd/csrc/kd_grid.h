@@ -22,12 +22,11 @@ constexpr int kGridMaxCells = AMK_GRID_MAX_CELLS;
 #ifndef AMK_GRID_PPC
 #define AMK_GRID_PPC 64
 #endif
-// Resolution: ~64 points per cell, <= 1024 cells (round 1: ~8 per cell, <= 8192).  The build's scatter keeps one open
-// output line per cell; 256 scenes x 8192 cells x 128 B is 8x the L2, so every 16-byte record left L2 on its own (write
-// traffic 2x the records), while 256 x <= 1024 lines mostly stay until they are full.  The search pays with longer
-// candidate lists (a cell is one coalesced run of records: cheap) -- measured with 20 steps in flight
-// (tools/experiments/cells_sens.sh): 50k-point clouds 385 -> 402 k steps/s, 200k-point clouds 125 -> 137 k, 5k / 3k-point
-// clouds unchanged; the histogram shrinks from 32 KB to 4 KB of LDS per block.
+// Resolution: ~64 points per cell, <= 1024 cells (round 1: ~8 per cell, <= 8192) -- chosen when the build scattered every
+// record over the scene's whole region and kept one open output line per cell (measured with 20 steps in flight,
+// tools/experiments/cells_sens.sh: 50k-point clouds 385 -> 402 k steps/s, 200k-point clouds 125 -> 137 k, 5k / 3k-point
+// clouds unchanged); with the one-pass tile build below it bounds the per-tile tables (4 KB each) and the LDS histogram.
+// The search pays with longer candidate lists (the ball clipping still applies).
 constexpr int kGridPointsPerCell = AMK_GRID_PPC;  // target occupancy of a cell
 // 512, not 1024: a 1024-thread workgroup needs four wave slots on every SIMD of one CU at the same moment, and the
 // dispatcher holds everything behind it until a CU qualifies -- measured: 1024-thread builds do not overlap with
@@ -39,7 +38,7 @@ constexpr int kGridPointsPerCell = AMK_GRID_PPC;  // target occupancy of a cell
 #endif
 constexpr int kGridBuildThreads = AMK_BUILD_THREADS;
 #ifndef AMK_GRID_UNROLL
-#define AMK_GRID_UNROLL 16  // points in flight per thread; 24 and more: the block's registers no longer fit beside a solve wave (tests/test_abi.py)
+#define AMK_GRID_UNROLL 16  // points in flight per thread of the two-pass build from SoA planes (keyframe sweep)
 #endif
 constexpr int kGridUnroll = AMK_GRID_UNROLL;
 constexpr int kGridParamDoubles = 8;  // bbmin[3], h, inv_h, gx, gy, gz

@@ -203,6 +203,38 @@ def test_points_outside_the_sampled_box_and_nan_runs(torch_cuda, oracle):
         assert np.array_equal(res["indices"][0, j], ri) and np.array_equal(res["sqdist"][0, j], rd), j
 
 
+def test_tile_boundaries_of_the_one_pass_build(torch_cuda, oracle):
+    """The index build cuts a cloud into tiles of 4096 points (kd_grid.h grid_build_tiles_scene): ragged batch whose sizes
+    sit on, before and behind tile and 512-point round boundaries, NaN-x runs across a tile boundary (the cloud indices of
+    everything behind them shift), a tile that is all NaN, pcl::PointXYZ stride -- indices, distances and
+    sizes must equal the oracle's on the NaN-x-filtered cloud."""
+    rng = np.random.default_rng(77)
+    sizes = [4096, 4097, 4095, 8192, 8193, 512, 513, 1, 12289, 20000, 0, 3]
+    clouds = []
+    for i, n in enumerate(sizes):
+        c = rng.uniform([-4, -4, 0], [4, 4, 3], (n, 3)).astype(np.float32)
+        if n > 4200:
+            c[4090:4110, 0] = np.nan                      # a run across the first tile boundary
+        if n >= 12289:
+            c[8192:12288, 0] = np.nan                     # the third tile holds no point at all
+        if n > 600:
+            c[rng.choice(n, 37, replace=False), 0] = np.nan
+        clouds.append(c)
+    q = rng.uniform([-5, -5, -1], [5, 5, 4], (24, 3))
+    qs = np.broadcast_to(q, (len(sizes),) + q.shape)
+    for stride in (3, 4):
+        for k in (1, 8):
+            res = _gpu_search(torch_cuda, clouds, qs, k, stride=stride)
+            for s, c in enumerate(clouds):
+                tree = _oracle.kd_oracle(c)
+                assert res["sizes"][s] == tree.size(), (s, stride)
+                for j in range(len(q)):
+                    ri, rd, _ = tree.search(q[j], k)
+                    cnt = len(ri)
+                    assert res["counts"][s, j] == cnt, (s, j, k)
+                    assert np.array_equal(res["indices"][s, j, :cnt], ri[:cnt]) and np.array_equal(res["sqdist"][s, j, :cnt], rd[:cnt]), (s, j, k)
+
+
 def test_tie_flags_mark_every_query_whose_indices_may_differ_from_nanoflann(torch_cuda, oracle):
     """amk_kd_tie_flags.  (a) tie-free random cloud: no flag, indices == the reference-pinned oracle (traversal order).
     (b) a QUANTISED cloud as the edge pipeline makes them (8-bit depth on a pixel grid, FrameKDMap.cpp:180-200: exact
