@@ -4,7 +4,7 @@
 // = max over ranks.  The reference runs a single instance (AM/src/mpc_obstacle_avoidance_node.cpp:8); this is the host side
 // of its batched counterpart, in C++ as north_star asks.
 //
-//   sweep_driver <in.bin> <out.bin> <rank> <world> <rendezvous file> [n_slots] [repeat]
+//   sweep_driver <in.bin> <out.bin> <rank> <world> <rendezvous file> [n_slots] [repeat] [gang]
 //
 // in.bin : int32 total_scenes, n, ne, N, K, mpc_max_iter ; double T, dt, speed, safety_distance ;
 //          double weights[25], tau[4], gains[4], limits[5] (aMinZ aMaxZ aMaxXy aMaxYawDot radius) ;
@@ -118,6 +118,7 @@ int main(int argc, char **argv) {
     const std::string rdv = argv[5];
     const int n_slots = argc > 6 ? atoi(argv[6]) : 4;
     const int repeat = argc > 7 ? atoi(argv[7]) : 1;
+    const int gang = argc > 8 ? atoi(argv[8]) : 0;   // frames per launch (amk_pipeline_config.gang)
     FILE *f = fopen(argv[1], "rb");
     if (!f) return 1;
     int hdr[6];
@@ -166,7 +167,7 @@ int main(int argc, char **argv) {
     amk_pipeline_config cfg;
     std::memset(&cfg, 0, sizeof cfg);
     cfg.n_slots = n_slots; cfg.n_scenes = S; cfg.max_points = n; cfg.max_edge_points = ne;
-    cfg.T = sc[0]; cfg.dt = sc[1]; cfg.nearest_point_num = K; cfg.queue_depth = 0;
+    cfg.T = sc[0]; cfg.dt = sc[1]; cfg.nearest_point_num = K; cfg.queue_depth = 0; cfg.gang = gang;
     cfg.step.speed = sc[2]; cfg.step.safety_distance = sc[3]; cfg.step.mpc_max_iter = max_iter;
     amk_pipeline *pl = nullptr;
     CHECK(amk_pipeline_create(&cfg, &pl));
@@ -192,11 +193,11 @@ int main(int argc, char **argv) {
     std::memset(&fr, 0, sizeof fr);
     fr.d_cloud = d_cl; fr.d_edge = d_ed; fr.point_stride = 3; fr.d_state_quad = d_sq; fr.d_pos_x = d_px; fr.d_ref_path_init = d_ref;
     // warm-up: every slot allocates its step workspace once
-    for (int i = 0; i < n_slots; ++i) { fr.d_u_out = nullptr; CHECK(amk_pipeline_submit(pl, &fr, nullptr)); }
+    for (int i = 0; i < n_slots * (gang > 1 ? gang : 1); ++i) { fr.d_u_out = nullptr; CHECK(amk_pipeline_submit(pl, &fr, nullptr)); }
     CHECK(amk_pipeline_drain(pl));
     tp.max(0.0);   // barrier
     const auto t0 = std::chrono::steady_clock::now();
-    int last_slot = 0;
+    int last_slot = 0;   // the last frame's ticket (= its slot without a gang)
     for (int r = 0; r < repeat; ++r) {
         fr.d_u_out = d_u + (size_t)r * S * 4;
         CHECK(amk_pipeline_submit(pl, &fr, &last_slot));
