@@ -441,15 +441,19 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     int rp = -1;  // everything within Chebyshev radius rp of the query's cell has been seen
     for (int r = 0;; ) {
         const int side = 2 * r + 1, nitems = side * side * gs.nt;
+        // item -> (row, tile) and row -> (dy, dz) through float reciprocals: exact while nitems < 4e6 ((x + 0.5) / n is at
+        // least 0.5 / n away from an integer; the integer-division sequences cost 40 instructions and 10 registers)
+        const float inv_nt = 1.0f / (float)gs.nt, inv_side = 1.0f / (float)side;
         for (int row0 = 0; row0 < nitems; row0 += 64) {
             // lane -> one (iy, iz) row of the shell (rp, r] in one tile: the whole run of cells x in [cx - r, cx + r] if
             // the row lies outside the box already seen, else the two end runs left and right of that box
             const int item = row0 + lane;
             int sA = 0, lA = 0, sB = 0, lB = 0;
             if (item < nitems) {
-                const int j = item / gs.nt;
+                const int j = (int)(((float)item + 0.5f) * inv_nt);
                 const int *cst = gs.cs + (size_t)(item - j * gs.nt) * (kGridMaxCells + 2);
-                const int dy = j % side - r, dz = j / side - r;
+                const int jz = (int)(((float)j + 0.5f) * inv_side);
+                const int dy = j - jz * side - r, dz = jz - r;
                 const int iy = c[1] + dy, iz = c[2] + dz;
                 if (iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2]) {
                     const int rowbase = (iz * g[1] + iy) * g[0];
