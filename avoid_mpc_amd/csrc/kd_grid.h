@@ -440,10 +440,15 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
     int rp = -1;  // everything within Chebyshev radius rp of the query's cell has been seen
     for (int r = 0;; ) {
-        const int side = 2 * r + 1, nitems = side * side * gs.nt;
-        // item -> (row, tile) and row -> (dy, dz) through float reciprocals: exact while nitems < 4e6 ((x + 0.5) / n is at
-        // least 0.5 / n away from an integer; the integer-division sequences cost 40 instructions and 10 registers)
-        const float inv_nt = 1.0f / (float)gs.nt, inv_side = 1.0f / (float)side;
+        // the (iy, iz) rows of the shell that lie inside the grid: [ylo, yhi] x [zlo, zhi] (a degenerate grid -- 1024 x 1 x 1
+        // cells of a cloud on a line -- has few rows however large r gets; at most kGridMaxCells of them)
+        const int ylo = max(c[1] - r, 0), ny = min(c[1] + r, g[1] - 1) - ylo + 1;
+        const int zlo = max(c[2] - r, 0), nz = min(c[2] + r, g[2] - 1) - zlo + 1;
+        const int nitems = ny * nz * gs.nt;
+        // item -> (row, tile) and row -> (iy, iz) through float reciprocals: exact while nitems < 4e6 ((x + 0.5) / n is at
+        // least 0.5 / n away from an integer; nitems <= kGridMaxCells x tiles); the integer-division sequences cost 40
+        // instructions and 10 registers
+        const float inv_nt = 1.0f / (float)gs.nt, inv_ny = 1.0f / (float)ny;
         for (int row0 = 0; row0 < nitems; row0 += 64) {
             // lane -> one (iy, iz) row of the shell (rp, r] in one tile: the whole run of cells x in [cx - r, cx + r] if
             // the row lies outside the box already seen, else the two end runs left and right of that box
@@ -452,10 +457,10 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             if (item < nitems) {
                 const int j = (int)(((float)item + 0.5f) * inv_nt);
                 const int *cst = gs.cs + (size_t)(item - j * gs.nt) * (kGridMaxCells + 2);
-                const int jz = (int)(((float)j + 0.5f) * inv_side);
-                const int dy = j - jz * side - r, dz = jz - r;
-                const int iy = c[1] + dy, iz = c[2] + dz;
-                if (iy >= 0 && iy < g[1] && iz >= 0 && iz < g[2]) {
+                const int jz = (int)(((float)j + 0.5f) * inv_ny);
+                const int iy = ylo + (j - jz * ny), iz = zlo + jz;
+                const int dy = iy - c[1], dz = iz - c[2];
+                {
                     const int rowbase = (iz * g[1] + iy) * g[0];
                     int x0 = max(c[0] - r, 0), x1 = min(c[0] + r, g[0] - 1);
                     if (tau < DBL_MAX) {  // clip to the ball of radius sqrt(tau) (conservatively: + slack)
@@ -587,12 +592,10 @@ __device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx
     const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
     double best = DBL_MAX;
     for (int r = 0; r <= rmax; ++r) {
-        for (int dz = -r; dz <= r; ++dz) {
+        for (int dz = max(-r, -c[2]); dz <= min(r, g[2] - 1 - c[2]); ++dz) {   // (only the rows inside the grid)
             const int iz = c[2] + dz;
-            if (iz < 0 || iz >= g[2]) continue;
-            for (int dy = -r; dy <= r; ++dy) {
+            for (int dy = max(-r, -c[1]); dy <= min(r, g[1] - 1 - c[1]); ++dy) {
                 const int iy = c[1] + dy;
-                if (iy < 0 || iy >= g[1]) continue;
                 const int rowbase = (iz * g[1] + iy) * g[0];
                 const bool face = (dy == -r || dy == r || dz == -r || dz == r);
                 const int x0 = c[0] - r, x1 = c[0] + r;

@@ -203,6 +203,29 @@ def test_points_outside_the_sampled_box_and_nan_runs(torch_cuda, oracle):
         assert np.array_equal(res["indices"][0, j], ri) and np.array_equal(res["sqdist"][0, j], rd), j
 
 
+def test_degenerate_grids_and_far_queries(torch_cuda, oracle):
+    """Clouds whose bounding box is (nearly) a line or a plane give grids of 1024 x 1 x 1 or 32 x 32 x 1 cells; a query far
+    from the cloud walks many rings before its k-th distance reaches the next face.  The ring walk enumerates only the rows
+    inside the grid (and decodes them through float reciprocals): results must still be the oracle's."""
+    rng = np.random.default_rng(311)
+    n = 20000
+    t = rng.uniform(0, 1, n).astype(np.float32)
+    line = np.stack([1000.0 * t, 0.001 * rng.standard_normal(n), 0.001 * rng.standard_normal(n)], 1).astype(np.float32)
+    plane = np.stack([rng.uniform(-50, 50, n), rng.uniform(-50, 50, n), 0.001 * rng.standard_normal(n)], 1).astype(np.float32)
+    diag = np.stack([300 * t, 300 * t + 0.01 * rng.standard_normal(n), 0.5 * rng.standard_normal(n)], 1).astype(np.float32)
+    q = np.concatenate([rng.uniform([-100, -5, -5], [1100, 5, 5], (16, 3)), rng.uniform(-400, 400, (16, 3)),
+                        np.array([[500.0, 300.0, 0.0], [-2000.0, 0.0, 0.0], [0.0, 0.0, 900.0]])])
+    clouds = [line, plane, diag]
+    qs = np.broadcast_to(q, (len(clouds),) + q.shape)
+    for k in (1, 8):
+        res = _gpu_search(torch_cuda, clouds, qs, k)
+        for s, c in enumerate(clouds):
+            tree = _oracle.kd_oracle(c)
+            for j in range(len(q)):
+                ri, rd, _ = tree.search(q[j], k)
+                assert np.array_equal(res["indices"][s, j, :len(ri)], ri) and np.array_equal(res["sqdist"][s, j, :len(ri)], rd), (s, j, k)
+
+
 def test_tile_boundaries_of_the_one_pass_build(torch_cuda, oracle):
     """The index build cuts a cloud into tiles of 4096 points (kd_grid.h grid_build_tiles_scene): ragged batch whose sizes
     sit on, before and behind tile and 512-point round boundaries, NaN-x runs across a tile boundary (the cloud indices of
