@@ -391,12 +391,15 @@ def main():
     # (profiles/r03_kernel_stats_streams1.md; same scenes: the frames of in-flight slot 0).  In the timed region above the same events also contain the wait for CUs the
     # other launches in flight occupy, which is why that figure is reported separately as in_flight_submit_to_complete_ms.
     lone = None
+    ticket_of_frames0 = None
     if rank == 0 and diag_streams is None:
         lib.amk__timing_enable(2)
         reps = 6   # always the frames of in-flight slot 0 = the scenes of `bench.py --streams 1` (the committed rocprof trace)
         for j in range(reps):   # one LAUNCH at a time: the `gang` steps that share it (frames 0 .. gang-1), then wait
             for g in range(gang):
                 t = one_step(j * gang + g, frames=g)
+                if g == 0:
+                    ticket_of_frames0 = t   # where the slot keeps the flags of frame set 0 (the CPU check below reads them)
             pl.wait(t)
         torch.cuda.synchronize()
         ms1 = (C.c_double * 8)(); cnt1 = (C.c_int * 8)()
@@ -404,6 +407,13 @@ def main():
         lib.amk__timing_enable(0)
         lone = {KCLASS[i]: {"avg_launch_us": round(1e3 * ms1[i] / cnt1[i], 2), "launches_per_step": cnt1[i] / (reps * gang)}
                 for i in range(8) if cnt1[i] and KCLASS[i]}
+    chk = None   # frame set 0's controls and flags for the CPU check, taken before anything else runs on that slot
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and diag_streams is None:
+        if ticket_of_frames0 is None:   # (no single-launch pass ran: run frame set 0 once more)
+            ticket_of_frames0 = one_step(0, frames=0)
+        pl.wait(ticket_of_frames0)
+        torch.cuda.synchronize()
+        chk = (u_sweep[slots[0].last_row].cpu().numpy().copy(), pl.outputs(ticket_of_frames0)["flags"].copy())
     breakdown = None
     if args.breakdown and world == 1:   # (extra steps on one rank would unbalance the collectives)
         lib.amk__timing_enable(2)
@@ -420,12 +430,12 @@ def main():
     parity, cpu = None, None
     if rank == 0 and not args.no_parity:
         parity = {"fixtures": fixture_parity(torch, args.precision)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if chk is not None:
         sl = slots[0]
         torch.cuda.synchronize()
         cl, ed = sl.clouds.cpu().numpy(), sl.edges.cpu().numpy()
         scenes = [(cl[s], ed[s], sl.sq_h[s], float(sl.posx_h[s]), sl.ref0_h[s]) for s in range(S)]
-        cpu, check = cpu_baseline_and_check(scenes, args.T, args.K, u_sweep[sl.last_row].cpu().numpy(), pl.outputs(0)["flags"])
+        cpu, check = cpu_baseline_and_check(scenes, args.T, args.K, chk[0], chk[1])
         parity = dict(parity or {}, timed_workload_vs_cpu_oracle=check)
 
     if rank == 0:
