@@ -1,0 +1,31 @@
+"""GPU: bench.py as the driver runs it (`--gpus 1 --steps 20 --warmup 5`: a warm-up that does NOT fill a gang, 20 timed steps)
+and with an odd pipeline shape -- one JSON line with the contract's fields, the roofline and cpu_baseline blocks, and both
+parity checks green (the fixture gate and the timed workload's own scenes against the CPU oracle)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("extra", [["--steps", "20", "--warmup", "5"],
+                                   ["--steps", "9", "--warmup", "2", "--streams", "3", "--gang", "3", "--scenes", "64", "--steady-steps", "0"]])
+def test_bench_line(extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra, capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == int(extra[1]) and d["value"] > 0 and d["dtype"] == "f64"
+    assert d["roofline"]["bound"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["parity"]["fixtures"]["ok"], d["parity"]["fixtures"]
+    chk = d["parity"]["timed_workload_vs_cpu_oracle"]
+    assert chk["ok"] and chk["scenes"] == d["config"]["scenes_per_gpu"], chk
