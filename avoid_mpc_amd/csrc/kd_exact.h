@@ -30,6 +30,9 @@ namespace amk {
 constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
 constexpr int kExactThreads = 1024; // 16 wavefronts per scene
 constexpr int kExactBigNode = 1024; // more points than this: the node is split by the whole workgroup
+constexpr int kExactTodo = -2;      // feat of a node divideTree has not visited yet (a leaf is -1)
+constexpr int kExactSubtree = 64;   // a node of at most this many points: its whole subtree is built by one wavefront, in registers
+constexpr int kExactSubStack = 12;  // pending right children of that wavefront (deeper: handed back to the level loop)
 constexpr int kExactMaxDepth = 48;  // traversal stack (one frame per level); deeper trees fall back to the bucketed index
 
 struct ExactTree {  // one scene
@@ -283,6 +286,7 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
     if (tid == 0) {
         T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
         T.left[c] = l; T.right[c] = l + idx; T.left[c + 1] = l + idx; T.right[c + 1] = r;
+        T.feat[c] = kExactTodo; T.feat[c + 1] = kExactTodo;
     }
     if (tid < 6) {
         const int d = tid >> 1, hi = tid & 1;
@@ -296,6 +300,137 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
 #undef bhi
 }
 
+// divideTree for node `id` AND everything below it, by one wavefront: the node's <= 64 points live in registers (lane i =
+// position left + i of vAcc_: its index and its three coordinates), every computeMinMax is a wave reduction over the lanes
+// of the current range, every planeSplit the same left / right misplaced-pair swap as hoare_partition with the pairing
+// through 64 LDS bytes per list -- the bottom levels of the tree (90 % of its nodes) cost a few hundred instructions per
+// node instead of a dozen dependent round trips to memory.  Same splits, same order of vAcc_ inside the leaves.
+struct ExactSubLds {   // per wavefront
+    unsigned char il[64], ir[64];                 // lane of the j-th misplaced element on the left / on the right
+    int l[kExactSubStack], r[kExactSubStack], id[kExactSubStack];
+    double bb[kExactSubStack][6];
+};
+__device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root, int *n_nodes_lds, int *overflow, ExactSubLds *ws) {
+    const int lane = threadIdx.x & 63;
+    const unsigned L0 = T.left[root];
+    const int W = (int)(T.right[root] - L0);
+    const bool mine = lane < W;
+    unsigned vi = mine ? T.vind[L0 + lane] : 0u;
+    float px = mine ? T.plane(0)[L0 + lane] : 0.f, py = mine ? T.plane(1)[L0 + lane] : 0.f, pz = mine ? T.plane(2)[L0 + lane] : 0.f;
+    int sp = 0;   // stack of pending nodes (LDS); the current node is in registers
+    int l = 0, r = W, id = root;
+    double b0l = T.nbbox[(size_t)root * 6 + 0], b0h = T.nbbox[(size_t)root * 6 + 1], b1l = T.nbbox[(size_t)root * 6 + 2],
+           b1h = T.nbbox[(size_t)root * 6 + 3], b2l = T.nbbox[(size_t)root * 6 + 4], b2h = T.nbbox[(size_t)root * 6 + 5];
+    auto coord = [&](int d) { return (double)(d == 0 ? px : (d == 1 ? py : pz)); };
+    auto minmax = [&](int a, int b, int d, double &mn, double &mx) {   // computeMinMax over lanes [a, b)
+        const bool in = lane >= a && lane < b;
+        const double v = coord(d);
+        mn = wave_min_f64(in ? v : DBL_MAX);
+        mx = wave_max_f64(in ? v : -DBL_MAX);
+    };
+    // one Hoare partition of planeSplit over lanes [a, b): returns the number of pred lanes; the registers are permuted
+    auto partition = [&](int a, int b, int d, double cutval, bool strict) {
+        const bool in = lane >= a && lane < b;
+        const double v = coord(d);
+        const bool pred = in && (strict ? v < cutval : v <= cutval);
+        const unsigned long long mp = __ballot(pred);
+        const int cnt = __popcll(mp), lim = a + cnt;
+        const bool ml = in && lane < lim && !pred, mr = in && lane >= lim && pred;
+        const unsigned long long mml = __ballot(ml), mmr = __ballot(mr);
+        if (ml) ws->il[__popcll(mml & ((1ull << lane) - 1ull))] = (unsigned char)lane;              // ascending
+        if (mr) ws->ir[__popcll(mmr & ~((2ull << lane) - 1ull))] = (unsigned char)lane;             // descending
+        __threadfence_block();   // the two lists: written and read by lanes of this wave
+        int partner = lane;
+        if (ml) partner = ws->ir[__popcll(mml & ((1ull << lane) - 1ull))];
+        if (mr) partner = ws->il[__popcll(mmr & ~((2ull << lane) - 1ull))];
+        vi = __shfl(vi, partner); px = __shfl(px, partner); py = __shfl(py, partner); pz = __shfl(pz, partner);
+        __threadfence_block();   // (the lists are rewritten by the next partition)
+        return cnt;
+    };
+    for (;;) {
+        const int count = r - l;
+        bool descend = false;
+        if (count <= kExactLeaf) {
+            if (lane == 0) T.feat[id] = -1;
+        } else {
+#define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
+#define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
+            // middleSplit_ (:1197-1245)
+            const double EPS = 0.00001;
+            double max_span = b0h - b0l;
+#pragma unroll
+            for (int d = 1; d < 3; ++d) {
+                const double span = bhi(d) - blo(d);
+                if (span > max_span) max_span = span;
+            }
+            double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
+            int cutfeat = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                const double span = bhi(d) - blo(d);
+                if (span > (1 - EPS) * max_span) {
+                    double mn, mx;
+                    minmax(l, r, d, mn, mx);
+                    const double spread = mx - mn;
+                    if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
+                }
+            }
+            const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
+            const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
+            // planeSplit (:1256-1294)
+            const int lim1 = partition(l, r, cutfeat, cutval, true);
+            const int lim2 = lim1 + partition(l + lim1, r, cutfeat, cutval, false);
+            const int half = count / 2;
+            const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+            double dlo, dhi, t0, t1;
+            minmax(l, l + idx, cutfeat, t0, dlo);      // divlow  = left child's high
+            minmax(l + idx, r, cutfeat, dhi, t1);      // divhigh = right child's low
+            int c = 0;
+            if (lane == 0) {
+                c = atomicAdd(n_nodes_lds, 2);
+                if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
+            }
+            c = __shfl(c, 0);
+            if (c >= 0) {
+                const bool room = sp < kExactSubStack;   // else: the right child goes back to the level loop
+                if (lane == 0) {
+                    T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
+                    T.left[c] = L0 + l; T.right[c] = L0 + l + idx; T.left[c + 1] = L0 + l + idx; T.right[c + 1] = L0 + r;
+                    T.feat[c + 1] = kExactTodo;   // (overwritten when this wave gets to it)
+                }
+                // right child: box = this box with low[cutfeat] = cutval
+                if (room) {
+                    if (lane < 6) {
+                        const int d = lane >> 1, hi = lane & 1;
+                        ws->bb[sp][lane] = (d == cutfeat && hi == 0) ? cutval : (hi ? bhi(d) : blo(d));
+                    }
+                    if (lane == 0) { ws->l[sp] = l + idx; ws->r[sp] = r; ws->id[sp] = c + 1; }
+                    ++sp;
+                } else if (lane < 6) {
+                    const int d = lane >> 1, hi = lane & 1;
+                    T.nbbox[(size_t)(c + 1) * 6 + lane] = (d == cutfeat && hi == 0) ? cutval : (hi ? bhi(d) : blo(d));
+                }
+                // left child next: box = this box with high[cutfeat] = cutval
+                if (cutfeat == 0) b0h = cutval; else if (cutfeat == 1) b1h = cutval; else b2h = cutval;
+                r = l + idx;
+                id = c;
+                descend = true;
+            }
+#undef blo
+#undef bhi
+        }
+        if (descend) continue;
+        if (sp == 0) break;
+        --sp;
+        l = ws->l[sp]; r = ws->r[sp]; id = ws->id[sp];
+        b0l = ws->bb[sp][0]; b0h = ws->bb[sp][1]; b1l = ws->bb[sp][2]; b1h = ws->bb[sp][3]; b2l = ws->bb[sp][4]; b2h = ws->bb[sp][5];
+    }
+    if (mine) {   // the permuted window back into vAcc_ and the coordinate planes
+        T.vind[L0 + lane] = vi;
+        T.plane(0)[L0 + lane] = px; T.plane(1)[L0 + lane] = py; T.plane(2)[L0 + lane] = pz;
+    }
+}
+
 // buildIndex for scene s; called by every thread of a kExactThreads block.  n = cloud.pts.size().
 __device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = kExactThreads / 64;
@@ -303,6 +438,7 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
     __shared__ double red[kExactThreads / 64][6];
     __shared__ unsigned coop_cnt[kExactThreads / 64 + 1];
     __shared__ double coop_red[kExactThreads / 64];
+    __shared__ ExactSubLds sub[kExactThreads / 64];
     const BlockCoop gb{coop_cnt, coop_red};
     const WaveCoop gw{};
     for (int i = tid; i < n; i += kExactThreads) {  // init_vind + the coordinate planes in the same (identity) order
@@ -328,7 +464,7 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
         T.root_bbox[tid] = v;
         if (n > 0) T.nbbox[tid] = v;
     }
-    if (tid == 0 && n > 0) { T.left[0] = 0; T.right[0] = (unsigned)n; }
+    if (tid == 0 && n > 0) { T.left[0] = 0; T.right[0] = (unsigned)n; T.feat[0] = kExactTodo; }
     __threadfence_block();
     __syncthreads();
     while (head < tail) {  // one level of divideTree per round
@@ -341,8 +477,12 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
                 if (T.right[id] - T.left[id] > (unsigned)kExactBigNode) exact_process_node(gb, T, id, &n_nodes_lds, &overflow);
         __threadfence_block();
         __syncthreads();
-        for (int id = h + w; id < t; id += nw)
-            if (!look || T.right[id] - T.left[id] <= (unsigned)kExactBigNode) exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+        for (int id = h + w; id < t; id += nw) {
+            if (T.feat[id] != kExactTodo) continue;   // built by the wavefront that built its ancestor
+            const unsigned cnt = T.right[id] - T.left[id];
+            if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
+            else if (!look || cnt <= (unsigned)kExactBigNode) exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+        }
         __threadfence_block();
         __syncthreads();
         if (tid == 0) { head = t; tail = overflow ? t : n_nodes_lds; }
