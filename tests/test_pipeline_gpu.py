@@ -136,6 +136,59 @@ def test_pipeline_gang_equals_the_separate_calls(gang, n_frames):
     pl.close()
 
 
+@pytest.mark.parametrize("gang,n_slots,depth,seed", [(3, 3, 2, 0), (4, 2, 1, 1), (2, 4, 3, 2)])
+def test_pipeline_random_interleavings(gang, n_slots, depth, seed):
+    """Random sequences of submit / wait / query / drain on a ganged pipeline: every frame's controls (written to the caller's
+    row) equal the separate calls' whatever gets launched partly filled, and a ticket's buffers hold its frame after wait()."""
+    import torch
+    from avoid_mpc_amd.host import KdBatch, MpcBatch, Pipeline, step_batch
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne, pool = 3, 1500, 150, 5
+    frames = _frames(torch, prm, pool, S, n)
+    want = []
+    kd_o, kd_e = KdBatch(S, n), KdBatch(S, ne)
+    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
+    for fr in frames:
+        kd_o.build(fr["cl"]); kd_e.build(fr["ed"]); mpc.reset_warm_start()
+        ref = fr["ref"].clone()
+        o = step_batch(kd_o, kd_e, mpc, prm, fr["sq"], fr["px"], ref)
+        torch.cuda.synchronize()
+        want.append(dict(u=o["u"].cpu().numpy().copy(), flags=o["flags"].cpu().numpy().copy()))
+    rng = np.random.default_rng(seed)
+    pl = Pipeline(n_slots, S, n, ne, prm, queue_depth=depth, gang=gang)
+    n_ops = 70
+    rows = torch.full((n_ops, S, 4), float("nan"), dtype=torch.float64, device="cuda")
+    submitted = []          # (row, frame index, ticket, launch-independent order)
+    live = {}               # ticket -> frame index of the LAST frame submitted with that ticket
+    for op in range(n_ops):
+        r = rng.random()
+        if r < 0.7 or not submitted:
+            f = int(rng.integers(pool))
+            fr = frames[f]
+            t = pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"], u_out=rows[op])
+            assert 0 <= t < n_slots * gang
+            submitted.append((op, f, t))
+            live[t] = f
+        elif r < 0.85:
+            _, f, t = submitted[int(rng.integers(len(submitted)))]
+            pl.wait(t)
+            assert pl.lib.amk_pipeline_query(pl.h, t) == 1
+            if live[t] == f:   # nothing newer was submitted at that ticket: its buffers hold this frame
+                o = pl.outputs(t)
+                # (a newer frame of the same slot at another position may have run since: only this position is checked)
+                assert np.array_equal(o["u"], want[f]["u"]) and np.array_equal(o["flags"], want[f]["flags"]), (op, f, t)
+        elif r < 0.95:
+            _, _, t = submitted[int(rng.integers(len(submitted)))]
+            assert pl.lib.amk_pipeline_query(pl.h, t) in (0, 1)
+        else:
+            pl.drain()
+    pl.drain()
+    got = rows.cpu().numpy()
+    for row, f, _ in submitted:
+        assert np.array_equal(got[row], want[f]["u"]), (row, f)
+    pl.close()
+
+
 def test_pipeline_argument_errors():
     import torch  # noqa: F401  (one HIP runtime per process)
     lib = capi.load()
