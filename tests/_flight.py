@@ -1,0 +1,252 @@
+"""Closed-loop flight drivers (TEST INFRASTRUCTURE): the same flights on the CPU oracle, on the GPU through the C ABI's
+pipeline, and on the IPOPT-shaped emulation capped at the reference's 10 iterations.
+
+Everything around the step (world, frames, GetInitPath, clock model, command, vehicle) is avoid_mpc_amd/flight.py and is
+shared by the three drivers; what differs is who runs the step:
+
+  oracle_flights   oracle/kd_oracle.c + step_oracle.c + mpc_oracle.c (warm start kept inside the oracle's MPC object)
+  gpu_flights      amk_pipeline_submit(keep_warm_start = 1) on one slot per batch of flights          (needs a GPU)
+  ipopt_flights    the oracle's KD queries + oracle/ipopt_emul.py with max_iter = 10 as the Solve of HighLvlMpc.cpp:93-137
+
+Reference: AM/src/AvoidanceStateMachine.cpp:24-54,183-203,322-355,369-397; AM/src/HighLvlMpc.cpp:17-23,109-129.
+"""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from avoid_mpc_amd import flight, synth  # noqa: E402
+
+
+def make_prm(cfg="C2", **kw):
+    c = synth.CONFIGS[cfg]
+    return synth.MpcParams(T=c["T"], K=c["K"], **kw), c["n"]
+
+
+def _log_arrays(periods):
+    return dict(x=np.zeros((periods + 1, 10)), u=np.zeros((periods, 4)), flags=np.zeros((periods, 4), np.int32),
+                cmd=np.zeros((periods, 3)))
+
+
+def _oracle_flight(job):
+    seed, cfg, periods, n_points, world_kw = job
+    from tests import _oracle
+    prm, n = make_prm(cfg)
+    n = n_points or n
+    world = flight.FlightWorld(seed, prm, n, **world_kw)
+    x, ref = flight.initial_state(seed, prm)
+    mpc = _oracle.MpcOracle(prm.T, prm.dt, prm.K); mpc.configure(prm)
+    log = _log_arrays(periods)
+    log["x"][0] = x
+    for t in range(periods):
+        cloud, edge = world.frame(t)
+        kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
+        sq, px = flight.period_inputs(x[None], ref[None], prm)
+        r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
+        kd.close(); ke.close()
+        a = flight.command(r["u"][None], r["flags"][None], x[None], prm)
+        x = flight.apply_command(x[None], a, prm)[0]
+        log["x"][t + 1] = x; log["u"][t] = r["u"]; log["flags"][t] = r["flags"]; log["cmd"][t] = a[0]
+    mpc.close()
+    log["clearance"] = world.clearance(log["x"][:, 0:3])
+    return log
+
+
+def _stack(logs):
+    return {k: np.stack([l[k] for l in logs]) for k in logs[0]}
+
+
+def _pool_map(fn, jobs, workers):
+    workers = max(1, min(workers or (os.cpu_count() or 1), len(jobs)))
+    if workers == 1:
+        return [fn(j) for j in jobs]
+    # one BLAS / OpenMP thread per worker: W workers x (all cores) LAPACK threads is 100 x slower than W x 1
+    keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    old = {k: os.environ.get(k) for k in keys}
+    os.environ.update({k: "1" for k in keys})
+    try:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            return pool.map(fn, jobs, chunksize=1)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def usable_cores():
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return cores
+
+
+def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None):
+    """-> dict of arrays [F, ...]: x [F, periods + 1, 10], u, flags, cmd, clearance [F, periods + 1]"""
+    from tests import _oracle
+    _oracle.build_oracle()
+    jobs = [(int(s), cfg, periods, n_points, world_kw or {}) for s in seeds]
+    return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
+
+
+def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batch=None, tie_order=0, precision=64):
+    """The same flights through amk_pipeline_*: one slot per batch of flights, one submit(keep_warm_start) per period."""
+    import torch
+    from avoid_mpc_amd.host import Pipeline
+    prm, n = make_prm(cfg)
+    n = n_points or n
+    F = len(seeds)
+    B = batch or F
+    assert F % B == 0
+    nb = F // B
+    dev = torch.device("cuda", torch.cuda.current_device())
+    worlds = [flight.FlightWorld(int(s), prm, n, **(world_kw or {})) for s in seeds]
+    st = [flight.initial_state(int(s), prm) for s in seeds]
+    x = np.stack([a for a, _ in st]); ref = np.stack([b for _, b in st])
+    pl = Pipeline(nb, B, n, n // 10, prm, queue_depth=1, gang=1)
+    for i in range(nb):
+        pl.kd(i, 0).set_tie_order(tie_order); pl.kd(i, 1).set_tie_order(tie_order); pl.mpc(i).set_precision(precision)
+    logs = dict(x=np.zeros((F, periods + 1, 10)), u=np.zeros((F, periods, 4)), flags=np.zeros((F, periods, 4), np.int32),
+                cmd=np.zeros((F, periods, 3)))
+    logs["x"][:, 0] = x
+    for t in range(periods):
+        keep, tickets = [], []
+        sq, px = flight.period_inputs(x, ref, prm)
+        for b in range(nb):   # every batch of the period in flight, then collect
+            sl = slice(b * B, (b + 1) * B)
+            fr = [worlds[i].frame(t) for i in range(sl.start, sl.stop)]
+            bufs = (torch.from_numpy(np.stack([c for c, _ in fr])).to(dev), torch.from_numpy(np.stack([e for _, e in fr])).to(dev),
+                    torch.from_numpy(sq[sl]).to(dev), torch.from_numpy(px[sl]).to(dev), torch.from_numpy(ref[sl]).to(dev))
+            torch.cuda.synchronize()
+            keep.append(bufs)
+            tickets.append(pl.submit(*bufs, keep_warm_start=t > 0))
+        for b, tk in enumerate(tickets):
+            sl = slice(b * B, (b + 1) * B)
+            pl.wait(tk)
+            o = pl.outputs(tk)
+            ref[sl] = o["ref_path"]
+            a = flight.command(o["u"], o["flags"], x[sl], prm)
+            x[sl] = flight.apply_command(x[sl], a, prm)
+            logs["u"][sl, t] = o["u"]; logs["flags"][sl, t] = o["flags"]; logs["cmd"][sl, t] = a
+        logs["x"][:, t + 1] = x
+    pl.close()
+    logs["clearance"] = np.stack([w.clearance(logs["x"][i, :, 0:3]) for i, w in enumerate(worlds)])
+    return logs
+
+
+# ---- the reference's solver regime, emulated: IPOPT stopped after 10 iterations, primal warm start -------------------------------
+def _ipopt_flight(job):
+    seed, cfg, periods, n_points, world_kw, max_iter = job
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ipopt_emul as IE
+    from tests import _oracle
+    prm, n = make_prm(cfg)
+    n = n_points or n
+    N, K = prm.N, prm.K
+    world = flight.FlightWorld(seed, prm, n, **world_kw)
+    x, ref = flight.initial_state(seed, prm)
+    lbu = np.array([-prm.a_max_xy, -prm.a_max_xy, prm.a_min_z, -prm.a_max_yaw_dot])
+    ubu = np.array([prm.a_max_xy, prm.a_max_xy, prm.a_max_z, prm.a_max_yaw_dot])
+    tail = np.concatenate([prm.gain, prm.tau, prm.weights, [prm.radius]])   # HighLvlMpc.cpp:97-107
+    w0 = np.zeros(10 + 14 * N)                                              # mNlpW0, HighLvlMpc.cpp:26-27,35
+    log = _log_arrays(periods)
+    log["x"][0] = x
+    log["ipopt_iters"] = np.zeros(periods, np.int32); log["ipopt_status"] = np.zeros((periods, prm.max_iter), np.int32) - 1
+    lib = _oracle.load_oracle()
+    for t in range(periods):
+        cloud, edge = world.frame(t)
+        kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
+        sq, px = flight.period_inputs(x[None], ref[None], prm)
+        # TASK branch (:322-355) with the emulated solver in the place of ObstacleAvoidanceMPC::Solve: the oracle's step with
+        # mpc_max_iter = 1 would hide the solver, so the loop is restated here on the oracle's KD queries
+        u = np.zeros(4); is_safety = 1; solves = 0; iters = 0
+        for it in range(prm.max_iter):
+            is_safety = 1
+            p1 = ref[0, 0:3]
+            i1, d1, _ = kd.search(p1, 1)
+            nd = np.sqrt(d1[0]) if len(d1) else np.sqrt(np.finfo(np.float64).max)
+            if not (nd > prm.safety_distance):
+                ie, de, pe = ke.search(p1, 1)
+                if len(ie) == 0:
+                    is_safety = 0
+                else:
+                    ref[0, 0:3] = pe[0]
+            obst = np.full((N, K, 3), 10000.0); need = False
+            for i in range(N):
+                ii, dd, pp = kd.search(ref[i, 0:3], K)
+                obst[i, :len(ii)] = pp
+                if len(ii) == 0 or np.sqrt(dd[0]) <= prm.safety_distance:
+                    need = True
+            if not need and it > 0 and is_safety:
+                break
+            tg = ref[N - 1].copy()
+            tg[0] += max(0.0, prm.speed * prm.T - max(0.0, tg[0] - px[0])); tg[1] = 0.0
+            P = np.concatenate([sq[0, it], ref.reshape(-1), obst.reshape(-1), tg, tail])
+            nlp = IE.ShootingNlp(P, N, K, prm.dt, lbu, ubu)
+            res = IE.solve(nlp, w0, max_iter=max_iter)
+            w0 = res["x"]; u = w0[10:14].copy()
+            log["ipopt_status"][t, it] = res["status"]; iters += res["iters"]; solves += 1
+            ref[:] = w0[:14 * N].reshape(N, 14)[:, :10]
+        kd.close(); ke.close()
+        flags = np.array([is_safety, solves, 0, iters], np.int32)
+        a = flight.command(u[None], flags[None], x[None], prm)
+        x = flight.apply_command(x[None], a, prm)[0]
+        log["x"][t + 1] = x; log["u"][t] = u; log["flags"][t] = flags; log["cmd"][t] = a[0]; log["ipopt_iters"][t] = iters
+    log["clearance"] = world.clearance(log["x"][:, 0:3])
+    del lib
+    return log
+
+
+def ipopt_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None, max_iter=10):
+    jobs = [(int(s), cfg, periods, n_points, world_kw or {}, max_iter) for s in seeds]
+    return _stack(_pool_map(_ipopt_flight, jobs, workers or usable_cores()))
+
+
+# ---- comparison ----------------------------------------------------------------------------------------------------------------
+def compare(a, b, pos_tol=1e-6):
+    """Period-by-period comparison of two sets of flights (dicts of [F, ...] arrays).  A flight SEPARATES at the first period
+    whose flags differ or whose position differs by more than pos_tol.  -> dict of statistics"""
+    F, P = a["u"].shape[0], a["u"].shape[1]
+    dpos = np.abs(a["x"][:, :, 0:3] - b["x"][:, :, 0:3]).max(axis=2)        # [F, P + 1]
+    flag_diff = np.any(a["flags"] != b["flags"], axis=2)                    # [F, P]
+    sep = np.full(F, -1)
+    for f in range(F):
+        bad = np.nonzero(flag_diff[f] | (dpos[f, 1:] > pos_tol))[0]
+        if bad.size:
+            sep[f] = bad[0]
+    together = sep < 0
+    dpos_before = np.array([dpos[f, :(sep[f] + 1 if sep[f] >= 0 else P + 1)].max() for f in range(F)])
+    return dict(flights=F, periods=P, separated=int((~together).sum()), separation_period=sep,
+                dpos_max_while_together=float(dpos_before.max()), dpos_final=dpos[:, -1],
+                dpos_final_max_separated=float(dpos[~together, -1].max()) if (~together).any() else 0.0,
+                du_max_together=float(np.abs(a["u"] - b["u"])[together].max()) if together.any() else None)
+
+
+def flight_stats(log, prm, con_dt=None):
+    """Clearance / collision statistics of a set of flights: clearance = horizontal distance from the vehicle's centre to the
+    nearest cylinder surface; a flight collides when it drops below the drone radius."""
+    cl = log["clearance"].min(axis=1)
+    fl = log["flags"]
+    radius = prm.radius
+    t = np.arange(log["x"].shape[1])
+    lag = log["x"][:, :, 0] - log["x"][:, :1, 0] - prm.speed * (con_dt or prm.dt) * t[None]   # flown x against the frames' nominal x
+    return dict(flights=int(cl.size), min_clearance_median=float(np.median(cl)), min_clearance_min=float(cl.min()),
+                collided=int((cl < radius).sum()), hit_surface=int((cl < 0).sum()),
+                unsafe_periods=int((fl[:, :, 0] == 0).sum()), solves_per_period=float(fl[:, :, 1].mean()),
+                iters_per_period=float(fl[:, :, 3].mean()), capped_periods=int((fl[:, :, 2] > 0).sum()),
+                x_final_mean=float(log["x"][:, -1, 0].mean()), x_behind_nominal_max=float(-lag.min()),
+                x_ahead_of_nominal_max=float(lag.max()))
