@@ -38,9 +38,9 @@ SYMBOLS = [
     "amk_mpc_eval_gamma_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
     "amk_pipeline_create", "amk_pipeline_destroy", "amk_pipeline_slots", "amk_pipeline_gang", "amk_pipeline_mpc", "amk_pipeline_kd",
     "amk_pipeline_stream", "amk_pipeline_submit", "amk_pipeline_wait", "amk_pipeline_query", "amk_pipeline_drain",
-    "amk_pipeline_outputs",
+    "amk_pipeline_outputs", "amk_pipeline_wait_stream",
     "amk_shard_scene_range", "amk_shard_unique_id", "amk_shard_create", "amk_shard_destroy", "amk_shard_rank",
-    "amk_shard_world", "amk_shard_last_rccl_error", "amk_shard_gather", "amk_shard_gather_u", "amk_shard_max",
+    "amk_shard_world", "amk_shard_last_rccl_error", "amk_shard_gather", "amk_shard_gather_u", "amk_shard_max", "amk_shard_padded_count",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -55,18 +55,26 @@ class StepParams(C.Structure):
                 ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
 
 
+class TaskParams(C.Structure):
+    """amk_task_params"""
+    _fields_ = [("decay", C.c_double), ("iter_time", C.c_double), ("farest_point", C.c_double), ("height", C.c_double),
+                ("slow_down_kp", C.c_double), ("slow_down_kd", C.c_double), ("a_max_xy", C.c_double), ("a_max_z", C.c_double),
+                ("use_odom_est", C.c_int), ("reserved", C.c_int)]
+
+
 class PipelineConfig(C.Structure):
     """amk_pipeline_config"""
     _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
                 ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("queue_depth", C.c_int),
-                ("gang", C.c_int), ("step", StepParams)]
+                ("gang", C.c_int), ("step", StepParams), ("task", TaskParams)]
 
 
 class PipelineFrame(C.Structure):
     """amk_pipeline_frame"""
     _fields_ = [("d_cloud", C.c_void_p), ("d_cloud_counts", C.c_void_p), ("d_edge", C.c_void_p), ("d_edge_counts", C.c_void_p),
                 ("point_stride", C.c_int), ("keep_warm_start", C.c_int), ("d_state_quad", C.c_void_p), ("d_pos_x", C.c_void_p),
-                ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p)]
+                ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p), ("d_odom", C.c_void_p), ("odom_age", C.c_double),
+                ("d_cmd_out", C.c_void_p), ("input_ready", C.c_void_p)]
 
 
 class FrameCamera(C.Structure):
@@ -163,6 +171,8 @@ def load():
         "amk_pipeline_stream": (vp, [vp, i]),
         "amk_pipeline_submit": (i, [vp, C.POINTER(PipelineFrame), C.POINTER(i)]),
         "amk_pipeline_wait": (i, [vp, i]),
+        "amk_pipeline_wait_stream": (i, [vp, i, vp]),
+        "amk__pipeline_inject_failure": (i, [vp, i]),   # internal (tests)
         "amk_pipeline_query": (i, [vp, i]),
         "amk_pipeline_drain": (i, [vp]),
         "amk_pipeline_outputs": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
@@ -176,6 +186,7 @@ def load():
         "amk_shard_gather": (i, [vp, vp, ll, vp, vp]),
         "amk_shard_gather_u": (i, [vp, vp, i, vp, vp]),
         "amk_shard_max": (i, [vp, vp, i, vp]),
+        "amk_shard_padded_count": (i, [i, i]),
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
         "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
         "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
@@ -229,6 +240,21 @@ def dptr(t):
     if not t.is_contiguous():
         raise AmkError("expected a contiguous tensor")
     return C.c_void_p(t.data_ptr())
+
+
+class _DevArray:
+    """A raw device pointer dressed as a CUDA-array-interface object, so that torch can alias it (no copy)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(v) for v in shape), "typestr": typestr, "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def tensor_from_ptr(ptr, shape, dtype):
+    """torch tensor aliasing device memory owned by the library (the pointer must outlive the tensor)."""
+    import torch
+    typestr = {torch.float64: "<f8", torch.float32: "<f4", torch.int32: "<i4"}[dtype]
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=torch.device("cuda", torch.cuda.current_device()))
 
 
 def stream_ptr(stream=None):

@@ -23,6 +23,7 @@
 // the node is split.  Round 2 (wave per node, gathers): 23 ms per 256 x 50k-point build, now 7 ms (0.4 ms at the reference's 3072 points):
 // DESIGN.md section 4.
 #pragma once
+#include <cstring>
 #include "kd_grid.h"
 
 namespace amk {
@@ -680,6 +681,7 @@ __device__ __forceinline__ int exact_knn_wave(const ExactTree &T, double qx, dou
 // host side: the batch pointers of a handle whose reference-shaped tree exists (amk_common.h: amk_kd)
 inline amk::ExactPtrs amk_exact_ptrs(amk_kd *kd) {
     amk::ExactPtrs ep;
+    std::memset(&ep, 0, sizeof ep);   // padding bytes too: step_frames.hip compares tables of these bytewise
     ep.x = kd->x.p; ep.y = kd->y.p; ep.z = kd->z.p; ep.cap = kd->cap;
     ep.vind = kd->ex_vind.p; ep.left = kd->ex_left.p; ep.right = kd->ex_right.p; ep.sa = kd->ex_sa.p; ep.sb = kd->ex_sb.p;
     ep.pc = kd->ex_pc.p; ep.pstride = (size_t)kd->n_scenes * kd->cap;

@@ -30,6 +30,10 @@ struct amk_pipeline {
         const double *ref_path_init;
         double *u_out;
         int keep_warm_start;
+        hipEvent_t input_ready;             // the caller's event (or null): the slot's stream waits for it before reading the inputs
+        const double *odom;                 // TASK mode (amk_pipeline_frame.d_odom): prologue / epilogue on the device
+        double odom_age;
+        double *cmd_out;
     };
     struct Slot {
         hipStream_t stream = nullptr;
@@ -42,11 +46,14 @@ struct amk_pipeline {
         amk::DevBuf<int> flags;
         std::vector<Staged> open;       // frames staged since the last launch (< gang)
         int point_stride = 3;
+        int fail_status = AMK_OK;       // the slot's newest launch failed half-way with this status: its frames were dropped, their
+                                        // results are undefined; reported by that submit() and by wait() / drain() until the next launch
     };
     int depth = 1, gang = 1;
     std::vector<Slot> slots;
     int next = 0;
     long long submitted = 0;
+    int inject_failure = 0;             // tests only (amk__pipeline_inject_failure): the next launch fails at this stage
 };
 
 namespace {
@@ -62,24 +69,99 @@ struct GatherArgs {
 __global__ __launch_bounds__(256) void pipeline_gather_kernel(const GatherArgs a) {
     const int g = blockIdx.y;
     const int stride = gridDim.x * 256, t0 = blockIdx.x * 256 + threadIdx.x;
-    if (a.sq_dst) {
+    if (a.sq_dst && a.sq[g]) {
         for (int i = t0; i < a.n_sq; i += stride) a.sq_dst[(size_t)g * a.n_sq + i] = a.sq[g][i];
         for (int i = t0; i < a.n_px; i += stride) a.px_dst[(size_t)g * a.n_px + i] = a.px[g][i];
     }
-    for (int i = t0; i < a.n_ref; i += stride) a.ref_dst[(size_t)g * a.n_ref + i] = a.ref[g][i];
+    if (a.ref[g])   // (a TASK-mode frame's path is the prologue kernel's business)
+        for (int i = t0; i < a.n_ref; i += stride) a.ref_dst[(size_t)g * a.n_ref + i] = a.ref[g][i];
     if (!a.keep_warm_start[g])
         for (int i = t0; i < a.n_w0; i += stride) a.w0[(size_t)g * a.n_w0 + i] = 0.0;
 }
-// ... and the controls of every frame to where its caller wants them
+// ... and the controls of every frame to where its caller wants them; for TASK-mode frames also what the node publishes:
+// PubCmd(u) when isSafety, else PubSlowDownCmd (AvoidanceStateMachine.cpp:345-350,369-397)
 struct ScatterArgs {
     double *dst[AMK_PIPELINE_MAX_GANG];   // NULL: stays in the slot's buffer only
+    double *cmd[AMK_PIPELINE_MAX_GANG];   // NULL: no command wanted
+    const double *odom[AMK_PIPELINE_MAX_GANG];
     const double *u;
-    int n_u;
+    const int *flags;
+    int n_u, S;
+    double kp, kd, a_max_xy, a_max_z;
 };
 __global__ __launch_bounds__(256) void pipeline_scatter_kernel(const ScatterArgs a) {
+#pragma clang fp contract(off)   // the command is compared bit for bit with the host twin (avoid_mpc_amd/flight.py: command)
     const int g = blockIdx.y;
-    if (!a.dst[g]) return;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_u; i += gridDim.x * 256) a.dst[g][i] = a.u[(size_t)g * a.n_u + i];
+    if (a.dst[g] && a.dst[g] != a.u + (size_t)g * a.n_u)
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.n_u; i += gridDim.x * 256) a.dst[g][i] = a.u[(size_t)g * a.n_u + i];
+    if (a.cmd[g]) {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < a.S * 3; i += gridDim.x * 256) {
+            const int s = i / 3, c = i - 3 * s;
+            const size_t gs = (size_t)g * a.S + s;
+            double v;
+            if (a.flags[gs * 4 + 0]) v = a.u[gs * 4 + c];                                  // PubCmd :369-378
+            else {                                                                         // PubSlowDownCmd :379-397
+                const double *o = a.odom[g] + (size_t)s * 10;
+                v = -o[4 + c] * a.kp - o[7 + c] * a.kd + (c == 2 ? 9.8 : 0.0);
+                const double lim = c == 2 ? a.a_max_z : a.a_max_xy;
+                v = fmax(-lim, fmin(lim, v));
+            }
+            a.cmd[g][i] = v;
+        }
+    }
+}
+
+// TASK-mode prologue (AvoidanceStateMachine.cpp:24-54,183-203,322-330): one wavefront per scene runs GetInitPath on the slot's
+// own mRefPath (optionally re-initialised from the caller's first) and GetCurStateQuad for every re-plan pass.
+struct PrologueArgs {
+    const double *odom[AMK_PIPELINE_MAX_GANG];       // NULL: not a TASK-mode frame
+    const double *ref_init[AMK_PIPELINE_MAX_GANG];   // NULL: the slot's own path
+    double age[AMK_PIPELINE_MAX_GANG];
+    double *sq_dst, *px_dst, *ref_dst;               // [G][S][mi][10], [G][S], [G][S][N][10]
+    int S, N, mi;
+    double decay, iter_time, farest, height, speed, T;
+    int use_odom_est;
+};
+__global__ __launch_bounds__(256) void pipeline_task_prologue_kernel(const PrologueArgs a) {
+#pragma clang fp contract(off)   // bit-identical to the host twins (avoid_mpc_amd/fsm.py, include/avoid_mpc_amd/avoidance_step.hpp)
+    const int g = blockIdx.y;
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const bool live = a.odom[g] && s < a.S;
+    const size_t gs = (size_t)g * a.S + (live ? s : 0);
+    const double *o = live ? a.odom[g] + (size_t)s * 10 : nullptr;
+    double *ref = a.ref_dst + gs * a.N * 10;
+    const double *src = (live && a.ref_init[g]) ? a.ref_init[g] + (size_t)s * a.N * 10 : ref;
+    // GetInitPath: mRefPath[i] = mRefPath[i + 1] with z = height, i < N - 1; the last point is the goal.  Every element is read
+    // before any is written (the shift runs in place).
+    const int n_shift = (a.N - 1) * 10;
+    double v[5];   // N <= AMK_MAX_HORIZON = 32: 310 elements <= 5 x 64
+    for (int k = 0; k < 5; ++k) {
+        const int e = k * 64 + lane;
+        v[k] = (live && e < n_shift) ? src[e + 10] : 0.0;
+    }
+    __syncthreads();
+    if (live) {
+        for (int k = 0; k < 5; ++k) {
+            const int e = k * 64 + lane;
+            if (e < n_shift) ref[e] = (e % 10 == 2) ? a.height : v[k];
+        }
+        if (lane < 10) {
+            const double goalx = fmin(a.speed * a.T + o[0], a.farest);
+            ref[n_shift + lane] = lane == 0 ? goalx : (lane == 2 ? a.height : (lane == 4 ? a.speed : 0.0));
+        }
+        // GetCurStateQuad(start + decay): pass i starts odom_age + decay + i * iter_time after the odometry stamp
+        for (int e = lane; e < a.mi * 10; e += 64) {
+            const int i = e / 10, j = e - 10 * i;
+            const double dt = a.age[g] + a.decay + i * a.iter_time;
+            double r;
+            if (j < 3) r = a.use_odom_est ? o[j] + o[4 + j] * dt + 0.5 * o[7 + j] * dt * dt : o[j];
+            else if (j == 3) r = o[3];
+            else if (j < 7) r = a.use_odom_est ? o[j] + o[j + 3] * dt : o[j];
+            else r = o[j];
+            a.sq_dst[(gs * a.mi + i) * 10 + j] = r;
+        }
+        if (lane == 0) a.px_dst[gs] = o[0];   // mPos.x() of GetRefStates (:251): the odometry position, not the extrapolated one
+    }
 }
 
 // Waits for a slot's launch.  hipEventSynchronize parks the thread on an HSA signal; with AMK_PIPELINE_SPIN=1 the thread polls
@@ -104,18 +186,27 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     const amk_pipeline_config &c = p->cfg;
     const int G = p->gang, S = c.n_scenes, N = amk_mpc_horizon(s.mpc), mi = c.step.mpc_max_iter;
     const int filled = (int)s.open.size();
+    if (filled > G || filled > AMK_PIPELINE_MAX_GANG) return AMK_ERR_INVALID_ARG;   // (submit() never stages more than a gang)
     hipStream_t st = s.stream;
+    for (const auto &f : s.open)   // inputs produced on the caller's streams: ordered on the device, not by the host
+        if (f.input_ready) AMK_HIP(hipStreamWaitEvent(st, f.input_ready, 0));
     const float *cl[AMK_PIPELINE_MAX_GANG], *ed[AMK_PIPELINE_MAX_GANG];
     const int *cc[AMK_PIPELINE_MAX_GANG], *ec[AMK_PIPELINE_MAX_GANG];
     GatherArgs ga{};
+    PrologueArgs pa{};
+    bool any_task = false;
     for (int g = 0; g < filled; ++g) {
         const amk_pipeline::Staged &f = s.open[g];
         cl[g] = f.cloud; ed[g] = f.edge; cc[g] = f.cloud_counts; ec[g] = f.edge_counts;
-        ga.sq[g] = f.state_quad; ga.px[g] = f.pos_x; ga.ref[g] = f.ref_path_init;
+        const bool task = f.odom != nullptr;
+        any_task = any_task || task;
+        ga.sq[g] = task ? nullptr : f.state_quad; ga.px[g] = task ? nullptr : f.pos_x; ga.ref[g] = task ? nullptr : f.ref_path_init;
+        pa.odom[g] = f.odom; pa.ref_init[g] = f.ref_path_init; pa.age[g] = f.odom_age;
         // fresh frame: mRefPath after GetInitPath, zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
         ga.keep_warm_start[g] = f.keep_warm_start;
     }
-    ga.sq_dst = G > 1 ? s.state_quad.p : nullptr; ga.px_dst = G > 1 ? s.pos_x.p : nullptr;
+    const bool own_inputs = G > 1 || any_task;   // the step reads the slot's contiguous copies (gang 1 without TASK mode: the caller's)
+    ga.sq_dst = own_inputs ? s.state_quad.p : nullptr; ga.px_dst = own_inputs ? s.pos_x.p : nullptr;
     ga.ref_dst = s.ref_path.p; ga.w0 = s.mpc->w0.p;
     ga.n_sq = S * mi * 10; ga.n_px = S; ga.n_ref = S * N * 10; ga.n_w0 = S * s.mpc->nx;
     {
@@ -125,22 +216,37 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         hipLaunchKernelGGL(pipeline_gather_kernel, dim3(bx, filled), dim3(256), 0, st, ga);
         AMK_HIP(hipGetLastError());
     }
+    if (any_task) {
+        const amk_task_params &t = c.task;
+        pa.sq_dst = s.state_quad.p; pa.px_dst = s.pos_x.p; pa.ref_dst = s.ref_path.p;
+        pa.S = S; pa.N = N; pa.mi = mi;
+        pa.decay = t.decay; pa.iter_time = t.iter_time > 0 ? t.iter_time : t.decay; pa.farest = t.farest_point; pa.height = t.height;
+        pa.speed = c.step.speed; pa.T = c.T; pa.use_odom_est = t.use_odom_est;
+        hipLaunchKernelGGL(pipeline_task_prologue_kernel, dim3((S + 3) / 4, filled), dim3(256), 0, st, pa);
+        AMK_HIP(hipGetLastError());
+    }
     int rc;
+    if (p->inject_failure == 1) { p->inject_failure = 0; return AMK_ERR_HIP; }
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
     if (G == 1) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
     else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st);
     if (rc != AMK_OK) return rc;
-    double *u = (G == 1 && s.open[0].u_out) ? s.open[0].u_out : s.u.p;
-    const double *sq = G == 1 ? s.open[0].state_quad : s.state_quad.p, *px = G == 1 ? s.open[0].pos_x : s.pos_x.p;
+    if (p->inject_failure == 2) { p->inject_failure = 0; return AMK_ERR_HIP; }
+    double *u = (G == 1 && s.open[0].u_out && !any_task) ? s.open[0].u_out : s.u.p;
+    const double *sq = own_inputs ? s.state_quad.p : s.open[0].state_quad, *px = own_inputs ? s.pos_x.p : s.open[0].pos_x;
     s.mpc->run_scenes = filled * S;
     rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
     s.mpc->run_scenes = 0;
     if (rc != AMK_OK) return rc;
-    if (G > 1) {
+    if (G > 1 || any_task) {
         ScatterArgs sa{};
         bool any = false;
-        for (int g = 0; g < filled; ++g) { sa.dst[g] = s.open[g].u_out; any = any || sa.dst[g]; }
-        sa.u = s.u.p; sa.n_u = S * 4;
+        for (int g = 0; g < filled; ++g) {
+            sa.dst[g] = s.open[g].u_out; sa.cmd[g] = s.open[g].odom ? s.open[g].cmd_out : nullptr; sa.odom[g] = s.open[g].odom;
+            any = any || sa.dst[g] || sa.cmd[g];
+        }
+        sa.u = s.u.p; sa.flags = s.flags.p; sa.n_u = S * 4; sa.S = S;
+        sa.kp = c.task.slow_down_kp; sa.kd = c.task.slow_down_kd; sa.a_max_xy = c.task.a_max_xy; sa.a_max_z = c.task.a_max_z;
         if (any) {
             hipLaunchKernelGGL(pipeline_scatter_kernel, dim3((sa.n_u + 255) / 256 > 16 ? 16 : (sa.n_u + 255) / 256, filled), dim3(256), 0, st, sa);
             AMK_HIP(hipGetLastError());
@@ -150,6 +256,24 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     ++s.count;
     s.open.clear();
     return AMK_OK;
+}
+
+// launch_gang with the slot left consistent whatever happens: on a failure half-way (a build or a step that could not be
+// launched) the staged frames are DROPPED -- a later submit() starts a new gang instead of re-launching a half-consumed one,
+// and wait() / drain() have an event to wait for (what did get enqueued stays ordered on the slot's stream) and report the
+// failure.  The round robin moves on either way.
+int launch_slot(amk_pipeline *p, amk_pipeline::Slot &s) {
+    if (s.open.empty()) return AMK_OK;
+    const int st = launch_gang(p, s);
+    if (st != AMK_OK) {
+        s.open.clear();
+        s.mpc->run_scenes = 0;
+        (void)hipEventRecord(s.done[s.count % p->depth], s.stream);
+        ++s.count;
+    }
+    s.fail_status = st;
+    if (&s == &p->slots[p->next]) p->next = (p->next + 1) % (int)p->slots.size();
+    return st;
 }
 }  // namespace
 
@@ -192,7 +316,7 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
             st = amk::hip_fail(e);
             break;
         }
-        if (p->gang > 1 && ((e = s.state_quad.alloc(S * cfg->step.mpc_max_iter * 10)) != hipSuccess || (e = s.pos_x.alloc(S)) != hipSuccess)) {
+        if ((e = s.state_quad.alloc(S * cfg->step.mpc_max_iter * 10)) != hipSuccess || (e = s.pos_x.alloc(S)) != hipSuccess) {
             st = amk::hip_fail(e);
             break;
         }
@@ -235,12 +359,14 @@ void *amk_pipeline_stream(amk_pipeline *p, int slot) {
 }
 
 int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticket_out) {
-    if (!p || !f || !f->d_cloud || !f->d_edge || !f->d_state_quad || !f->d_pos_x || !f->d_ref_path_init)
-        return AMK_ERR_INVALID_ARG;
+    if (!p || !f || !f->d_cloud || !f->d_edge) return AMK_ERR_INVALID_ARG;
+    if (!f->d_odom && (!f->d_state_quad || !f->d_pos_x || !f->d_ref_path_init)) return AMK_ERR_INVALID_ARG;
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
     const int stride = f->point_stride ? f->point_stride : 3;
+    if (stride != 3 && stride != 4) return AMK_ERR_INVALID_ARG;
     if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
+    if ((int)s.open.size() >= p->gang) return AMK_ERR_INVALID_ARG;                  // (cannot happen: a full gang is launched at once)
     // Flow control.  A slot's launches are ordered by its stream, so queuing the next one behind a running one is safe (same
     // handles, same workspaces, in order); submit() only blocks when `depth` launches of this slot are still unfinished --
     // the event about to be re-recorded belongs to the launch issued `depth` launches ago.  depth 1 = at most one launch per
@@ -254,15 +380,11 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     s.point_stride = stride;
     // staged: the frame's inputs are read when its gang is launched (they stay the caller's until then)
     s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
-                                           f->d_ref_path_init, f->d_u_out, f->keep_warm_start});
+                                           f->d_ref_path_init, f->d_u_out, f->keep_warm_start, (hipEvent_t)f->input_ready,
+                                           f->d_odom, f->odom_age, f->d_cmd_out});
     if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
-    const bool launch = (int)s.open.size() == p->gang;
-    if (launch) {
-        const int st = launch_gang(p, s);
-        if (st != AMK_OK) return st;
-        p->next = (si + 1) % ns;
-    }
+    if ((int)s.open.size() == p->gang) return launch_slot(p, s);
     return AMK_OK;
 }
 
@@ -270,16 +392,26 @@ int amk_pipeline_wait(amk_pipeline *p, int ticket) {
     if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return AMK_ERR_INVALID_ARG;
     auto &s = p->slots[ticket % (int)p->slots.size()];
     if (!s.open.empty()) {   // a partly filled gang: launch it now
-        const int st = launch_gang(p, s);
+        const int st = launch_slot(p, s);
         if (st != AMK_OK) return st;
-        if (&s == &p->slots[p->next]) p->next = (p->next + 1) % (int)p->slots.size();
     }
     if (s.waited < s.count) {   // the newest event implies all earlier ones (in-order stream)
         const int ws = wait_event(s.done[(s.count - 1) % p->depth]);
         if (ws != AMK_OK) return ws;
         s.waited = s.count;
     }
-    return AMK_OK;
+    return s.fail_status;   // AMK_OK unless the slot's newest launch failed half-way (its frames were dropped)
+}
+
+int amk_pipeline_wait_stream(amk_pipeline *p, int ticket, void *stream) {
+    if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return AMK_ERR_INVALID_ARG;
+    auto &s = p->slots[ticket % (int)p->slots.size()];
+    if (!s.open.empty()) {
+        const int st = launch_slot(p, s);
+        if (st != AMK_OK) return st;
+    }
+    if (s.count > 0) AMK_HIP(hipStreamWaitEvent((hipStream_t)stream, s.done[(s.count - 1) % p->depth], 0));
+    return s.fail_status;
 }
 
 int amk_pipeline_query(amk_pipeline *p, int ticket) {  // 1 = finished (or idle), 0 = still running or staged, -1 error
@@ -294,16 +426,24 @@ int amk_pipeline_query(amk_pipeline *p, int ticket) {  // 1 = finished (or idle)
 
 int amk_pipeline_drain(amk_pipeline *p) {
     if (!p) return AMK_ERR_INVALID_ARG;
+    int first_error = AMK_OK;   // every slot is launched and waited for even when one fails: drain() leaves nothing in flight
     for (auto &s : p->slots) {   // every open gang first: a launch must not wait for the slots before it to finish
         if (s.open.empty()) continue;
-        const int st = launch_gang(p, s);
-        if (st != AMK_OK) return st;
-        if (&s == &p->slots[p->next]) p->next = (p->next + 1) % (int)p->slots.size();
+        const int st = launch_slot(p, s);
+        if (st != AMK_OK && first_error == AMK_OK) first_error = st;
     }
     for (int i = 0; i < (int)p->slots.size(); ++i) {
         const int st = amk_pipeline_wait(p, i);
-        if (st != AMK_OK) return st;
+        if (st != AMK_OK && first_error == AMK_OK) first_error = st;
     }
+    return first_error;
+}
+
+// tests only: the next launch of this pipeline fails at stage 1 (after the gather of the small inputs, before the index
+// builds) or 2 (after the builds, before the control step) with AMK_ERR_HIP
+int amk__pipeline_inject_failure(amk_pipeline *p, int stage) {
+    if (!p || stage < 0 || stage > 2) return AMK_ERR_INVALID_ARG;
+    p->inject_failure = stage;
     return AMK_OK;
 }
 

@@ -71,6 +71,11 @@ int amk_shard_scene_range(int rank, int world, int total, int *first, int *count
     return AMK_OK;
 }
 
+int amk_shard_padded_count(int world, int total) {   // what every rank passes to the gathers: ncclAllGather needs equal counts
+    if (world <= 0 || total < 0) return -1;
+    return (total + world - 1) / world;
+}
+
 int amk_shard_unique_id(char *id_out) {
     static_assert(sizeof(ncclUniqueId) == AMK_SHARD_ID_BYTES, "ncclUniqueId size");
     if (!id_out) return AMK_ERR_INVALID_ARG;

@@ -368,8 +368,9 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         for (int f = 0; f < F; ++f) {
             h->use_obs[f] = obstacle[f]->tie_order && obstacle[f]->ex_valid;
             h->use_edge[f] = edge[f]->tie_order && edge[f]->ex_valid;
-            if (h->use_obs[f]) h->obs[f] = amk_exact_ptrs(obstacle[f]);
-            if (h->use_edge[f]) h->edge[f] = amk_exact_ptrs(edge[f]);
+            // bytewise copies of zero-filled structs: the table is compared bytewise below, padding included
+            if (h->use_obs[f]) { const ExactPtrs t = amk_exact_ptrs(obstacle[f]); std::memcpy(&h->obs[f], &t, sizeof t); }
+            if (h->use_edge[f]) { const ExactPtrs t = amk_exact_ptrs(edge[f]); std::memcpy(&h->edge[f], &t, sizeof t); }
             any_exact |= h->use_obs[f] || h->use_edge[f];
         }
         if (any_exact) {

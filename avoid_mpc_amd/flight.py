@@ -160,3 +160,66 @@ def apply_command(x, a_cmd, prm, con_dt=None):
     (:376) holds the heading, so yaw_dot = 0."""
     uu = np.concatenate([a_cmd, np.zeros((a_cmd.shape[0], 1))], axis=1)
     return plant_step(x, uu, prm.tau, prm.dt if con_dt is None else con_dt)
+
+
+class FlightWorldsTorch:
+    """S flights' worlds and frames generated ON the device (bench.py --workload flight: frames are made before the clock starts
+    and stay resident in HBM).  The scene model of FlightWorld -- vertical cylinders along a corridor, a window of surface points
+    around the nominal position resampled every period, ground returns, silhouette points as the edge cloud -- on torch's random
+    stream (values differ from the numpy generator's; the drivers that compare GPU and CPU flights hand the SAME frames to
+    both)."""
+
+    def __init__(self, S, n_points, prm, seed, device, cyl_per_m=1.5, length=80.0, x_first=8.0, back=6.0, ahead=30.0,
+                 ground_frac=0.15, con_dt=None):
+        import torch
+        self.S, self.n, self.prm, self.seed, self.dev = int(S), int(n_points), prm, int(seed), device
+        self.back, self.ahead, self.ground_frac = float(back), float(ahead), float(ground_frac)
+        self.con_dt = prm.dt if con_dt is None else float(con_dt)
+        g = torch.Generator(device=device); g.manual_seed(self.seed)
+        self.ncyl = max(1, int(round(cyl_per_m * (length - x_first))))
+        r = lambda: torch.rand((self.S, self.ncyl), generator=g, device=device, dtype=torch.float64)
+        self.cx = torch.sort(x_first + (length - x_first) * r(), dim=1).values.contiguous()
+        self.cy = -8.0 + 16.0 * r()
+        self.cr = 0.1 + 0.4 * r()
+
+    def x_nom(self, t):
+        return self.prm.speed * self.con_dt * t
+
+    def frame(self, t):
+        """-> (cloud float32 [S, n, 3], edge float32 [S, n // 10, 3]) of period t."""
+        import math
+        import torch
+        S, n, ne, dev = self.S, self.n, self.n // 10, self.dev
+        g = torch.Generator(device=dev); g.manual_seed(self.seed * 1000003 + 7919 * int(t) + 1)
+        rnd = lambda *shape: torch.rand(shape, generator=g, device=dev, dtype=torch.float32)
+        xn = self.x_nom(t)
+        lo, hi = xn - self.back, xn + self.ahead
+        lo_i = torch.searchsorted(self.cx, torch.full((S, 1), lo, device=dev, dtype=torch.float64))
+        hi_i = torch.searchsorted(self.cx, torch.full((S, 1), hi, device=dev, dtype=torch.float64), right=True)
+        cnt = (hi_i - lo_i).clamp_(min=1)
+        n_g = int(self.ground_frac * n); n_c = n - n_g
+        ci = (lo_i + (rnd(S, n_c) * cnt).long()).clamp_(max=self.ncyl - 1)
+        th = 2.0 * math.pi * rnd(S, n_c)
+        gx, gy, gr = (v.gather(1, ci).float() for v in (self.cx, self.cy, self.cr))
+        on_cyl = torch.stack([gx + gr * torch.cos(th), gy + gr * torch.sin(th), 4.0 * rnd(S, n_c)], dim=2)
+        ground = torch.stack([lo + (hi - lo) * rnd(S, n_g), -8.0 + 16.0 * rnd(S, n_g), torch.zeros((S, n_g), device=dev)], dim=2)
+        cloud = torch.cat([on_cyl, ground], dim=1)
+        perm = torch.argsort(rnd(S, n), dim=1)
+        cloud = cloud.gather(1, perm[:, :, None].expand(S, n, 3)).contiguous()
+        a_i = torch.searchsorted(self.cx, torch.full((S, 1), xn + 0.6, device=dev, dtype=torch.float64), right=True)
+        a_i = torch.minimum(a_i, hi_i - 1).clamp_(min=0)
+        cnt2 = (hi_i - a_i).clamp_(min=1)
+        ei = (a_i + (rnd(S, ne) * cnt2).long()).clamp_(max=self.ncyl - 1)
+        side = (rnd(S, ne) < 0.5).float() * 2.0 - 1.0
+        ex0, ey0, er = (v.gather(1, ei).float() for v in (self.cx, self.cy, self.cr))
+        dx = ex0 - xn
+        dist = torch.sqrt(dx * dx + ey0 * ey0)
+        ang = torch.atan2(ey0, dx) + side * (math.pi / 2.0 + torch.asin((er / dist).clamp(-1.0, 1.0)))
+        edge = torch.stack([ex0 + er * torch.cos(ang), ey0 + er * torch.sin(ang), 4.0 * rnd(S, ne)], dim=2).contiguous()
+        return cloud, edge
+
+    def clearance(self, pos):
+        """pos float64 [S, P, 3] (numpy) -> horizontal distance to the nearest cylinder surface [S, P]."""
+        cx, cy, cr = (v.cpu().numpy() for v in (self.cx, self.cy, self.cr))
+        d = np.sqrt((pos[:, :, 0:1] - cx[:, None, :]) ** 2 + (pos[:, :, 1:2] - cy[:, None, :]) ** 2) - cr[:, None, :]
+        return d.min(axis=2)

@@ -234,16 +234,20 @@ class Pipeline:
     """amk_pipeline: n_slots launches in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs};
     gang = frames (of n_scenes scenes) that share one set of launches -- the slot's handles then hold gang * n_scenes scenes."""
 
-    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0):
+    def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0, farest_point=500.0,
+                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True):
         self.lib = capi.load()
+        task = capi.TaskParams(float(prm.decay), float(iter_time), float(farest_point), float(prm.height), float(slow_down_kp),
+                               float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)), 0)
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
                                   int(prm.K), int(queue_depth), int(gang),
-                                  capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0))
+                                  capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task)
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
         self.N = self.lib.amk_mpc_horizon(self.lib.amk_pipeline_mpc(h, 0))
         self.gang = self.lib.amk_pipeline_gang(h)
+        self._events = []
         hs = n_scenes * self.gang   # scenes of a slot's handles
         self._mpc = [MpcBatch(prm.T, prm.dt, prm.K, hs, handle=self.lib.amk_pipeline_mpc(h, i)) for i in range(n_slots)]
         self._kd = [(KdBatch(hs, max_points, handle=self.lib.amk_pipeline_kd(h, i, 0)),
@@ -264,19 +268,50 @@ class Pipeline:
 
     __del__ = close
 
-    def submit(self, clouds, edges, state_quad, pos_x, ref_path_init, cloud_counts=None, edge_counts=None, u_out=None,
-               keep_warm_start=False):
+    def submit(self, clouds, edges, state_quad=None, pos_x=None, ref_path_init=None, cloud_counts=None, edge_counts=None, u_out=None,
+               keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None):
         """One fresh frame + control step on the next slot; returns its ticket at once (blocks only when that slot's queue
         is full).  ticket % n_slots = slot; with a gang the frame is staged until the gang is full (or wait / drain).
-        All tensors are device tensors that must stay alive until the frame finished."""
+        All tensors are device tensors that must stay alive until the frame finished.  A slot runs on its own stream: by default
+        an event recorded on torch's current stream is handed over (amk_pipeline_frame.input_ready) so that the slot reads the
+        inputs only after the work queued on that stream so far -- like every other entry point of this module, which run ON the
+        current stream.  order_after_current_stream=False: the caller guarantees the inputs are complete (bench.py: frames made
+        once, synchronised).
+        TASK mode: odom float64 [S, 10] = [mPos, yaw, mVel, mAcc] instead of state_quad / pos_x; the slot then runs GetInitPath on
+        its own mRefPath (ref_path_init, when given, re-initialises it first), the clock model, the step and PubCmd /
+        PubSlowDownCmd (cmd_out float64 [S, 3])."""
         assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
+        opt = lambda t: t.data_ptr() if t is not None else None
+        ev_ptr = None
+        if order_after_current_stream:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            ev_ptr = ev.cuda_event
+            self._events.append(ev)                      # alive until the frame has been launched: keep the newest ones
+            if len(self._events) > 4 * self.n_slots * self.gang + 8:
+                del self._events[:len(self._events) // 2]
         fr = capi.PipelineFrame(clouds.data_ptr(), cloud_counts.data_ptr() if cloud_counts is not None else None,
                                 edges.data_ptr(), edge_counts.data_ptr() if edge_counts is not None else None,
-                                int(clouds.shape[2]), int(bool(keep_warm_start)), state_quad.data_ptr(), pos_x.data_ptr(),
-                                ref_path_init.data_ptr(), u_out.data_ptr() if u_out is not None else None)
+                                int(clouds.shape[2]), int(bool(keep_warm_start)), opt(state_quad), opt(pos_x), opt(ref_path_init), opt(u_out),
+                                opt(odom), float(odom_age), opt(cmd_out), ev_ptr)
         slot = C.c_int(-1)
         capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
         return slot.value
+
+    def wait_stream(self, ticket, stream=None):
+        """Device-side wait (amk_pipeline_wait_stream): work queued on `stream` (default: torch's current stream) after this call
+        runs after the frame's step; the host does not block."""
+        capi.check(self.lib.amk_pipeline_wait_stream(self.h, int(ticket), capi.stream_ptr(stream)), "amk_pipeline_wait_stream")
+
+    def output_tensors(self, ticket):
+        """The frame's results as torch tensors ALIASING the slot's buffers (no copy, no synchronisation): valid to read on a
+        stream that waited for the frame (wait / wait_stream) until the slot's next launch overwrites them.
+        -> dict(u [S,4], x0array [S,N,14], flags [S,4] int32, ref_path [S,N,10])"""
+        ptr = [C.c_void_p() for _ in range(4)]
+        capi.check(self.lib.amk_pipeline_outputs(self.h, int(ticket), *[C.byref(p) for p in ptr]), "amk_pipeline_outputs")
+        S, N = self.S, self.N
+        return dict(u=capi.tensor_from_ptr(ptr[0].value, (S, 4), torch.float64), x0array=capi.tensor_from_ptr(ptr[1].value, (S, N, 14), torch.float64),
+                    flags=capi.tensor_from_ptr(ptr[2].value, (S, 4), torch.int32), ref_path=capi.tensor_from_ptr(ptr[3].value, (S, N, 10), torch.float64))
 
     def wait(self, ticket):
         capi.check(self.lib.amk_pipeline_wait(self.h, int(ticket)), "amk_pipeline_wait")

@@ -1,7 +1,11 @@
 #!/usr/bin/env python
 """bench.py -- MPC steps/sec of the Avoid-MPC hot path on MI355X (BASELINE.json's metric).
 
-  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: one process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this process IS a rank;
+      started plainly it re-launches itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+      127.0.0.1 --master-port <free port> bench.py <same arguments>` and rank 0 prints the one JSON line.
+  python bench.py --workload flight ...                 closed-loop flights (warm-started control periods), see flight_main()
 
 One "step" = one pass of the hot path over one batch of synthetic scenes resident in HBM: for every scene a fresh
 depth frame (build the obstacle + edge KD indices) and one control step (<= 3 outer passes of {dual KD queries, pack P,
@@ -189,6 +193,188 @@ def fixture_parity(torch, precision):
 
 
 # ------------------------------------------------------------------------------------------------
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks of ONE node under torch.distributed.run
+    (the driver's own command line), stream rank 0's JSON line through, return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """The launch path without a GPU: rendezvous over gloo, the library's own partition (amk_shard_scene_range /
+    amk_shard_padded_count), an all-gather shaped like the sweep's, max-over-ranks of a wall time, one JSON line from rank 0."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from avoid_mpc_amd import capi
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lib = capi.load()
+    total = args.scenes * world
+    first, count = C.c_int(), C.c_int()
+    capi.check(lib.amk_shard_scene_range(rank, world, total, C.byref(first), C.byref(count)), "amk_shard_scene_range")
+    padded = lib.amk_shard_padded_count(world, total)
+    t0 = time.perf_counter()
+    local = torch.full((args.steps, padded, 4), float(rank), dtype=torch.float64)
+    local[:, :, 0] = torch.arange(first.value, first.value + padded, dtype=torch.float64)[None, :]
+    out = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(out, local)
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    ok = all(int(out[r][0, 0, 1]) == r for r in range(world)) and \
+        [int(out[r][0, 0, 0]) for r in range(world)] == [r * args.scenes for r in range(world)]
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch path only)", "value": None, "unit": "MPC steps/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": world, "gather_ok": bool(ok),
+                          "scenes_per_rank": count.value, "padded_scenes_per_rank": padded, "max_over_ranks_s": float(dt.item())}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
+def flight_main(args):
+    """--workload flight: the reference's regime.  Every step is one control period of a batch of S flights: a fresh frame
+    (both index builds), GetInitPath on the slot's own mRefPath, GetCurStateQuad per pass, the re-plan loop from the previous
+    period's solution (mNlpW0), PubCmd / PubSlowDownCmd -- all inside amk_pipeline's TASK mode -- and the vehicle (the MPC's own
+    model driven by the command: two torch kernels per batch and period, part of the workload, not of the product).  The loop
+    never synchronises with the host: inputs are ordered by amk_pipeline_frame.input_ready, outputs by amk_pipeline_wait_stream.
+    value = flight-periods per second = MPC steps/s of warm-started steps; the cold-start headline is the default workload."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    import numpy as np
+    import torch
+    from avoid_mpc_amd import capi, flight, synth
+    from avoid_mpc_amd.host import Pipeline
+    assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the flight workload is a single-GPU secondary measurement"
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    prm = synth.MpcParams(T=args.T, K=args.K)
+    S, n, ne, N = args.scenes, args.points, args.points // 10, prm.N
+    nslots, gang = max(1, args.streams), max(1, args.gang)
+    B = nslots * gang                                        # batches of flights = (slot, gang position) pairs
+    P = args.periods if args.periods > 0 else max(2, -(-args.steps // B))
+    W = min(B, 4)                                            # distinct world sets (frames of W x P x 169 MB stay resident)
+    worlds = [flight.FlightWorldsTorch(S, n, prm, 9000 + w, dev) for w in range(W)]
+    t_gen = time.perf_counter()
+    frames = [[worlds[w].frame(t) for t in range(P)] for w in range(W)]
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t_gen
+    A, Bm, c = flight.affine_plant(prm.tau, prm.dt)
+    ABt = torch.from_numpy(np.concatenate([A, Bm], axis=1).T.copy()).to(dev)      # [14, 10]: x' = [x, a_cmd, 0] @ ABt + c
+    cvec = torch.from_numpy(c).to(dev)
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang)
+    for i in range(nslots):
+        pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
+        pl.mpc(i).set_precision(args.precision)
+    x0 = np.zeros((B, S, 10)); ref0 = np.zeros((B, S, N, 10))
+    for b in range(B):
+        for s_ in range(S):
+            x0[b, s_], ref0[b, s_] = flight.initial_state(77000 + b * S + s_, prm)
+    ref0_d = torch.from_numpy(ref0).to(dev)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
+
+    def fly(periods, log=None):
+        """All B batches for `periods` periods from the start state; returns (seconds, host seconds in submit)."""
+        x = [torch.from_numpy(x0[b]).to(dev) for b in range(B)]
+        xu = [torch.zeros((S, 14), dtype=torch.float64, device=dev) for _ in range(B)]   # [x, a_cmd, yaw_dot = 0]
+        cmd = [torch.zeros((S, 3), dtype=torch.float64, device=dev) for _ in range(B)]   # Command.acceleration of the period
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); t_sub = 0.0
+        for t in range(periods):
+            tickets = []
+            ts = time.perf_counter()
+            for b in range(B):
+                with torch.cuda.stream(streams[b]):
+                    cl, ed = frames[b % W][t]
+                    tickets.append(pl.submit(cl, ed, ref_path_init=ref0_d[b] if t == 0 else None, odom=x[b], cmd_out=cmd[b],
+                                             keep_warm_start=t > 0))
+            t_sub += time.perf_counter() - ts
+            for b in range(B):
+                with torch.cuda.stream(streams[b]):
+                    pl.wait_stream(tickets[b], streams[b])
+                    xu[b][:, 0:10] = x[b]
+                    xu[b][:, 10:13] = cmd[b]
+                    torch.addmm(cvec, xu[b], ABt, out=x[b])                               # the vehicle over one control period
+                    if log is not None:
+                        log["pos"][b, t + 1] = x[b][:, 0:3]
+                        o = pl.output_tensors(tickets[b])
+                        log["flags"][b, t] = o["flags"]; log["u"][b, t] = o["u"]
+        pl.drain()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, t_sub
+
+    fly(min(P, max(2, args.warmup)))                          # untimed: workspaces, first-touch, clocks
+    dt, t_sub = fly(P)
+    log = dict(pos=torch.zeros((B, P + 1, S, 3), dtype=torch.float64, device=dev), flags=torch.zeros((B, P, S, 4), dtype=torch.int32, device=dev),
+               u=torch.zeros((B, P, S, 4), dtype=torch.float64, device=dev))
+    log["pos"][:, 0] = torch.from_numpy(x0[:, :, 0:3]).to(dev)
+    fly(P, log)                                               # the same flights once more, logged (untimed)
+    pos = log["pos"].cpu().numpy().transpose(0, 2, 1, 3); fl = log["flags"].cpu().numpy().transpose(0, 2, 1, 3)
+    ug = log["u"].cpu().numpy().transpose(0, 2, 1, 3)                                     # [B, S, P(+1), .]
+    clear = np.stack([worlds[b % W].clearance(pos[b]) for b in range(B)])                 # [B, S, P + 1]
+    cmin = clear.min(axis=2)
+    stats = {"flights": int(B * S), "periods": P, "solves_per_step": round(float(fl[..., 1].mean()), 3),
+             "ipm_iters_per_step": round(float(fl[..., 3].mean()), 2), "ipm_iters_first_period": round(float(fl[:, :, 0, 3].mean()), 2),
+             "unsafe_periods": int((fl[..., 0] == 0).sum()), "capped_solves": int((fl[..., 2] > 0).sum()),
+             "min_clearance_median_m": round(float(np.median(cmin)), 3), "flights_inside_drone_radius": int((cmin < prm.radius).sum()),
+             "flights_through_a_cylinder": int((cmin < 0).sum()), "x_final_mean_m": round(float(pos[:, :, -1, 0].mean()), 2)}
+    parity = None
+    if not args.no_cpu_baseline and not args.no_parity:
+        # the same flights on the CPU oracle: a sample of batch 0, on the frames the GPU saw
+        from tests import _flight
+        nf = min(S, 16)
+        cl = np.stack([frames[0][t][0][:nf].cpu().numpy() for t in range(P)], axis=1)     # [nf, P, n, 3]
+        ed = np.stack([frames[0][t][1][:nf].cpu().numpy() for t in range(P)], axis=1)
+        t0 = time.perf_counter()
+        o = _flight.oracle_flights_on_frames(cl, ed, x0[0, :nf], ref0[0, :nf], args.T, args.K)
+        t_cpu = time.perf_counter() - t0
+        g = dict(x=np.concatenate([pos[0, :nf], np.zeros((nf, P + 1, 7))], axis=2), flags=fl[0, :nf], u=ug[0, :nf])
+        cmp = _flight.compare(g, o, pos_tol=1e-6)
+        parity = {"flights_vs_cpu_oracle": {"flights": nf, "periods": P, "separated": cmp["separated"],
+                                            "dpos_max_while_flags_agree_m": cmp["dpos_max_while_together"],
+                                            "dpos_final_max_of_separated_m": cmp["dpos_final_max_separated"],
+                                            "ok": bool(cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= max(1, nf // 8)),
+                                            "cpu_oracle_steps_per_s_all_cores": round(nf * P / t_cpu, 1), "cores": _flight.usable_cores(),
+                                            "note": "same frames, same start; a flight separates when its flags differ in some period "
+                                                    "(another branch at a rounding-level tie); tests/test_flight_gpu.py is the "
+                                                    "64-flight x 100-period version of this check"}}
+    steps = B * P
+    value = S * steps / dt
+    step_bytes = alg_bytes_per_step(n, ne, N, prm.K)
+    line = {"metric": f"MPC steps/sec ({n // 1000}k-pt cloud, N={N}, {prm.K} obstacle constraints) -- closed-loop flights, warm-started",
+            "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": 1, "steps": steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / steps, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
+            "config": {"workload": f"closed-loop flights: {B} batches x {S} flights x {P} control periods; per period and flight a fresh "
+                                   f"{n}-pt frame + {ne}-pt edge cloud (both index builds), GetInitPath, warm start kept "
+                                   f"(mNlpW0), <= {prm.max_iter} re-plan passes, PubCmd / PubSlowDownCmd, vehicle = the MPC's model; "
+                                   "SECONDARY to the cold-start headline (default workload)",
+                       "scenes_per_gpu": S, "points": n, "horizon": N, "K": prm.K, "batches": B, "periods": P, "streams_in_flight": nslots,
+                       "steps_per_launch": gang, "queue_depth_per_slot": args.queue_depth if args.queue_depth > 0 else 2,
+                       "distinct_world_sets": W, "distinct_frames_bytes": int(W * P * S * 12 * (n + ne)),
+                       "frame_generation_s_untimed": round(t_gen, 2), "host_submit_ms_per_step": round(1e3 * t_sub / steps, 4),
+                       "orchestration": "amk_pipeline TASK mode (prologue / epilogue kernels), input_ready events in, "
+                                        "amk_pipeline_wait_stream out: no host synchronisation inside the loop"},
+            "flight": stats,
+            "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes, "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
+                                    "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5),
+                                    "note": "SURVEY 8(d) bytes per step x steps/s over the HBM peak: with ~1 warm solve of a few "
+                                            "iterations per step the index builds (HBM-bound) are most of a period"},
+            "parity": parity}
+    print(json.dumps(line), flush=True)
+    pl.close()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -215,7 +401,21 @@ def main():
     ap.add_argument("--steady-steps", type=int, default=1024,
                     help="extra untimed-by-contract run reported as value_steady_state when --steps is smaller")
     ap.add_argument("--breakdown", action="store_true", help="extra untimed pass with every kernel class timed")
+    ap.add_argument("--workload", default="cold", choices=("cold", "flight"),
+                    help="cold (the headline: fresh frame + zero warm start every step) or flight (closed loop: every step is one "
+                         "control period of a batch of flights -- fresh frame, GetInitPath, warm start, command, vehicle)")
+    ap.add_argument("--periods", type=int, default=0, help="flight workload: control periods per flight (0: from --steps)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only (CPU, gloo): ranks rendezvous, partition the scenes, exchange a gather-shaped buffer and "
+                         "rank 0 prints a JSON line without a value -- what tests/test_bench_launch.py runs without a GPU")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
+    if args.workload == "flight":
+        return flight_main(args)
 
     # one hardware queue per in-flight step (ROCm defaults to 4 and multiplexes streams onto them: two streams on one
     # queue serialise); measured on MI355X: 4 queues 280k, 8 -> 315k, 24 -> 390k steps/s at 16 streams
@@ -228,7 +428,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:   # a launcher's WORLD_SIZE wins over the flag (it decided how many ranks exist)
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: running on {world} rank(s)", file=sys.stderr)
+        args.gpus = world
     launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ   # under torch.distributed.run (also with 1 rank)
     dist = None
     if world > 1 or launched:
@@ -307,7 +510,7 @@ def main():
         step_no[0] += 1
         fr.last_row = row
         if diag_streams is None:
-            return pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row])
+            return pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row], order_after_current_stream=False)
         st = diag_streams[i]
         with torch.cuda.stream(st):
             diag_ref[i].copy_(fr.ref0, non_blocking=True)
@@ -556,4 +759,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

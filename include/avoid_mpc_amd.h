@@ -146,7 +146,10 @@ typedef struct amk_mpc amk_mpc;
  * number counts IPOPT's iterations, which this library does not reproduce.  The default is a
  * safety net, not a budget: a solve runs until its last barrier problem is solved to tol (mean 10 / 21 / 25 iterations
  * at N = 10 / 20 / 30, the slowest of 1024 + 64 + 256 bench scenes 54; a cap of 40 cut 1.5 % of the cold starts short).
- * A solve that does hit the cap reports status 1 (amk_mpc_solve: info[0]; amk_step_batch: flags[2]).              */
+ * A solve that does hit the cap reports status 1 (amk_mpc_solve: info[0]; amk_step_batch: flags[2]).  Real-time hosts:
+ * in a batched launch the slowest scene sets the launch time, and a non-converging scene runs to the cap (~25 us per
+ * iteration and solve when the chip is full); set a tighter cap per handle (amk_mpc_set_solver_options; for a pipeline:
+ * on amk_pipeline_mpc(p, slot) of every slot) and fall back to PubSlowDownCmd when flags[2] > 0.      */
 int amk_mpc_create(double T, double dt, int nearest_point_num, int n_scenes, amk_mpc **out);
 int amk_mpc_destroy(amk_mpc *mpc);
 int amk_mpc_horizon(const amk_mpc *mpc);   /* N                                                  */
@@ -294,8 +297,23 @@ int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_
  * InitializeNew) -> AvoidanceStateMachine::Step TASK branch (AvoidanceStateMachine.cpp:322-355) -- and returns at once;
  * it blocks only when queue_depth steps of that slot are still unfinished.  The host should export GPU_MAX_HW_QUEUES >= n_slots
  * before the first HIP call (ROCm multiplexes streams onto 4 hardware queues by default; two streams on one queue
- * serialise).  Input buffers belong to the caller and must stay valid until the slot has finished.                      */
+ * serialise).  Input buffers belong to the caller and must stay valid until the slot has finished.  They must also be
+ * COMPLETE: a slot runs on its own non-blocking stream, which is not ordered against the stream that produced the inputs, and
+ * with a gang the inputs are only read when the gang is launched (the G-th submit, wait or drain).  Either synchronise the
+ * producing stream before submit(), or record an event on it and pass it as amk_pipeline_frame.input_ready -- the slot's stream
+ * then waits for it on the device (hipStreamWaitEvent), the host does not.                                                */
 typedef struct amk_pipeline amk_pipeline;
+/* What the TASK case does around the re-plan loop (AvoidanceStateMachine.cpp:322-355), for frames submitted in TASK mode.  */
+typedef struct amk_task_params {
+    double decay;           /* mParamDecay: assumed compute latency, mpc_parameters.yaml:77                                 */
+    double iter_time;       /* assumed duration of one re-plan pass (the reference measures it, :329,343); <= 0: decay      */
+    double farest_point;    /* goal_x, mpc_parameters.yaml:55 (GetInitPath :31)                                             */
+    double height;          /* mHeight, :54                                                                                 */
+    double slow_down_kp, slow_down_kd;   /* :79-80  (PubSlowDownCmd :379-397)                                               */
+    double a_max_xy, a_max_z;            /* clamp of the slow-down command (:383-388; z clamped to +-aMaxZ as there)        */
+    int use_odom_est;       /* mParamIsUseOdomEstimate, :78                                                                 */
+    int reserved;
+} amk_task_params;
 #define AMK_PIPELINE_MAX_SLOTS 64
 #define AMK_PIPELINE_DEFAULT_DEPTH 3
 #define AMK_PIPELINE_MAX_DEPTH 64
@@ -318,6 +336,7 @@ typedef struct amk_pipeline_config {
                             /* are those of separate launches, bit for bit (scenes are independent).  On the bench workload */
                             /* 10 slots x 4 frames of 256 scenes beat 20 slots x 1 by 11 %.           */
     amk_step_params step;
+    amk_task_params task;   /* only read for frames submitted with d_odom (TASK mode, below)                                */
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
     const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame                   */
@@ -332,6 +351,20 @@ typedef struct amk_pipeline_frame {
     const double *d_ref_path_init; /* [S][N][10]  mRefPath after GetInitPath; copied, the slot's copy is refilled       */
     double *d_u_out;               /* [S][4] or NULL: where the control goes instead of the slot's own buffer (e.g. a   */
                                    /* row of the sweep's result array that amk_shard_gather exchanges at the end)       */
+    /* TASK mode: the slot keeps the state machine's persistent state -- mRefPath next to mNlpW0 -- and the caller supplies  */
+    /* per control period what the reference's callbacks supply: the frame and the odometry.  With d_odom != NULL the slot   */
+    /* runs, on the device, GetInitPath (:24-54, task "forward") on ITS OWN mRefPath (position g of slot s keeps the path of */
+    /* the frame submitted there last: submit the same robots in the same order every period), GetCurStateQuad (:183-203)    */
+    /* for every re-plan pass at odom_age + decay + i * iter_time, the step, and PubCmd / PubSlowDownCmd (:345-350,369-397). */
+    /* d_state_quad / d_pos_x are then ignored (may be NULL); d_ref_path_init != NULL first (re)sets mRefPath               */
+    /* (InitCircleState :14-23 or any re-initialisation) BEFORE GetInitPath, NULL keeps the slot's.                          */
+    const double *d_odom;          /* [S][10] or NULL: [mPos(3), yaw, mVel(3), mAcc(3)] as the callbacks left them       */
+    double odom_age;               /* now - mTimePos at the start of the step, seconds (:183-184); 0 = fresh odometry    */
+    double *d_cmd_out;             /* [S][3] or NULL: Command.acceleration -- u[0..2] when isSafety, else the slow-down  */
+                                   /* command (TASK mode only)                                                           */
+    void *input_ready;             /* hipEvent_t or NULL: recorded by the caller on the stream that produces this       */
+                                   /* frame's inputs; the slot's stream waits for it before it reads them.  The event   */
+                                   /* must stay alive (and must not be re-recorded) until the frame has been launched   */
 } amk_pipeline_frame;
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out);
 int amk_pipeline_destroy(amk_pipeline *p);
@@ -345,6 +378,10 @@ void *amk_pipeline_stream(amk_pipeline *p, int slot);
  * ticket % n_slots is the slot, for amk_pipeline_mpc / _kd / _stream.                                                    */
 int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *frame, int *ticket_out);
 int amk_pipeline_wait(amk_pipeline *p, int ticket);   /* until that frame's step has finished (launches an open gang)     */
+/* Device-side wait: work queued on `stream` after this call runs after the frame's step has finished; the host does not
+ * block (launches an open gang).  A closed loop -- outputs -> the caller's kernels -> next submit(input_ready) -- then never
+ * synchronises with the host.  The slot's NEWEST launch is the one waited for: call it before the next submit on that slot. */
+int amk_pipeline_wait_stream(amk_pipeline *p, int ticket, void *stream);
 int amk_pipeline_query(amk_pipeline *p, int ticket);  /* 1 finished / idle, 0 running or staged, -1 error                 */
 int amk_pipeline_drain(amk_pipeline *p);              /* wait for every slot                                              */
 /* Device pointers of the frame's results (valid after wait): u [S][4], x0array [S][N][14], flags [S][4], ref_path [S][N][10] */
@@ -366,7 +403,12 @@ int amk_shard_destroy(amk_shard *s);
 int amk_shard_rank(const amk_shard *s);
 int amk_shard_world(const amk_shard *s);
 int amk_shard_last_rccl_error(void);
-/* d_all[r * n + i] = rank r's d_local[i]: equal shards (pad the last one); stream-ordered.                                */
+/* d_all[r * n + i] = rank r's d_local[i]; stream-ordered.  ncclAllGather needs the SAME count on every rank: when
+ * total % world != 0 the counts of amk_shard_scene_range differ by one, so every rank passes the PADDED shard size
+ * amk_shard_padded_count(world, total) = ceil(total / world) (its buffers sized for it; rows beyond its own count are
+ * padding) -- passing the natural `count` would hang or corrupt d_all.  amk_shard_gather_u: n_local_scenes is that padded
+ * size too (4 doubles per scene).                                                                                      */
+int amk_shard_padded_count(int world, int total);
 int amk_shard_gather(amk_shard *s, const double *d_local, long long n_doubles_per_rank, double *d_all, void *stream);
 int amk_shard_gather_u(amk_shard *s, const double *d_u_local, int n_local_scenes, double *d_u_all, void *stream);
 int amk_shard_max(amk_shard *s, double *d_values, int n, void *stream);   /* in-place max over ranks (timing)              */

@@ -33,13 +33,33 @@ def _log_arrays(periods):
                 cmd=np.zeros((periods, 3)))
 
 
+class _GivenFrames:
+    """Frames handed over by the caller (bench.py --workload flight: the frames its GPU flights saw)."""
+
+    def __init__(self, clouds, edges, cyl=None):
+        self.clouds, self.edges, self.cyl = clouds, edges, cyl
+
+    def frame(self, t):
+        return self.clouds[t], self.edges[t]
+
+    def clearance(self, p):
+        if self.cyl is None:
+            return np.full(p.shape[:-1], np.nan)
+        cx, cy, cr = self.cyl
+        return (np.sqrt((p[..., 0:1] - cx) ** 2 + (p[..., 1:2] - cy) ** 2) - cr).min(axis=-1)
+
+
 def _oracle_flight(job):
     seed, cfg, periods, n_points, world_kw = job
     from tests import _oracle
-    prm, n = make_prm(cfg)
+    prm, n = make_prm(cfg) if isinstance(cfg, str) else (synth.MpcParams(T=cfg[0], K=cfg[1]), n_points)
     n = n_points or n
-    world = flight.FlightWorld(seed, prm, n, **world_kw)
-    x, ref = flight.initial_state(seed, prm)
+    if isinstance(seed, dict):   # explicit frames and start (oracle_flights_on_frames)
+        world = _GivenFrames(seed["clouds"], seed["edges"], seed.get("cyl"))
+        x, ref = seed["x0"].copy(), seed["ref0"].copy()
+    else:
+        world = flight.FlightWorld(seed, prm, n, **world_kw)
+        x, ref = flight.initial_state(seed, prm)
     mpc = _oracle.MpcOracle(prm.T, prm.dt, prm.K); mpc.configure(prm)
     log = _log_arrays(periods)
     log["x"][0] = x
@@ -103,8 +123,23 @@ def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, w
     return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
 
 
-def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batch=None, tie_order=0, precision=64):
-    """The same flights through amk_pipeline_*: one slot per batch of flights, one submit(keep_warm_start) per period."""
+def oracle_flights_on_frames(clouds, edges, x0, ref0, T, K, cyl=None, workers=None):
+    """CPU-oracle flights on given frames: clouds [F, P, n, 3], edges [F, P, ne, 3] float32, x0 [F, 10], ref0 [F, N, 10];
+    cyl: optional (cx, cy, cr) [F, ncyl] for the clearance.  -> the same dict of arrays as oracle_flights."""
+    from tests import _oracle
+    _oracle.build_oracle()
+    F, P = clouds.shape[0], clouds.shape[1]
+    jobs = [(dict(clouds=clouds[f], edges=edges[f], x0=x0[f], ref0=ref0[f], cyl=None if cyl is None else tuple(c[f] for c in cyl)),
+             (T, K), P, clouds.shape[2], {}) for f in range(F)]
+    return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
+
+
+def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batch=None, tie_order=0, precision=64, mode="host",
+                gang=1):
+    """The same flights through amk_pipeline_*: one (slot, gang position) per batch of flights, one submit(keep_warm_start) per
+    period.  mode "host": GetInitPath / clock model / command on the host (avoid_mpc_amd/flight.py), the pipeline gets
+    state_quad, pos_x and the shifted path; mode "task": the pipeline's TASK mode -- the slot keeps mRefPath, the caller hands
+    over the odometry and gets the command (prologue / epilogue kernels of csrc/pipeline.hip)."""
     import torch
     from avoid_mpc_amd.host import Pipeline
     prm, n = make_prm(cfg)
@@ -113,33 +148,44 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
     B = batch or F
     assert F % B == 0
     nb = F // B
+    assert nb % gang == 0
     dev = torch.device("cuda", torch.cuda.current_device())
     worlds = [flight.FlightWorld(int(s), prm, n, **(world_kw or {})) for s in seeds]
     st = [flight.initial_state(int(s), prm) for s in seeds]
     x = np.stack([a for a, _ in st]); ref = np.stack([b for _, b in st])
-    pl = Pipeline(nb, B, n, n // 10, prm, queue_depth=1, gang=1)
-    for i in range(nb):
+    pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang)
+    for i in range(nb // gang):
         pl.kd(i, 0).set_tie_order(tie_order); pl.kd(i, 1).set_tie_order(tie_order); pl.mpc(i).set_precision(precision)
     logs = dict(x=np.zeros((F, periods + 1, 10)), u=np.zeros((F, periods, 4)), flags=np.zeros((F, periods, 4), np.int32),
                 cmd=np.zeros((F, periods, 3)))
     logs["x"][:, 0] = x
     for t in range(periods):
         keep, tickets = [], []
-        sq, px = flight.period_inputs(x, ref, prm)
+        if mode == "host":
+            sq, px = flight.period_inputs(x, ref, prm)
         for b in range(nb):   # every batch of the period in flight, then collect
             sl = slice(b * B, (b + 1) * B)
             fr = [worlds[i].frame(t) for i in range(sl.start, sl.stop)]
-            bufs = (torch.from_numpy(np.stack([c for c, _ in fr])).to(dev), torch.from_numpy(np.stack([e for _, e in fr])).to(dev),
-                    torch.from_numpy(sq[sl]).to(dev), torch.from_numpy(px[sl]).to(dev), torch.from_numpy(ref[sl]).to(dev))
-            torch.cuda.synchronize()
-            keep.append(bufs)
-            tickets.append(pl.submit(*bufs, keep_warm_start=t > 0))
+            clouds = torch.from_numpy(np.stack([c for c, _ in fr])).to(dev); edges = torch.from_numpy(np.stack([e for _, e in fr])).to(dev)
+            if mode == "host":
+                bufs = (clouds, edges, torch.from_numpy(sq[sl]).to(dev), torch.from_numpy(px[sl]).to(dev), torch.from_numpy(ref[sl]).to(dev))
+                keep.append(bufs)
+                tickets.append(pl.submit(*bufs, keep_warm_start=t > 0))
+            else:
+                odom = torch.from_numpy(x[sl]).to(dev); cmd = torch.empty((B, 3), dtype=torch.float64, device=dev)
+                ref0 = torch.from_numpy(ref[sl]).to(dev) if t == 0 else None     # InitCircleState's role; afterwards the slot's own
+                keep.append((clouds, edges, odom, cmd, ref0))
+                tickets.append(pl.submit(clouds, edges, ref_path_init=ref0, odom=odom, cmd_out=cmd, keep_warm_start=t > 0))
         for b, tk in enumerate(tickets):
             sl = slice(b * B, (b + 1) * B)
             pl.wait(tk)
             o = pl.outputs(tk)
             ref[sl] = o["ref_path"]
             a = flight.command(o["u"], o["flags"], x[sl], prm)
+            if mode == "task":   # the device's command is the host twin's, bit for bit
+                a_dev = keep[b][3].cpu().numpy()
+                assert np.array_equal(a_dev, a), (t, b, np.abs(a_dev - a).max())
+                a = a_dev
             x[sl] = flight.apply_command(x[sl], a, prm)
             logs["u"][sl, t] = o["u"]; logs["flags"][sl, t] = o["flags"]; logs["cmd"][sl, t] = a
         logs["x"][:, t + 1] = x

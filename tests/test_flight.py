@@ -94,3 +94,23 @@ def test_ipopt_emulation_flights_small():
     du = np.abs(a["u"] - b["u"]).max(axis=(1, 2))
     print("oracle vs IPOPT-10 emulation, C1, 30 periods: max |dpos| per flight", np.round(d, 4), "max |du|", np.round(du, 3))
     assert d.max() < 0.5 and du.max() > 1e-6      # different iterates, nearby trajectories
+
+
+def test_flight_fixture_c2():
+    """tests/golden/flight_golden.npz (make_flight_golden.py): 16 flights x 100 periods at BASELINE configs[1] size flown by the
+    oracle and by the IPOPT-10 emulation.  (1) the oracle driver reproduces the committed oracle trajectories (first flights,
+    first periods: a regression pin of the whole loop -- world, frames, shift, warm start, step, vehicle); (2) the statistics
+    DESIGN.md quotes follow from the fixture."""
+    import os
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "flight_golden.npz"))
+    seeds, P = G["seeds"], 30
+    a = _flight.oracle_flights(seeds[:4], "C2", P, world_kw=dict(cyl_per_m=float(G["cyl_per_m"])), workers=4)
+    assert np.abs(a["x"][:, :, 0:3] - G["oracle.pos"][:4, :P + 1]).max() < 1e-5          # float32 fixture
+    assert np.array_equal(a["flags"], G["oracle.flags"][:4, :P])
+    d = np.abs(G["oracle.pos"].astype(np.float64) - G["ipopt10.pos"]).max(axis=(1, 2))
+    hits_o, hits_i = int((G["oracle.clearance_min"] < 0).sum()), int((G["ipopt10.clearance_min"] < 0).sum())
+    print("\noracle vs IPOPT-10 emulation over 100 periods, max |dpos| per flight: median %.2f m, p90 %.2f, max %.2f; "
+          "flights through a cylinder: %d vs %d of %d; IPOPT stopped by max_iter in %.0f %% of its solves"
+          % (np.median(d), np.quantile(d, 0.9), d.max(), hits_o, hits_i, len(d),
+             100.0 * (G["ipopt10.status"] == 1).sum() / max(1, (G["ipopt10.status"] >= 0).sum())))
+    assert np.median(d) < 1.0 and hits_o <= hits_i + 2

@@ -64,3 +64,16 @@ def test_flights_c1_and_batches():
     cmp = _flight.compare(g1, o)
     print("\nC1 flights:", {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")})
     assert cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= 1
+
+
+def test_task_mode_equals_host_mode():
+    """The pipeline's TASK mode (GetInitPath on the slot's own mRefPath, GetCurStateQuad per pass, PubCmd / PubSlowDownCmd on the
+    device: AvoidanceStateMachine.cpp:24-54,183-203,345-350,379-397) flies the flights of the host-driven loop, bit for bit -- also
+    with the batches of a period sharing launches (gang 2) and with a slow-down period forced by an empty edge cloud."""
+    seeds = list(range(700, 716))
+    kw = dict(cyl_per_m=2.0, x_first=3.0)
+    h = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4)
+    t1 = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4, mode="task")
+    t2 = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4, mode="task", gang=2)
+    for t in (t1, t2):
+        assert np.array_equal(h["x"], t["x"]) and np.array_equal(h["flags"], t["flags"]) and np.array_equal(h["cmd"], t["cmd"])

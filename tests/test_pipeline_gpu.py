@@ -208,3 +208,112 @@ def test_pipeline_argument_errors():
     assert lib.amk_pipeline_mpc(h, 2) is None and lib.amk_pipeline_kd(h, 0, 2) is None
     assert lib.amk_pipeline_query(h, 0) == 1 and lib.amk_pipeline_drain(h) == 0           # idle slots count as finished
     assert lib.amk_pipeline_destroy(h) == 0
+
+
+@pytest.mark.parametrize("gang", [1, 2])
+@pytest.mark.parametrize("stage", [1, 2])
+def test_pipeline_survives_a_failed_launch(gang, stage):
+    """A launch that fails half-way: the staged frames are dropped, the failure is reported by that
+    submit() and by wait() / drain(), the round robin moves on, and every later frame returns what a fresh pipeline returns."""
+    import torch
+    from avoid_mpc_amd.host import Pipeline
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne, n_slots = 4, 5000, 500, 2
+    frames = _frames(torch, prm, 3 * gang * n_slots, S, n)
+
+    def run(pl, frs):
+        rows = torch.zeros((len(frs), S, 4), dtype=torch.float64, device="cuda")
+        for i, fr in enumerate(frs):
+            pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"], u_out=rows[i])
+        pl.drain()
+        return rows.cpu().numpy()
+
+    good = Pipeline(n_slots, S, n, ne, prm, gang=gang)
+    want = run(good, frames)
+    good.close()
+    pl = Pipeline(n_slots, S, n, ne, prm, gang=gang)
+    run(pl, frames[:gang * n_slots])                       # a healthy round first
+    assert pl.lib.amk__pipeline_inject_failure(pl.h, stage) == capi.AMK_OK
+    bad = torch.zeros((S, 4), dtype=torch.float64, device="cuda")
+    st = [pl.lib.amk_pipeline_submit(pl.h, C.byref(capi.PipelineFrame(fr["cl"].data_ptr(), None, fr["ed"].data_ptr(), None, 3, 0,
+                                                                       fr["sq"].data_ptr(), fr["px"].data_ptr(), fr["ref"].data_ptr(),
+                                                                       bad.data_ptr(), None, 0.0, None, None)), None)
+          for fr in frames[:gang]]
+    assert st[:-1] == [capi.AMK_OK] * (gang - 1) and st[-1] == capi.AMK_ERR_HIP       # the submit that launched reports it
+    assert pl.lib.amk_pipeline_wait(pl.h, 0) == capi.AMK_ERR_HIP                        # ... and so does wait() on that slot
+    assert pl.lib.amk_pipeline_query(pl.h, 0) == 1                                      # nothing of it is left staged or running
+    assert pl.lib.amk_pipeline_drain(pl.h) == capi.AMK_ERR_HIP
+    # the failed launch consumed slot 0's turn: the next frames start on slot 1, fill whole gangs, and are the fresh pipeline's
+    got = run(pl, frames)
+    assert np.array_equal(got, want)
+    assert pl.lib.amk_pipeline_drain(pl.h) == capi.AMK_OK                                # the failure is forgotten once the slot ran again
+    # argument errors leave nothing staged either
+    fr = frames[0]
+    f5 = capi.PipelineFrame(fr["cl"].data_ptr(), None, fr["ed"].data_ptr(), None, 5, 0, fr["sq"].data_ptr(), fr["px"].data_ptr(),
+                            fr["ref"].data_ptr(), None, None, 0.0, None, None)
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(f5), None) == capi.AMK_ERR_INVALID_ARG
+    assert np.array_equal(run(pl, frames), want)
+    pl.close()
+
+
+def test_pipeline_orders_inputs_after_the_producing_stream():
+    """a slot runs on its own stream.  Pipeline.submit hands over an event recorded on torch's current stream
+    (amk_pipeline_frame.input_ready), so inputs written by kernels still queued there are complete when the slot reads them."""
+    import torch
+    from avoid_mpc_amd.host import Pipeline
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne = 4, 5000, 500
+    fr = _frames(torch, prm, 1, S, n)[0]
+    pl = Pipeline(2, S, n, ne, prm, gang=2)
+    pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"]); pl.drain()
+    want = pl.outputs(0)["u"].copy()
+    # the inputs are produced by a long chain of kernels on torch's stream, then submitted at once without a host synchronisation
+    big = torch.zeros(64 << 20, device="cuda")
+    for rep in range(3):
+        cl = torch.zeros_like(fr["cl"]); ref = torch.zeros_like(fr["ref"]); sq = torch.zeros_like(fr["sq"])
+        torch.cuda.synchronize()
+        for _ in range(20):
+            big.add_(1.0)                         # ~ms of queued work in front of the producers
+        cl.copy_(fr["cl"]); ref.copy_(fr["ref"]); sq.copy_(fr["sq"])
+        t = pl.submit(cl, fr["ed"], sq, fr["px"], ref)
+        pl.wait(t)
+        assert np.array_equal(pl.outputs(t)["u"], want), rep
+    # and the way back: wait_stream orders torch's stream after the step without blocking the host
+    t = pl.submit(fr["cl"], fr["ed"], fr["sq"], fr["px"], fr["ref"])
+    pl.wait_stream(t)
+    u = pl.output_tensors(t)["u"].clone()         # queued on torch's stream behind the slot's event
+    torch.cuda.synchronize()
+    assert np.array_equal(u.cpu().numpy(), want)
+    pl.close()
+
+
+def test_task_mode_slow_down_command():
+    """TASK mode's epilogue: PubCmd when isSafety, PubSlowDownCmd (AvoidanceStateMachine.cpp:379-397) when PlanWapionts found no
+    edge point next to a too-close obstacle (:270-274).  Scenes with an empty edge cloud and an obstacle point on the first
+    reference point are unsafe; the command equals the host twin's."""
+    import torch
+    from avoid_mpc_amd import flight
+    from avoid_mpc_amd.host import Pipeline
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne = 6, 5000, 500
+    fr = _frames(torch, prm, 1, S, n)[0]
+    rng = np.random.default_rng(3)
+    x = np.zeros((S, 10)); x[:, 0:3] = [0.0, 0.2, prm.height]; x[:, 4:7] = rng.normal(size=(S, 3)) * [12.0, 40.0, 3.0]
+    x[:, 7:10] = rng.normal(size=(S, 3)) * [3.0, 3.0, 40.0]
+    ref = np.stack([synth.make_ref_path(x[s, 0:3], prm) for s in range(S)])
+    shifted = ref.copy()
+    flight.period_inputs(x, shifted, prm)                     # what GetInitPath leaves in mRefPath[0]
+    cl = fr["cl"].clone()
+    cl[:, 0, :] = torch.from_numpy(shifted[:, 0, 0:3].astype(np.float32)).cuda()   # an obstacle point ON the first reference point
+    edge_counts = torch.tensor([0, ne, 0, ne, 0, ne], dtype=torch.int32, device="cuda")
+    pl = Pipeline(1, S, n, ne, prm)
+    cmd = torch.zeros((S, 3), dtype=torch.float64, device="cuda")
+    t = pl.submit(cl, fr["ed"], ref_path_init=torch.from_numpy(ref).cuda(), odom=torch.from_numpy(x).cuda(), cmd_out=cmd,
+                  edge_counts=edge_counts)
+    pl.wait(t)
+    o = pl.outputs(t)
+    assert list(o["flags"][:, 0]) == [0, 1, 0, 1, 0, 1]
+    want = flight.command(o["u"], o["flags"], x, prm)
+    assert np.array_equal(cmd.cpu().numpy(), want)
+    assert np.abs(want[0] - o["u"][0, :3]).max() > 1e-3      # the slow-down command is not the solver's
+    pl.close()
