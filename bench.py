@@ -247,13 +247,15 @@ def flight_main(args):
     (both index builds), GetInitPath on the slot's own mRefPath, GetCurStateQuad per pass, the re-plan loop from the previous
     period's solution (mNlpW0), PubCmd / PubSlowDownCmd -- all inside amk_pipeline's TASK mode -- and the vehicle (the MPC's own
     model driven by the command: two torch kernels per batch and period, part of the workload, not of the product).  The loop
-    never synchronises with the host: inputs are ordered by amk_pipeline_frame.input_ready, outputs by amk_pipeline_wait_stream.
+    never synchronises with the host: the vehicle's kernels are queued on the slot's own stream behind the step (a host with its
+    own streams would use amk_pipeline_frame.input_ready / amk_pipeline_wait_stream: tests/test_pipeline_gpu.py).
     value = flight-periods per second = MPC steps/s of warm-started steps; the cold-start headline is the default workload."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     import numpy as np
     import torch
     from avoid_mpc_amd import capi, flight, synth
     from avoid_mpc_amd.host import Pipeline
+    lib = capi.load()
     assert int(os.environ.get("WORLD_SIZE", "1")) == 1, "the flight workload is a single-GPU secondary measurement"
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)
@@ -280,7 +282,9 @@ def flight_main(args):
         for s_ in range(S):
             x0[b, s_], ref0[b, s_] = flight.initial_state(77000 + b * S + s_, prm)
     ref0_d = torch.from_numpy(ref0).to(dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(B)]
+    # the vehicle's kernels run on the slot's own stream, right behind the step that produced the command: no second set of
+    # streams (2 B streams oversubscribe the 32 hardware queues), no events; batch b lives on slot b // gang, position b % gang
+    slot_stream = [torch.cuda.ExternalStream(lib.amk_pipeline_stream(pl.h, i), device=dev) for i in range(nslots)]
 
     def fly(periods, log=None):
         """All B batches for `periods` periods from the start state; returns (seconds, host seconds in submit)."""
@@ -290,24 +294,26 @@ def flight_main(args):
         torch.cuda.synchronize()
         t0 = time.perf_counter(); t_sub = 0.0
         for t in range(periods):
-            tickets = []
-            ts = time.perf_counter()
-            for b in range(B):
-                with torch.cuda.stream(streams[b]):
+            for si in range(nslots):
+                ts = time.perf_counter()
+                tickets = []
+                for g in range(gang):
+                    b = si * gang + g
                     cl, ed = frames[b % W][t]
                     tickets.append(pl.submit(cl, ed, ref_path_init=ref0_d[b] if t == 0 else None, odom=x[b], cmd_out=cmd[b],
-                                             keep_warm_start=t > 0))
-            t_sub += time.perf_counter() - ts
-            for b in range(B):
-                with torch.cuda.stream(streams[b]):
-                    pl.wait_stream(tickets[b], streams[b])
-                    xu[b][:, 0:10] = x[b]
-                    xu[b][:, 10:13] = cmd[b]
-                    torch.addmm(cvec, xu[b], ABt, out=x[b])                               # the vehicle over one control period
-                    if log is not None:
-                        log["pos"][b, t + 1] = x[b][:, 0:3]
-                        o = pl.output_tensors(tickets[b])
-                        log["flags"][b, t] = o["flags"]; log["u"][b, t] = o["u"]
+                                             keep_warm_start=t > 0, order_after_current_stream=False))
+                    assert tickets[-1] % nslots == si
+                t_sub += time.perf_counter() - ts
+                with torch.cuda.stream(slot_stream[si]):      # queued behind the gang's launches on the same stream
+                    for g in range(gang):
+                        b = si * gang + g
+                        xu[b][:, 0:10] = x[b]
+                        xu[b][:, 10:13] = cmd[b]
+                        torch.addmm(cvec, xu[b], ABt, out=x[b])                           # the vehicle over one control period
+                        if log is not None:
+                            log["pos"][b, t + 1] = x[b][:, 0:3]
+                            o = pl.output_tensors(tickets[g])
+                            log["flags"][b, t] = o["flags"]; log["u"][b, t] = o["u"]
         pl.drain()
         torch.cuda.synchronize()
         return time.perf_counter() - t0, t_sub
@@ -362,8 +368,8 @@ def flight_main(args):
                        "steps_per_launch": gang, "queue_depth_per_slot": args.queue_depth if args.queue_depth > 0 else 2,
                        "distinct_world_sets": W, "distinct_frames_bytes": int(W * P * S * 12 * (n + ne)),
                        "frame_generation_s_untimed": round(t_gen, 2), "host_submit_ms_per_step": round(1e3 * t_sub / steps, 4),
-                       "orchestration": "amk_pipeline TASK mode (prologue / epilogue kernels), input_ready events in, "
-                                        "amk_pipeline_wait_stream out: no host synchronisation inside the loop"},
+                       "orchestration": "amk_pipeline TASK mode (prologue / epilogue kernels); the vehicle's kernels are queued on the "
+                                        "slot's own stream behind the step: no host synchronisation inside the loop"},
             "flight": stats,
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes, "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5),

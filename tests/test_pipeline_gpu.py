@@ -290,11 +290,12 @@ def test_pipeline_orders_inputs_after_the_producing_stream():
 def test_task_mode_slow_down_command():
     """TASK mode's epilogue: PubCmd when isSafety, PubSlowDownCmd (AvoidanceStateMachine.cpp:379-397) when PlanWapionts found no
     edge point next to a too-close obstacle (:270-274).  Scenes with an empty edge cloud and an obstacle point on the first
-    reference point are unsafe; the command equals the host twin's."""
+    reference point are unsafe; the command equals the host twin's.  One re-plan pass (mpc_max_iter = 1): isSafety is
+    overwritten by every pass (:331), and a later pass plans from the PREDICTED path, which has left the obstacle."""
     import torch
     from avoid_mpc_amd import flight
     from avoid_mpc_amd.host import Pipeline
-    prm = synth.MpcParams(T=0.33, K=3)
+    prm = synth.MpcParams(T=0.33, K=3, max_iter=1)
     S, n, ne = 6, 5000, 500
     fr = _frames(torch, prm, 1, S, n)[0]
     rng = np.random.default_rng(3)
