@@ -69,10 +69,17 @@ struct SolveOpts {     // DESIGN.md section 5; the CPU restatement used by the t
 // LDS carve-up for one scene (offsets in doubles).  All per-scene state of the solve lives here.
 // The feedback gains of the Riccati sweep (4 x 10 + feed-forward per stage) live in a global, L2-resident scratch, not
 // in LDS: written once by the backward sweep, read once by the forward roll, 7.7 KB of the former 26.3 KB per scene --
-// with them in LDS a CU held 6 scenes, without them 8 (two per SIMD).  Layout [k][a][16]: row a of K_k in lane 16 a + j.
+// with them in LDS a CU held 6 scenes, without them 8 (two per SIMD).  Only the entries that are not structurally zero are
+// stored (round 4; rounds 2-3 kept [k][4][16] = 64 doubles per stage): the yaw chain is decoupled (build_plan checks it), so
+// K_k[a][yaw] = 0 for the three acceleration rows and K_k[yaw_dot][j] = 0 for every state but yaw -- 3 x (9 states +
+// feed-forward) + (yaw, feed-forward) = 32 doubles = two cache lines per stage instead of four.  gain_offset(a, c): where
+// K_k[a][c] lives (c = 10: feed-forward), -1 for a structural zero.
 constexpr int kTermRecord = 4;  // doubles per collision term in the global scratch (mpc_device_impl.h: YB)
-constexpr int GAIN_ROW = 16;
-constexpr int GAIN_STAGE = 4 * GAIN_ROW;
+constexpr int GAIN_STAGE = 32;
+__host__ __device__ __forceinline__ int gain_offset(int a, int c) {
+    if (a < 3) return c == 3 ? -1 : a * 10 + (c < 3 ? c : c - 1);
+    return c == 3 ? 30 : (c == 10 ? 31 : -1);
+}
 
 struct LdsMap {
     int prm, xinit, target, cy, sy;

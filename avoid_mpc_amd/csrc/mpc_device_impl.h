@@ -557,7 +557,7 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
 }
 
 // Backward Riccati sweep.  Returns false when a
-// control block is not positive definite.  Gains go to the scene's global scratch ([k][a][GAIN_ROW], column 10 =
+// control block is not positive definite.  Gains go to the scene's global scratch ([k][GAIN_STAGE], gain_offset; column 10 =
 // feed-forward): stores that nothing in the sweep waits for.
 //
 // A stage is two LDS rounds.  Both are straight-line code (every lane runs the same instructions on its own
@@ -634,10 +634,11 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
             const real t = (gi[0] * u0 + gi[1] * u1) + gi[2] * u2;
             const real base = (fma(lp.bdelta, delta, lp.bconst) + b0) + (b1 + b2);
             const real val = fma(-t, rd, fma(-gi[3], u3, base));
-            if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward)
-                double *kk = gains + k * GAIN_STAGE + R.gain_col;
-                kk[0] = (double)(-u0 * rd); kk[GAIN_ROW] = (double)(-u1 * rd);
-                kk[2 * GAIN_ROW] = (double)(-u2 * rd); kk[3 * GAIN_ROW] = (double)(-u3);
+            if (R.gain_col >= 0) {  // K(:,c) = -Hm^-1 g_c (column 10 = feed-forward); structural zeros are not stored
+                double *kk = gains + k * GAIN_STAGE;
+                const int c = R.gain_col, o0 = gain_offset(0, c), o3 = gain_offset(3, c);
+                if (o0 >= 0) { kk[o0] = (double)(-u0 * rd); kk[o0 + 10] = (double)(-u1 * rd); kk[o0 + 20] = (double)(-u2 * rd); }
+                if (o3 >= 0) kk[o3] = (double)(-u3);
             }
             if (k > 0) {  // P_k = Q_k + delta I + A'PA - G'Hm^-1 G ; p_k = q_k + A'p - G'Hm^-1 qu ; lam_k
                 sm[R.out1] = val;
@@ -649,7 +650,7 @@ __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, cons
 }
 
 // forward roll of the Newton step: dX_0 = 0, dU_k = K_k dX_k + d_k, dX_{k+1} = A dX_k + B dU_k.
-// Lane 16 a + j (j < 11) holds K_k[a][j] (j = 10: the feed-forward term) -- one coalesced global load per stage,
+// Lane 16 a + j (j < 11) holds K_k[a][j] (j = 10: the feed-forward term; structural zeros are not loaded) -- one coalesced global load per stage,
 // prefetched kFwdPrefetch stages ahead -- multiplies it with dX_k[j] from LDS, and a DPP row reduction leaves dU_k[a] in
 // every lane of row a.  State i is owned by a spare lane of the row of ITS control (p_a, v_a, a_a in row a; yaw in row 3:
 // B couples a state to that control only, cols_of_A_row / rows_of_B), so dX_{k+1}[i] needs no second exchange: a stage
@@ -677,10 +678,11 @@ __device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N
         for (int t = 0; t < 3; ++t) ac[t] = t < nc ? (real)A[own * SD + cols[t]] : RL(0.0);
         bc = (real)B[own * UD + a];
     }
-    const bool gain_lane = j <= SD;
+    const int goff = j <= SD ? gain_offset(a, j) : -1;
+    const bool gain_lane = goff >= 0;
     real kv[kFwdPrefetch];
 #pragma unroll
-    for (int u = 0; u < kFwdPrefetch; ++u) kv[u] = (u < N && gain_lane) ? (real)gains[u * GAIN_STAGE + lane] : RL(0.0);
+    for (int u = 0; u < kFwdPrefetch; ++u) kv[u] = (u < N && gain_lane) ? (real)gains[u * GAIN_STAGE + goff] : RL(0.0);
     if (lane < SD) sm[L.dX + lane] = RL(0.0);
     __syncthreads();
     const int xsrc = j < SD ? j : 0;
@@ -691,7 +693,7 @@ __device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N
             const int k = k0 + u;
             if (k >= N) break;
             const real g = kv[u];
-            kv[u] = (k + kFwdPrefetch < N && gain_lane) ? (real)gains[(k + kFwdPrefetch) * GAIN_STAGE + lane] : RL(0.0);
+            kv[u] = (k + kFwdPrefetch < N && gain_lane) ? (real)gains[(k + kFwdPrefetch) * GAIN_STAGE + goff] : RL(0.0);
             const real *xk = sm + L.dX + k * SD;
             const real xj = xk[xsrc], x0 = xk[cols[0]], x1 = xk[cols[1]], x2 = xk[cols[2]];
             const real du = row_reduce<OpSum>(g * (j < SD ? xj : RL(1.0)));  // lanes j > 10 hold g = 0

@@ -16,7 +16,7 @@ struct amk_mpc {
     amk::DevBuf<double> prm;  // [PRM_LEN]
     amk::DevBuf<double> w0;   // [S][nx]  mNlpW0
     amk::DevBuf<double> ybuf; // [S][N][K][4]  per collision term: its two multipliers + the geometry cache of the derivative pass (scratch of one solve)
-    amk::DevBuf<double> gains; // [S][N][4][16] Riccati feedback gains (scratch of one interior-point iteration)
+    amk::DevBuf<double> gains; // [S][N][GAIN_STAGE = 32] Riccati feedback gains, structural zeros left out (scratch of one interior-point iteration)
     amk::DevBuf<double> plan_coef;  // item coefficients + lane-role constants of the Riccati plan (mpc_device.h)
     amk::DevBuf<int> plan_meta;     // [PLAN_ITEMS] PlanItemMeta + [64] LaneRole
     // staging for amk_mpc_eval_host

@@ -396,7 +396,7 @@ def main():
                     help="steps (frames) that share one set of launches on a slot (amk_pipeline_config.gang): streams x gang steps "
                          "are in flight or staged.  10 x 4 against the 20 x 1 of rounds 2-3a, same box: 519 k vs 466 k scene-steps/s "
                          "steady, 410-422 k vs 378 k over the driver's 20 steps")
-    ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1 without, 8 with a process group)")
+    ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1; flight workload: 2)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
     ap.add_argument("--ipm-max-iter", type=int, default=None, help="iteration cap of the solve (default: the library's)")
@@ -476,11 +476,14 @@ def main():
             self.posx = torch.from_numpy(posx).to(dev)
             self.last_row = 0
 
-    # the C ABI's pipeline (include/avoid_mpc_amd.h: amk_pipeline_*): what a C++ host would call; bench.py only feeds it
-    # steps queued per slot before submit() blocks.  1 is best without a communicator (+1-2 %); with a live RCCL communicator in
-    # the process the host sees a finished step ~0.3 ms late (cause not found: tools/experiments/rccl_presence.py) and a slot
-    # that waits for the host idles: 287 k steps/s at depth 1, 384 k at 3, 402 k at 8 -- so the next steps are queued ahead
-    qdepth = args.queue_depth if args.queue_depth > 0 else (8 if collective else 1)
+    # the C ABI's pipeline (include/avoid_mpc_amd.h: amk_pipeline_*): what a C++ host would call; bench.py only feeds it.
+    # Steps queued per slot before submit() blocks: 1 (+1-2 % against deeper queues).  Rounds 2-3 used 8 whenever a process
+    # group existed because a live RCCL communicator cost 35 % at depth 1 -- with 20 slots.  Cause (round 4,
+    # tools/experiments/rccl_presence2.py): hardware queues.  A communicator brings its own streams; with 20 pipeline streams the
+    # process then holds more streams than it gets hardware queues, the runtime maps two streams onto one queue and they
+    # serialise -- the same loss as GPU_MAX_HW_QUEUES=16 without any communicator (338 k vs 334 k steps/s; <= 16 slots: no loss).
+    # The shipped 10 slots x gang 4 holds 10 streams and is unaffected (558.9 k without, 558.3 k with a communicator, depth 1).
+    qdepth = args.queue_depth if args.queue_depth > 0 else 1
     pl = Pipeline(nslots, S, n, ne, prm, queue_depth=qdepth, gang=gang)
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
