@@ -223,3 +223,36 @@ class FlightWorldsTorch:
         cx, cy, cr = (v.cpu().numpy() for v in (self.cx, self.cy, self.cr))
         d = np.sqrt((pos[:, :, 0:1] - cx[:, None, :]) ** 2 + (pos[:, :, 1:2] - cy[:, None, :]) ** 2) - cr[:, None, :]
         return d.min(axis=2)
+
+
+# T_b_c of AM/config/mpc_parameters.yaml:67-71: camera (x right, y down, z forward) in the body frame (x forward, y left, z up)
+TBC_YAML = np.array([[0.0, 0.0, 1.0, 0.05], [-1.0, 0.0, 0.0, 0.0], [0.0, -1.0, 0.0, 0.01], [0.0, 0.0, 0.0, 1.0]])
+
+
+def render_depth(cyl, Twb, Tbc, rows, cols, fx, fy, cx, cy, z_top=4.0, max_range=60.0):
+    """Planar depth image (metres, float32 [rows, cols]; 0 = no return) of vertical cylinders cyl = (cx, cy, r) arrays standing
+    on the ground plane z = 0, seen by a pinhole camera at Twb * Tbc -- the synthetic counterpart of the depth frames the
+    reference receives (AirSim's DepthPlanar, AM/src/AvoidanceStateMachine.cpp:153-164).  Pixel (u, v) looks along
+    ((u - cx) / fx, (v - cy) / fy, 1) in the camera frame; the value is the z coordinate of the first hit in that frame, which is
+    what FrameKDMap::UV2Camera back-projects (FrameKDMap.cpp:131-138)."""
+    ccx, ccy, cr = (np.asarray(v, np.float64) for v in cyl)
+    Twc = np.asarray(Twb, np.float64).reshape(4, 4) @ np.asarray(Tbc, np.float64).reshape(4, 4)
+    R, o = Twc[:3, :3], Twc[:3, 3]
+    v, u = np.meshgrid(np.arange(rows, dtype=np.float64), np.arange(cols, dtype=np.float64), indexing="ij")
+    dc = np.stack([(u - cx) / fx, (v - cy) / fy, np.ones_like(u)], axis=-1)      # camera-frame ray, z component 1: t = planar depth
+    d = dc @ R.T                                                                    # world-frame ray
+    best = np.full((rows, cols), np.inf)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tg = np.where(d[..., 2] < 0, -o[2] / d[..., 2], np.inf)                     # ground plane
+        best = np.minimum(best, np.where(tg > 0, tg, np.inf))
+        a = d[..., 0] ** 2 + d[..., 1] ** 2
+        for k in range(ccx.size):
+            ox, oy = o[0] - ccx[k], o[1] - ccy[k]
+            b = ox * d[..., 0] + oy * d[..., 1]
+            c = ox * ox + oy * oy - cr[k] ** 2
+            disc = b * b - a * c
+            t = (-b - np.sqrt(np.where(disc >= 0, disc, np.nan))) / a
+            z = o[2] + t * d[..., 2]
+            ok = (disc >= 0) & (t > 0) & (z >= 0) & (z <= z_top)
+            best = np.where(ok & (t < best), t, best)
+    return np.where(best <= max_range, best, 0.0).astype(np.float32)
