@@ -55,6 +55,13 @@ class StepParams(C.Structure):
                 ("mpc_max_iter", C.c_int), ("reserved", C.c_int)]
 
 
+class DepthParams(C.Structure):
+    """amk_depth_params (FrameKDMap's perception parameters, mpc_parameters.yaml:59-66)."""
+    _fields_ = [("pixel2meter", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
+                ("resize_scale", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
+                ("cy", C.c_double), ("Tbc", C.c_double * 16)]
+
+
 class TaskParams(C.Structure):
     """amk_task_params"""
     _fields_ = [("decay", C.c_double), ("iter_time", C.c_double), ("farest_point", C.c_double), ("height", C.c_double),
@@ -66,7 +73,7 @@ class PipelineConfig(C.Structure):
     """amk_pipeline_config"""
     _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
                 ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("queue_depth", C.c_int),
-                ("gang", C.c_int), ("step", StepParams), ("task", TaskParams)]
+                ("gang", C.c_int), ("step", StepParams), ("task", TaskParams), ("depth", DepthParams)]
 
 
 class PipelineFrame(C.Structure):
@@ -74,20 +81,14 @@ class PipelineFrame(C.Structure):
     _fields_ = [("d_cloud", C.c_void_p), ("d_cloud_counts", C.c_void_p), ("d_edge", C.c_void_p), ("d_edge_counts", C.c_void_p),
                 ("point_stride", C.c_int), ("keep_warm_start", C.c_int), ("d_state_quad", C.c_void_p), ("d_pos_x", C.c_void_p),
                 ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p), ("d_odom", C.c_void_p), ("odom_age", C.c_double),
-                ("d_cmd_out", C.c_void_p), ("input_ready", C.c_void_p)]
+                ("d_cmd_out", C.c_void_p), ("d_depth", C.c_void_p), ("depth_type", C.c_int), ("depth_rows", C.c_int), ("depth_cols", C.c_int),
+                ("reserved", C.c_int), ("d_Twb", C.c_void_p), ("input_ready", C.c_void_p)]
 
 
 class FrameCamera(C.Structure):
     """amk_frame_camera: PtIsInFrame's camera model (FrameKDMap.cpp:215-231), intrinsics already divided by the resize scale."""
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("depth_max", C.c_double), ("width", C.c_int), ("height", C.c_int)]
-
-
-class DepthParams(C.Structure):
-    """amk_depth_params (FrameKDMap's perception parameters, mpc_parameters.yaml:59-66)."""
-    _fields_ = [("pixel2meter", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
-                ("resize_scale", C.c_double), ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double),
-                ("cy", C.c_double), ("Tbc", C.c_double * 16)]
 
 
 AMK_DEPTH_U16, AMK_DEPTH_F32 = 0, 1

@@ -75,7 +75,7 @@ namespace amk {
 // kd_index.hip: the frames of a pipeline gang built by one launch (see there)
 int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes, const float *const *d_xyz,
                   const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
-                  hipStream_t stream);
+                  hipStream_t stream, const int *const *d_keep_if_zero = nullptr);
 }  // namespace amk
 
 // ------------------------------------------------------------------------------------------------

@@ -159,6 +159,8 @@ struct BuildArgs {   // one tree's InitializeNew
     int *cell_start;
     int ntiles;
     double *gparams;
+    const int *keep_if_zero;   // [S] or null: scene s keeps its previous index when keep_if_zero[s] == 0 (FrameKDMap::AddVertex
+                               // returns before BOTH InitializeNew calls when the frame's obstacle cloud is empty, FrameKDMap.cpp:39-41)
 };
 // grid = (scenes, trees): blockIdx.y selects the tree.  FrameKDMap::AddVertex builds TWO trees per depth frame (obstacle +
 // edge cloud, FrameKDMap.cpp:44-47): amk_kd_build_pair issues them as one launch, so the small edge build (24 us alone,
@@ -168,6 +170,7 @@ struct BuildArgs2 { BuildArgs t[kBuildMaxEntries]; };
 __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildArgs2 args) {
     const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
     const int s = blockIdx.x;
+    if (a.keep_if_zero && a.keep_if_zero[s] == 0) return;   // (block-uniform)
     const float *src = a.xyz + (long long)s * a.scene_stride;
     int n = a.counts ? a.counts[s] : a.max_points;
     n = n < 0 ? 0 : (n > a.max_points ? a.max_points : n);
@@ -181,7 +184,7 @@ static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, lo
     return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap,
                      kd->size.p + so, kd->pmax.p + so, kd->bbox.p + so * 6, kd->gpt.p + so * kd->cap,
                      kd->cell_start.p + so * kd->ntiles * (amk::kGridMaxCells + 2), kd->ntiles,
-                     kd->gparams.p + so * amk::kGridParamDoubles};
+                     kd->gparams.p + so * amk::kGridParamDoubles, nullptr};
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
@@ -723,7 +726,7 @@ int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts,
 namespace amk {
 int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes, const float *const *d_xyz,
                   const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
-                  hipStream_t stream) {
+                  hipStream_t stream, const int *const *d_keep_if_zero) {
     if (!obstacle || !edge || n_frames < 1 || n_frames > AMK_PIPELINE_MAX_GANG || point_stride < 3 ||
         obstacle->n_scenes < n_frames * frame_scenes || edge->n_scenes != obstacle->n_scenes)
         return AMK_ERR_INVALID_ARG;
@@ -734,6 +737,7 @@ int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes
             const size_t so = (size_t)f * frame_scenes;
             args.t[2 * f] = build_args(obstacle, d_xyz[f], point_stride, (long long)obstacle->max_points * point_stride, d_counts[f], so);
             args.t[2 * f + 1] = build_args(edge, d_edge_xyz[f], point_stride, (long long)edge->max_points * point_stride, d_edge_counts[f], so);
+            if (d_keep_if_zero) args.t[2 * f].keep_if_zero = args.t[2 * f + 1].keep_if_zero = d_keep_if_zero[f];
         }
         hipLaunchKernelGGL(kd_build_kernel, dim3(frame_scenes, 2 * n_frames), dim3(kCompactThreads), 0, stream, args);
         for (amk_kd *kd : {obstacle, edge}) {

@@ -34,6 +34,9 @@ struct amk_pipeline {
         const double *odom;                 // TASK mode (amk_pipeline_frame.d_odom): prologue / epilogue on the device
         double odom_age;
         double *cmd_out;
+        const void *depth;                  // raw depth image (amk_pipeline_frame.d_depth): ProcessDepth / BuildEdgeCloud on the device
+        int depth_type, depth_rows, depth_cols;
+        const double *Twb;
     };
     struct Slot {
         hipStream_t stream = nullptr;
@@ -46,6 +49,10 @@ struct amk_pipeline {
         amk::DevBuf<int> flags;
         std::vector<Staged> open;       // frames staged since the last launch (< gang)
         int point_stride = 3;
+        // frames that start at the depth image: the slot's own clouds + counts, and mCurFrame.Twc of every scene (persistent)
+        amk::DevBuf<float> dcloud, dedge;      // [G S][max_points][3], [G S][max_edge_points][3]
+        amk::DevBuf<int> dcount, decount;      // [G S]
+        amk::DevBuf<double> Twc;               // [G S][16]
         int fail_status = AMK_OK;       // the slot's newest launch failed half-way with this status: its frames were dropped, their
                                         // results are undefined; reported by that submit() and by wait() / drain() until the next launch
     };
@@ -109,6 +116,24 @@ __global__ __launch_bounds__(256) void pipeline_scatter_kernel(const ScatterArgs
             a.cmd[g][i] = v;
         }
     }
+}
+
+// mCurFrame.Twc = mat4Twb * mParamTbc (FrameKDMap.cpp:50) for the scenes whose frame produced an obstacle cloud (:39-41 returns
+// before it otherwise); Twc == nullptr-initialised slots start from the identity (pipeline_twc_init_kernel)
+__global__ __launch_bounds__(256) void pipeline_twc_update_kernel(const double *__restrict__ Twb, const int *__restrict__ counts,
+                                                                  double *__restrict__ Twc, int S, const amk_depth_params prm) {
+#pragma clang fp contract(off)   // the product the host twin forms (include/avoid_mpc_amd/frame_kd_map.hpp: AddVertex), sum in k order
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= S * 16) return;
+    const int s = e / 16, i = (e % 16) / 4, j = e % 4;
+    if (counts[s] == 0) return;
+    double acc = 0.0;
+    for (int k = 0; k < 4; ++k) acc += Twb[s * 16 + 4 * i + k] * prm.Tbc[4 * k + j];
+    Twc[e] = acc;
+}
+__global__ __launch_bounds__(256) void pipeline_twc_init_kernel(double *__restrict__ Twc, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < n * 16) Twc[e] = (e % 16) % 5 == 0 ? 1.0 : 0.0;
 }
 
 // TASK-mode prologue (AvoidanceStateMachine.cpp:24-54,183-203,322-330): one wavefront per scene runs GetInitPath on the slot's
@@ -227,9 +252,38 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     }
     int rc;
     if (p->inject_failure == 1) { p->inject_failure = 0; return AMK_ERR_HIP; }
+    // frames that start at the depth image: ProcessDepth + BuildEdgeCloud (FrameKDMap.cpp:90-130,176-214) into the slot's clouds
+    const int *keep[AMK_PIPELINE_MAX_GANG];
+    bool any_depth = false;
+    for (int g = 0; g < filled; ++g) {
+        const amk_pipeline::Staged &f = s.open[g];
+        keep[g] = nullptr;
+        if (!f.depth) continue;
+        if (s.point_stride != 3) return AMK_ERR_INVALID_ARG;   // the slot's own clouds are packed xyz
+        if (!s.dcloud.p) {   // first depth frame of this slot
+            const size_t GS = (size_t)G * S;
+            AMK_HIP(s.dcloud.alloc(GS * c.max_points * 3)); AMK_HIP(s.dedge.alloc(GS * c.max_edge_points * 3));
+            AMK_HIP(s.dcount.alloc(GS)); AMK_HIP(s.decount.alloc(GS)); AMK_HIP(s.Twc.alloc(GS * 16));
+            hipLaunchKernelGGL(pipeline_twc_init_kernel, dim3((unsigned)((GS * 16 + 255) / 256)), dim3(256), 0, st, s.Twc.p, (int)GS);
+        }
+        any_depth = true;
+        const size_t o = (size_t)g * S;
+        float *dc = s.dcloud.p + o * c.max_points * 3, *de = s.dedge.p + o * c.max_edge_points * 3;
+        const long long img = (long long)f.depth_rows * f.depth_cols;
+        rc = amk_depth_to_cloud(f.depth, f.depth_type, f.depth_rows, f.depth_cols, img, S, &c.depth, f.Twb, dc, 3,
+                                (long long)c.max_points * 3, s.dcount.p + o, st);
+        if (rc != AMK_OK) return rc;
+        rc = amk_depth_to_edge_cloud(f.depth, f.depth_type, f.depth_rows, f.depth_cols, img, S, &c.depth, s.Twc.p + o * 16, de, 3,
+                                     (long long)c.max_edge_points * 3, s.decount.p + o, st);
+        if (rc != AMK_OK) return rc;
+        hipLaunchKernelGGL(pipeline_twc_update_kernel, dim3((S * 16 + 255) / 256), dim3(256), 0, st, f.Twb, s.dcount.p + o, s.Twc.p + o * 16, S, c.depth);
+        AMK_HIP(hipGetLastError());
+        cl[g] = dc; ed[g] = de; cc[g] = s.dcount.p + o; ec[g] = s.decount.p + o;
+        keep[g] = s.dcount.p + o;
+    }
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
-    if (G == 1) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
-    else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st);
+    if (G == 1 && !any_depth) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
+    else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st, any_depth ? keep : nullptr);
     if (rc != AMK_OK) return rc;
     if (p->inject_failure == 2) { p->inject_failure = 0; return AMK_ERR_HIP; }
     double *u = (G == 1 && s.open[0].u_out && !any_task) ? s.open[0].u_out : s.u.p;
@@ -359,11 +413,19 @@ void *amk_pipeline_stream(amk_pipeline *p, int slot) {
 }
 
 int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticket_out) {
-    if (!p || !f || !f->d_cloud || !f->d_edge) return AMK_ERR_INVALID_ARG;
+    if (!p || !f) return AMK_ERR_INVALID_ARG;
+    if (f->d_depth) {   // a frame that starts at the depth image
+        if (!f->d_Twb || f->depth_rows <= 0 || f->depth_cols <= 0 || (f->depth_type != AMK_DEPTH_U16 && f->depth_type != AMK_DEPTH_F32))
+            return AMK_ERR_INVALID_ARG;
+        int w = 0, h = 0;
+        if (amk_depth_out_size(f->depth_rows, f->depth_cols, p->cfg.depth.resize_scale, &w, &h) != AMK_OK) return AMK_ERR_INVALID_ARG;
+        if ((long long)w * h > p->cfg.max_points || (long long)w * h > p->cfg.max_edge_points) return AMK_ERR_INVALID_ARG;
+        if ((long long)w * h > AMK_EDGE_MAX_PIXELS) return AMK_ERR_UNSUPPORTED;
+    } else if (!f->d_cloud || !f->d_edge) return AMK_ERR_INVALID_ARG;
     if (!f->d_odom && (!f->d_state_quad || !f->d_pos_x || !f->d_ref_path_init)) return AMK_ERR_INVALID_ARG;
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
-    const int stride = f->point_stride ? f->point_stride : 3;
+    const int stride = f->d_depth ? 3 : (f->point_stride ? f->point_stride : 3);
     if (stride != 3 && stride != 4) return AMK_ERR_INVALID_ARG;
     if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
     if ((int)s.open.size() >= p->gang) return AMK_ERR_INVALID_ARG;                  // (cannot happen: a full gang is launched at once)
@@ -381,7 +443,7 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     // staged: the frame's inputs are read when its gang is launched (they stay the caller's until then)
     s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
                                            f->d_ref_path_init, f->d_u_out, f->keep_warm_start, (hipEvent_t)f->input_ready,
-                                           f->d_odom, f->odom_age, f->d_cmd_out});
+                                           f->d_odom, f->odom_age, f->d_cmd_out, f->d_depth, f->depth_type, f->depth_rows, f->depth_cols, f->d_Twb});
     if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
     if ((int)s.open.size() == p->gang) return launch_slot(p, s);

@@ -235,13 +235,14 @@ class Pipeline:
     gang = frames (of n_scenes scenes) that share one set of launches -- the slot's handles then hold gang * n_scenes scenes."""
 
     def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0, farest_point=500.0,
-                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True):
+                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None):
         self.lib = capi.load()
         task = capi.TaskParams(float(prm.decay), float(iter_time), float(farest_point), float(prm.height), float(slow_down_kp),
                                float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)), 0)
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
                                   int(prm.K), int(queue_depth), int(gang),
-                                  capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task)
+                                  capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task,
+                                  depth if depth is not None else capi.DepthParams())
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
@@ -269,7 +270,7 @@ class Pipeline:
     __del__ = close
 
     def submit(self, clouds, edges, state_quad=None, pos_x=None, ref_path_init=None, cloud_counts=None, edge_counts=None, u_out=None,
-               keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None):
+               keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None, depth=None, Twb=None):
         """One fresh frame + control step on the next slot; returns its ticket at once (blocks only when that slot's queue
         is full).  ticket % n_slots = slot; with a gang the frame is staged until the gang is full (or wait / drain).
         All tensors are device tensors that must stay alive until the frame finished.  A slot runs on its own stream: by default
@@ -280,8 +281,14 @@ class Pipeline:
         TASK mode: odom float64 [S, 10] = [mPos, yaw, mVel, mAcc] instead of state_quad / pos_x; the slot then runs GetInitPath on
         its own mRefPath (ref_path_init, when given, re-initialises it first), the clock model, the step and PubCmd /
         PubSlowDownCmd (cmd_out float64 [S, 3])."""
-        assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
         opt = lambda t: t.data_ptr() if t is not None else None
+        dinfo = (None, 0, 0, 0, 0, None)
+        if depth is not None:   # a frame that starts at the raw depth image: depth [S, rows, cols] uint16 / int16 / float32, Twb [S, 4, 4]
+            assert depth.dim() == 3 and depth.is_contiguous() and Twb.dtype == torch.float64 and Twb.is_contiguous()
+            kind = capi.AMK_DEPTH_F32 if depth.dtype == torch.float32 else capi.AMK_DEPTH_U16
+            dinfo = (depth.data_ptr(), kind, int(depth.shape[1]), int(depth.shape[2]), 0, Twb.data_ptr())
+        else:
+            assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
         ev_ptr = None
         if order_after_current_stream:
             ev = torch.cuda.Event()
@@ -290,10 +297,9 @@ class Pipeline:
             self._events.append(ev)                      # alive until the frame has been launched: keep the newest ones
             if len(self._events) > 4 * self.n_slots * self.gang + 8:
                 del self._events[:len(self._events) // 2]
-        fr = capi.PipelineFrame(clouds.data_ptr(), cloud_counts.data_ptr() if cloud_counts is not None else None,
-                                edges.data_ptr(), edge_counts.data_ptr() if edge_counts is not None else None,
-                                int(clouds.shape[2]), int(bool(keep_warm_start)), opt(state_quad), opt(pos_x), opt(ref_path_init), opt(u_out),
-                                opt(odom), float(odom_age), opt(cmd_out), ev_ptr)
+        fr = capi.PipelineFrame(opt(clouds), opt(cloud_counts), opt(edges), opt(edge_counts),
+                                int(clouds.shape[2]) if clouds is not None else 3, int(bool(keep_warm_start)), opt(state_quad), opt(pos_x),
+                                opt(ref_path_init), opt(u_out), opt(odom), float(odom_age), opt(cmd_out), *dinfo, ev_ptr)
         slot = C.c_int(-1)
         capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
         return slot.value

@@ -303,6 +303,17 @@ int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_
  * producing stream before submit(), or record an event on it and pass it as amk_pipeline_frame.input_ready -- the slot's stream
  * then waits for it on the device (hipStreamWaitEvent), the host does not.                                                */
 typedef struct amk_pipeline amk_pipeline;
+/* FrameKDMap's perception parameters (used by amk_depth_to_cloud / _edge_cloud below and by pipeline frames that start at the
+ * raw depth image).                                                                                                       */
+typedef struct amk_depth_params {
+    double pixel2meter;   /* mParamPixel2Meter   mpc_parameters.yaml:64                            */
+    double depth_min;     /* mParamDepthMin      :66                                               */
+    double depth_max;     /* mParamDepthMax      :65                                               */
+    double resize_scale;  /* mParamDepthScale    :63  (output is cols/scale x rows/scale, truncated) */
+    double fx, fy, cx, cy; /* FULL-resolution intrinsics (:59-62); divided by resize_scale inside,
+                             as the FrameKDMap constructor does (FrameKDMap.cpp:21-24)             */
+    double Tbc[16];       /* body <- camera, row-major 4x4 (mParamTbc)                             */
+} amk_depth_params;
 /* What the TASK case does around the re-plan loop (AvoidanceStateMachine.cpp:322-355), for frames submitted in TASK mode.  */
 typedef struct amk_task_params {
     double decay;           /* mParamDecay: assumed compute latency, mpc_parameters.yaml:77                                 */
@@ -337,9 +348,10 @@ typedef struct amk_pipeline_config {
                             /* 10 slots x 4 frames of 256 scenes beat 20 slots x 1 by 11 %.           */
     amk_step_params step;
     amk_task_params task;   /* only read for frames submitted with d_odom (TASK mode, below)                                */
+    amk_depth_params depth; /* only read for frames submitted with d_depth (below)                                          */
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
-    const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame                   */
+    const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame (NULL with d_depth)*/
     const int *d_cloud_counts;     /* [S] or NULL (= max_points)                                                        */
     const float *d_edge;           /* [S][max_edge_points][point_stride] edge cloud                                     */
     const int *d_edge_counts;      /* [S] or NULL                                                                       */
@@ -362,6 +374,15 @@ typedef struct amk_pipeline_frame {
     double odom_age;               /* now - mTimePos at the start of the step, seconds (:183-184); 0 = fresh odometry    */
     double *d_cmd_out;             /* [S][3] or NULL: Command.acceleration -- u[0..2] when isSafety, else the slow-down  */
                                    /* command (TASK mode only)                                                           */
+    /* Frames that start where FrameKDMap::AddVertex starts (FrameKDMap.cpp:34-52): the raw depth image.  With d_depth != NULL  */
+    /* d_cloud / d_edge are ignored (may be NULL) and the slot runs ProcessDepth (:90-130) and BuildEdgeCloud (:176-214) on the */
+    /* device with amk_pipeline_config.depth -- the edge cloud through the slot's own mCurFrame.Twc (the PREVIOUS frame's        */
+    /* Twb * Tbc of the same position, identity at first, as the reference: :50,209) -- then both index builds; a scene whose  */
+    /* frame yields no obstacle point keeps its previous frame and its Twc (:39-41).  The down-scaled image must fit the       */
+    /* pipeline's capacities: (cols / resize_scale) * (rows / resize_scale) <= max_points and <= max_edge_points.              */
+    const void *d_depth;           /* [S][rows][cols] uint16 / float32 (depth_type: AMK_DEPTH_U16 / AMK_DEPTH_F32) or NULL */
+    int depth_type, depth_rows, depth_cols, reserved;
+    const double *d_Twb;           /* [S][16] world <- body, row-major (DepthCallback, AvoidanceStateMachine.cpp:153-164) */
     void *input_ready;             /* hipEvent_t or NULL: recorded by the caller on the stream that produces this       */
                                    /* frame's inputs; the slot's stream waits for it before it reads them.  The event   */
                                    /* must stay alive (and must not be re-recorded) until the frame has been launched   */
@@ -417,15 +438,7 @@ int amk_shard_max(amk_shard *s, double *d_values, int n, void *stream);   /* in-
 /* Depth image -> obstacle cloud: FrameKDMap::ProcessDepth            FrameKDMap.cpp:75-138   */
 /* (the step immediately before the tree build)                   */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct amk_depth_params {
-    double pixel2meter;   /* mParamPixel2Meter   mpc_parameters.yaml:64                            */
-    double depth_min;     /* mParamDepthMin      :66                                               */
-    double depth_max;     /* mParamDepthMax      :65                                               */
-    double resize_scale;  /* mParamDepthScale    :63  (output is cols/scale x rows/scale, truncated) */
-    double fx, fy, cx, cy; /* FULL-resolution intrinsics (:59-62); divided by resize_scale inside,
-                             as the FrameKDMap constructor does (FrameKDMap.cpp:21-24)             */
-    double Tbc[16];       /* body <- camera, row-major 4x4 (mParamTbc)                             */
-} amk_depth_params;
+/* amk_depth_params: defined with the pipeline, above */
 
 #define AMK_DEPTH_U16 0   /* CV_16UC1 */
 #define AMK_DEPTH_F32 1   /* CV_32FC1 */

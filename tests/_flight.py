@@ -296,3 +296,98 @@ def flight_stats(log, prm, con_dt=None):
                 iters_per_period=float(fl[:, :, 3].mean()), capped_periods=int((fl[:, :, 2] > 0).sum()),
                 x_final_mean=float(log["x"][:, -1, 0].mean()), x_behind_nominal_max=float(-lag.min()),
                 x_ahead_of_nominal_max=float(lag.max()))
+
+
+# ---- flights from the raw depth image: the reference's real regime (640 x 480 / 10 -> 3072-point frames in the yaml; here a
+# 320 x 240 sensor / 5), FrameKDMap::AddVertex's ProcessDepth + BuildEdgeCloud included (FrameKDMap.cpp:34-52,75-214) --------------
+DEPTH_CAM = dict(rows=240, cols=320, pixel2meter=1e-3, depth_min=0.1, depth_max=60.0, resize_scale=5.0, fx=160.0, fy=160.0, cx=160.0,
+                 cy=120.0, Tbc=flight.TBC_YAML)
+
+
+def _depth_frame(world, x):
+    """(depth uint16 [rows, cols] in millimetres, Twb) as the depth callback would hand them over: the pose is the odometry rounded
+    to a micrometre, so that two drivers whose states agree to 1e-9 m render identical images."""
+    c = DEPTH_CAM
+    Twb = np.eye(4); Twb[:3, 3] = np.round(x[0:3], 6)          # Command.yaw = 0 holds the heading: R = I
+    sel = (world.cx > x[0] - 2.0) & (world.cx < x[0] + 40.0)
+    d = flight.render_depth((world.cx[sel], world.cy[sel], world.cr[sel]), Twb, c["Tbc"], c["rows"], c["cols"], c["fx"], c["fy"], c["cx"], c["cy"])
+    return np.clip(np.round(d / c["pixel2meter"]), 0, 65535).astype(np.uint16), Twb
+
+
+def _oracle_depth_flight(job):
+    seed, cfg, periods, world_kw = job
+    from tests import _oracle
+    prm, _ = make_prm(cfg)
+    world = flight.FlightWorld(seed, prm, 1000, **world_kw)
+    x, ref = flight.initial_state(seed, prm)
+    mpc = _oracle.MpcOracle(prm.T, prm.dt, prm.K); mpc.configure(prm)
+    log = _log_arrays(periods)
+    log["x"][0] = x
+    log["n_cloud"] = np.zeros(periods, np.int32); log["n_edge"] = np.zeros(periods, np.int32)
+    Twc = np.eye(4); kd = ke = None
+    for t in range(periods):
+        img, Twb = _depth_frame(world, x)
+        cloud, _ = _oracle.depth_oracle(img, DEPTH_CAM, Twb)
+        if len(cloud):                                          # AddVertex, FrameKDMap.cpp:39-51
+            edge = _oracle.depth_edge_oracle(img, DEPTH_CAM, Twc)[0]
+            if kd is not None:
+                kd.close(); ke.close()
+            kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
+            Twc = Twb @ DEPTH_CAM["Tbc"]
+        log["n_cloud"][t] = kd.size(); log["n_edge"][t] = ke.size()
+        sq, px = flight.period_inputs(x[None], ref[None], prm)
+        r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
+        a = flight.command(r["u"][None], r["flags"][None], x[None], prm)
+        x = flight.apply_command(x[None], a, prm)[0]
+        log["x"][t + 1] = x; log["u"][t] = r["u"]; log["flags"][t] = r["flags"]; log["cmd"][t] = a[0]
+    log["clearance"] = world.clearance(log["x"][:, 0:3])
+    return log
+
+
+def oracle_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, workers=None):
+    from tests import _oracle
+    _oracle.build_oracle()
+    jobs = [(int(s), cfg, periods, world_kw or {}) for s in seeds]
+    return _stack(_pool_map(_oracle_depth_flight, jobs, workers or usable_cores()))
+
+
+def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=None):
+    """The same flights through amk_pipeline frames that START at the depth image (d_depth + d_Twb) in TASK mode."""
+    import torch
+    from avoid_mpc_amd.host import Pipeline, depth_params
+    prm, _ = make_prm(cfg)
+    c = DEPTH_CAM
+    F = len(seeds); B = batch or F; nb = F // B
+    assert F % B == 0 and nb % gang == 0
+    dev = torch.device("cuda", torch.cuda.current_device())
+    worlds = [flight.FlightWorld(int(s), prm, 1000, **(world_kw or {})) for s in seeds]
+    st = [flight.initial_state(int(s), prm) for s in seeds]
+    x = np.stack([a for a, _ in st]); ref0 = np.stack([b for _, b in st])
+    cap = int(c["cols"] / c["resize_scale"]) * int(c["rows"] / c["resize_scale"])
+    dp = depth_params(c["pixel2meter"], c["depth_min"], c["depth_max"], c["resize_scale"], c["fx"], c["fy"], c["cx"], c["cy"], c["Tbc"])
+    pl = Pipeline(nb // gang, B, cap, cap, prm, queue_depth=1, gang=gang, depth=dp)
+    logs = dict(x=np.zeros((F, periods + 1, 10)), u=np.zeros((F, periods, 4)), flags=np.zeros((F, periods, 4), np.int32),
+                cmd=np.zeros((F, periods, 3)))
+    logs["x"][:, 0] = x
+    for t in range(periods):
+        keep, tickets = [], []
+        for b in range(nb):
+            sl = slice(b * B, (b + 1) * B)
+            fr = [_depth_frame(worlds[i], x[i]) for i in range(sl.start, sl.stop)]
+            depth = torch.from_numpy(np.stack([d for d, _ in fr]).view(np.int16)).to(dev)
+            Twb = torch.from_numpy(np.stack([T for _, T in fr])).to(dev)
+            odom = torch.from_numpy(x[sl]).to(dev); cmd = torch.empty((B, 3), dtype=torch.float64, device=dev)
+            r0 = torch.from_numpy(ref0[sl]).to(dev) if t == 0 else None
+            keep.append((depth, Twb, odom, cmd, r0))
+            tickets.append(pl.submit(None, None, ref_path_init=r0, odom=odom, cmd_out=cmd, keep_warm_start=t > 0, depth=depth, Twb=Twb))
+        for b, tk in enumerate(tickets):
+            sl = slice(b * B, (b + 1) * B)
+            pl.wait(tk)
+            o = pl.outputs(tk)
+            a = keep[b][3].cpu().numpy()
+            x[sl] = flight.apply_command(x[sl], a, prm)
+            logs["u"][sl, t] = o["u"]; logs["flags"][sl, t] = o["flags"]; logs["cmd"][sl, t] = a
+        logs["x"][:, t + 1] = x
+    pl.close()
+    logs["clearance"] = np.stack([w.clearance(logs["x"][i, :, 0:3]) for i, w in enumerate(worlds)])
+    return logs

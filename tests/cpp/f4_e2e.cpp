@@ -88,8 +88,8 @@ int main(int argc, char **argv) {
     FILE *o = fopen(argv[2], "wb");
     const int bpp = dtype == 0 ? 2 : 4;
     for (int fr = 0; fr < n_frames; ++fr) {
-        double m[18];   // odom_pos[3] quat[4] vel[3] t_odom accb[3] t_imu t_depth t_step
-        rd(f, m, 18);
+        double m[17];   // odom_pos[3] quat[4] vel[3] t_odom accb[3] t_imu t_depth t_step
+        rd(f, m, 17);
         Image img;
         img.height = rows; img.width = cols; img.encoding = dtype == 0 ? "16UC1" : "32FC1";
         img.step = (uint32_t)(cols * bpp + pad);

@@ -77,3 +77,20 @@ def test_task_mode_equals_host_mode():
     t2 = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4, mode="task", gang=2)
     for t in (t1, t2):
         assert np.array_equal(h["x"], t["x"]) and np.array_equal(h["flags"], t["flags"]) and np.array_equal(h["cmd"], t["cmd"])
+
+
+def test_flights_from_the_raw_depth_image():
+    """Pipeline frames that start where FrameKDMap::AddVertex starts (FrameKDMap.cpp:34-52): rendered 16UC1 depth images ->
+    ProcessDepth + BuildEdgeCloud (through the slot's own stale Twc, :209) -> both index builds -> TASK step, against the oracle
+    chain depth_oracle -> kd_oracle -> step_oracle, over whole flights; one launch per batch and two batches per launch."""
+    seeds = list(range(900, 908))
+    kw = dict(cyl_per_m=2.0, x_first=3.0, length=40.0)
+    o = _flight.oracle_depth_flights(seeds, "C1", 30, world_kw=kw)
+    assert o["n_cloud"].min() > 300 and o["n_edge"].max() > 50 and o["n_cloud"].max() <= 3072
+    prm, _ = _flight.make_prm("C1")
+    for gang, batch in ((1, 8), (2, 4)):
+        g = _flight.gpu_depth_flights(seeds, "C1", 30, world_kw=kw, gang=gang, batch=batch)
+        cmp = _flight.compare(g, o, pos_tol=1e-9)
+        print("\ndepth-image flights, gang %d:" % gang, {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")},
+              _flight.flight_stats(g, prm))
+        assert cmp["dpos_max_while_together"] <= 1e-9 and cmp["separated"] <= 1
