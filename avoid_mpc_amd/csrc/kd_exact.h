@@ -29,8 +29,10 @@
 namespace amk {
 
 constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
-constexpr int kExactThreads = 1024; // 16 wavefronts per scene
-constexpr int kExactBigNode = 1024; // more points than this: the node is split by the whole workgroup
+constexpr int kExactThreads = 1024; // 16 wavefronts per scene (exact_build_rest)
+constexpr int kExactTopThreads = 512; // exact_build_top: 8 wavefronts with a 256-register budget (at 1024 threads / 128 registers the
+                                      // block-wide split spilled ~500 B per lane to scratch)
+constexpr int kExactBigNode = 4096; // more points than this: the node is split by the whole workgroup
 constexpr int kExactTodo = -2;      // feat of a node divideTree has not visited yet (a leaf is -1)
 constexpr int kExactSubtree = 64;   // a node of at most this many points: its whole subtree is built by one wavefront, in registers
 constexpr int kExactSubStack = 12;  // pending right children of that wavefront (deeper: handed back to the level loop)
@@ -82,16 +84,30 @@ struct ExactPtrs {  // the batch
     }
 };
 
-__device__ __forceinline__ double wave_min_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmin(v, __shfl_xor(v, off));
-    return v;
+// min / max over the 64 lanes, every lane gets the result.  DPP inside the rows of 16 lanes (quad_perm xor 1 / xor 2,
+// row_half_mirror, row_mirror: each level is valid because every lane of the lower level already holds that level's result)
+// and four v_readlane for the rows -- ~10 short-latency VALU operations where six __shfl_xor rounds on a double are twelve
+// ds_bpermute_b32 with an LDS-crossbar round trip each.  The bottom of the tree (exact_subtree_wave: 90 % of the nodes) is a
+// chain of such reductions: round 4 measured the build's lower levels at 5 of its 6 ms.
+template <int CTRL>
+__device__ __forceinline__ double exact_dpp_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double wave_max_f64(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
+template <bool MAX>
+__device__ __forceinline__ double wave_minmax_f64(double v) {
+    auto op = [](double a, double b) { return MAX ? fmax(a, b) : fmin(a, b); };
+    v = op(v, exact_dpp_f64<0xB1>(v));    // quad_perm:[1,0,3,2]
+    v = op(v, exact_dpp_f64<0x4E>(v));    // quad_perm:[2,3,0,1]
+    v = op(v, exact_dpp_f64<0x141>(v));   // row_half_mirror
+    v = op(v, exact_dpp_f64<0x140>(v));   // row_mirror
+    const double r0 = readlane_f64(v, 0), r1 = readlane_f64(v, 16), r2 = readlane_f64(v, 32), r3 = readlane_f64(v, 48);
+    return op(op(r0, r1), op(r2, r3));
 }
+__device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
+__device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
 
 // ---- who works on a node: one wavefront, or the whole workgroup.  Both expose the same five collectives.
 struct WaveCoop {
@@ -104,14 +120,18 @@ struct WaveCoop {
         total = __popcll(m);
         return __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
     }
-    __device__ __forceinline__ unsigned sum(unsigned v) const {
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        return v;
+    __device__ __forceinline__ unsigned sum(unsigned v) const {   // DPP inside the rows, v_readlane across them
+        int x = (int)v;
+        x += __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true);
+        x += __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true);
+        return (unsigned)(__builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16) + __builtin_amdgcn_readlane(x, 32) +
+                          __builtin_amdgcn_readlane(x, 48));
     }
     __device__ __forceinline__ double min(double v) const { return wave_min_f64(v); }
     __device__ __forceinline__ double max(double v) const { return wave_max_f64(v); }
-    __device__ __forceinline__ int bcast(int v) const { return __shfl(v, 0); }
+    __device__ __forceinline__ int bcast(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 };
 struct BlockCoop {  // every thread of the kExactThreads workgroup; scratch in LDS (exact_build_scene owns it)
     static constexpr int kN = kExactThreads;
@@ -340,12 +360,12 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
         const unsigned long long mml = __ballot(ml), mmr = __ballot(mr);
         if (ml) ws->il[__popcll(mml & ((1ull << lane) - 1ull))] = (unsigned char)lane;              // ascending
         if (mr) ws->ir[__popcll(mmr & ~((2ull << lane) - 1ull))] = (unsigned char)lane;             // descending
-        __threadfence_block();   // the two lists: written and read by lanes of this wave
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the two lists: written and read by lanes of this wave
         int partner = lane;
         if (ml) partner = ws->ir[__popcll(mml & ((1ull << lane) - 1ull))];
         if (mr) partner = ws->il[__popcll(mmr & ~((2ull << lane) - 1ull))];
         vi = __shfl(vi, partner); px = __shfl(px, partner); py = __shfl(py, partner); pz = __shfl(pz, partner);
-        __threadfence_block();   // (the lists are rewritten by the next partition)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the lists are rewritten by the next partition)
         return cnt;
     };
     for (;;) {
@@ -432,23 +452,196 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
     }
 }
 
-// buildIndex for scene s; called by every thread of a kExactThreads block.  n = cloud.pts.size().
-__device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nw = kExactThreads / 64;
-    __shared__ int n_nodes_lds, overflow, head, tail;
-    __shared__ double red[kExactThreads / 64][6];
-    __shared__ unsigned coop_cnt[kExactThreads / 64 + 1];
-    __shared__ double coop_red[kExactThreads / 64];
-    __shared__ ExactSubLds sub[kExactThreads / 64];
-    const BlockCoop gb{coop_cnt, coop_red};
-    const WaveCoop gw{};
-    for (int i = tid; i < n; i += kExactThreads) {  // init_vind + the coordinate planes in the same (identity) order
+
+// ---- round 4: the two ends of the tree that cost the build its 5 ms at 50k points ------------------------------------------
+// (1) Nodes of more than kExactBigNode points (the top 4 levels of a 50k-point tree) are split by the whole workgroup.  Rounds
+// 2-3 ran planeSplit's compactions CHUNK by chunk (1024 elements, two barriers per chunk and direction: ~200 barrier pairs per
+// level).  Here every wavefront owns one contiguous SEGMENT of the node, walks it with ballots (no barrier), keeps its
+// misplaced positions in its own part of the lists, and the sixteen counts meet in LDS once: a partition is three barriers.
+// The passes are fused as well: min / max of all three dimensions in one pass, and ONE statistics pass on the cut dimension
+// (#{v < cut}, #{v == cut}, max{v < cut}, min{v > cut}) gives both partition sizes and divlow / divhigh -- the left child is
+// [all v < cut | idx - lim1 elements equal to cut], so its maximum is cutval when idx > lim1 and max{v < cut} otherwise; the
+// right child mirrors it (nanoflann_two.hpp:1086,1096-1102 take them from the children's recomputed boxes).
+struct ExactBigLds {
+    double red[kExactTopThreads / 64][6];
+    unsigned cnt[kExactTopThreads / 64][2];
+    unsigned pre[2][kExactTopThreads / 64 + 1];
+};
+template <bool STRICT>
+__device__ __forceinline__ void block_partition(const ExactTree &T, unsigned lo, unsigned hi, int dim, double cutval, unsigned cnt,
+                                                ExactBigLds *B) {
+    constexpr int NW = kExactTopThreads / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned n = hi - lo, lim = lo + cnt;
+    const unsigned seg = ((n + NW - 1) / NW + 63) & ~63u;   // whole chunks of 64 per wavefront
+    const unsigned s_lo = min(hi, lo + w * seg), s_hi = min(hi, s_lo + seg);
+    auto pred = [&](unsigned i) {
+        const double v = T.val(i, dim);
+        return STRICT ? v < cutval : v <= cutval;
+    };
+    // misplaced positions of this wavefront's segment, both ASCENDING, at the start of its own part of sa / sb
+    unsigned ml = 0, mr = 0;
+    for (unsigned base = s_lo; base < s_hi; base += 64) {
+        const unsigned i = base + lane;
+        const bool in = i < s_hi;
+        const bool pr = in && pred(i);
+        const bool fl = in && i < lim && !pr, fr = in && i >= lim && pr;
+        const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (fl) T.sa[s_lo + ml + __popcll(bl & below)] = i;
+        if (fr) T.sb[s_lo + mr + __popcll(br & below)] = i;
+        ml += __popcll(bl); mr += __popcll(br);
+    }
+    if (lane == 0) { B->cnt[w][0] = ml; B->cnt[w][1] = mr; }
+    __threadfence_block();
+    __syncthreads();
+    if (tid < 2) {
+        unsigned acc = 0;
+        for (int j = 0; j < NW; ++j) { B->pre[tid][j] = acc; acc += B->cnt[j][tid]; }
+        B->pre[tid][NW] = acc;
+    }
+    __syncthreads();
+    const unsigned total = B->pre[0][NW];   // == B->pre[1][NW]: as many misplaced on the left as on the right
+    // planeSplit's swap loop pairs the j-th misplaced from the left (ascending) with the j-th from the right (DESCENDING)
+    for (unsigned j = tid; j < total; j += kExactTopThreads) {
+        int wl = 0, wr = 0;
+        const unsigned jr = total - 1 - j;
+#pragma unroll
+        for (int st = NW / 2; st > 0; st >>= 1) {   // the last wavefront whose prefix is <= j (prefixes ascend): 4 probes
+            wl += B->pre[0][wl + st] <= j ? st : 0;
+            wr += B->pre[1][wr + st] <= jr ? st : 0;
+        }
+        const unsigned a = T.sa[min(hi, lo + wl * seg) + (j - B->pre[0][wl])];
+        const unsigned b = T.sb[min(hi, lo + wr * seg) + (jr - B->pre[1][wr])];
+        const unsigned ta = T.vind[a], tb = T.vind[b];
+        T.vind[a] = tb; T.vind[b] = ta;
+        float *p0 = T.plane(0), *p1 = T.plane(1), *p2 = T.plane(2);
+        const float xa = p0[a], xb = p0[b], ya = p1[a], yb = p1[b], za = p2[a], zb = p2[b];
+        p0[a] = xb; p0[b] = xa; p1[a] = yb; p1[b] = ya; p2[a] = zb; p2[b] = za;
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+__device__ __forceinline__ void exact_process_big_node(const ExactTree &T, int id, int *n_nodes_lds, int *overflow, ExactBigLds *B) {
+    constexpr int NW = kExactTopThreads / 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned l = T.left[id], r = T.right[id], count = r - l;
+    const double b0l = T.nbbox[(size_t)id * 6 + 0], b0h = T.nbbox[(size_t)id * 6 + 1], b1l = T.nbbox[(size_t)id * 6 + 2],
+                 b1h = T.nbbox[(size_t)id * 6 + 3], b2l = T.nbbox[(size_t)id * 6 + 4], b2h = T.nbbox[(size_t)id * 6 + 5];
+#define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
+#define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
+    // pass 1: computeMinMax of the three dimensions at once (:1037-1052; the reference computes only those it needs)
+    double mn0 = DBL_MAX, mn1 = DBL_MAX, mn2 = DBL_MAX, mx0 = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
+#pragma unroll 4
+    for (unsigned i = l + tid; i < r; i += kExactTopThreads) {
+        const double x = T.val(i, 0), y = T.val(i, 1), z = T.val(i, 2);
+        mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z);
+    }
+    mn0 = wave_min_f64(mn0); mn1 = wave_min_f64(mn1); mn2 = wave_min_f64(mn2);
+    mx0 = wave_max_f64(mx0); mx1 = wave_max_f64(mx1); mx2 = wave_max_f64(mx2);
+    if (lane == 0) { B->red[w][0] = mn0; B->red[w][1] = mx0; B->red[w][2] = mn1; B->red[w][3] = mx1; B->red[w][4] = mn2; B->red[w][5] = mx2; }
+    __syncthreads();
+    mn0 = B->red[0][0]; mx0 = B->red[0][1]; mn1 = B->red[0][2]; mx1 = B->red[0][3]; mn2 = B->red[0][4]; mx2 = B->red[0][5];
+#pragma unroll
+    for (int j = 1; j < NW; ++j) {
+        mn0 = fmin(mn0, B->red[j][0]); mx0 = fmax(mx0, B->red[j][1]); mn1 = fmin(mn1, B->red[j][2]); mx1 = fmax(mx1, B->red[j][3]);
+        mn2 = fmin(mn2, B->red[j][4]); mx2 = fmax(mx2, B->red[j][5]);
+    }
+    __syncthreads();   // red is reused below
+    // middleSplit_ (:1197-1245)
+    const double EPS = 0.00001;
+    double max_span = b0h - b0l;
+#pragma unroll
+    for (int d = 1; d < 3; ++d) {
+        const double span = bhi(d) - blo(d);
+        if (span > max_span) max_span = span;
+    }
+    double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
+    int cutfeat = 0;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const double span = bhi(d) - blo(d);
+        if (span > (1 - EPS) * max_span) {
+            const double mn = d == 0 ? mn0 : (d == 1 ? mn1 : mn2), mx = d == 0 ? mx0 : (d == 1 ? mx1 : mx2);
+            const double spread = mx - mn;
+            if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
+        }
+    }
+    const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
+    const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
+    // pass 2: the statistics of the cut
+    unsigned na = 0, nb = 0;
+    double maxa = -DBL_MAX, minc = DBL_MAX;
+#pragma unroll 4
+    for (unsigned i = l + tid; i < r; i += kExactTopThreads) {
+        const double v = T.val(i, cutfeat);
+        na += v < cutval ? 1u : 0u; nb += v == cutval ? 1u : 0u;
+        maxa = v < cutval ? fmax(maxa, v) : maxa;
+        minc = v > cutval ? fmin(minc, v) : minc;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { na += __shfl_xor(na, off); nb += __shfl_xor(nb, off); }
+    maxa = wave_max_f64(maxa); minc = wave_min_f64(minc);
+    if (lane == 0) { B->cnt[w][0] = na; B->cnt[w][1] = nb; B->red[w][0] = maxa; B->red[w][1] = minc; }
+    __syncthreads();
+    na = 0; nb = 0; maxa = -DBL_MAX; minc = DBL_MAX;
+#pragma unroll
+    for (int j = 0; j < NW; ++j) { na += B->cnt[j][0]; nb += B->cnt[j][1]; maxa = fmax(maxa, B->red[j][0]); minc = fmin(minc, B->red[j][1]); }
+    __syncthreads();
+    // planeSplit (:1256-1294): the two Hoare partitions
+    const unsigned lim1 = na, lim2 = na + nb;
+    block_partition<true>(T, l, r, cutfeat, cutval, na, B);
+    block_partition<false>(T, l + lim1, r, cutfeat, cutval, nb, B);
+    const unsigned half = count / 2;
+    const unsigned idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+    const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = the left child's high on the cut dimension
+    const double dhi = idx < lim2 ? cutval : minc;     // divhigh = the right child's low
+    int c = 0;
+    if (tid == 0) {
+        c = atomicAdd(n_nodes_lds, 2);
+        if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
+        B->cnt[0][0] = (unsigned)c;
+    }
+    __syncthreads();
+    c = (int)B->cnt[0][0];
+    __syncthreads();
+    if (c < 0) return;
+    if (tid == 0) {
+        T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
+        T.left[c] = l; T.right[c] = l + idx; T.left[c + 1] = l + idx; T.right[c + 1] = r;
+        T.feat[c] = kExactTodo; T.feat[c + 1] = kExactTodo;
+    }
+    if (tid < 6) {
+        const int d = tid >> 1, hi = tid & 1;
+        double vl = hi ? bhi(d) : blo(d), vr = vl;
+        if (d == cutfeat && hi == 1) vl = cutval;  // left_bbox[cutfeat].high = cutval
+        if (d == cutfeat && hi == 0) vr = cutval;  // right_bbox[cutfeat].low = cutval
+        T.nbbox[(size_t)c * 6 + tid] = vl;
+        T.nbbox[(size_t)(c + 1) * 6 + tid] = vr;
+    }
+#undef blo
+#undef bhi
+}
+
+// buildIndex for scene s in two kernels (each called by every thread of a kExactThreads block); n = cloud.pts.size().
+// exact_build_top: identity vAcc_ + planes, computeBoundingBox, and every node of more than kExactBigNode points, level by level,
+// by the whole workgroup; leaves the node count in *T.n_nodes (-1: capacity exceeded) and the remaining nodes marked kExactTodo.
+// exact_build_rest: everything below, one wavefront per node (<= 64 points: the whole subtree in registers).  Two kernels because the two halves
+// want different register files: together (round 3, and the first version of this round) the uniform state of both -- two
+// views of the tree, the LDS blocks -- spilled SGPRs through VGPR lanes into scratch at the 128-VGPR budget of a 1024-thread block.
+__device__ __forceinline__ void exact_build_top(const ExactTree T, int n) {
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = kExactTopThreads / 64;
+    __shared__ int n_nodes_lds, overflow, head, tail, any_big;
+    __shared__ double red[kExactTopThreads / 64][6];
+    __shared__ ExactBigLds big;
+    for (int i = tid; i < n; i += kExactTopThreads) {  // init_vind + the coordinate planes in the same (identity) order
         T.vind[i] = i;
         T.plane(0)[i] = T.x[i]; T.plane(1)[i] = T.y[i]; T.plane(2)[i] = T.z[i];
     }
     // computeBoundingBox (:1694-1720)
     double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
-    for (int i = tid; i < n; i += kExactThreads) {
+    for (int i = tid; i < n; i += kExactTopThreads) {
         const double v[3] = {(double)T.x[i], (double)T.y[i], (double)T.z[i]};
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = fmin(lo[d], v[d]); hi[d] = fmax(hi[d], v[d]); }
@@ -468,21 +661,41 @@ __device__ __forceinline__ void exact_build_scene(const ExactTree T, int n) {
     if (tid == 0 && n > 0) { T.left[0] = 0; T.right[0] = (unsigned)n; T.feat[0] = kExactTodo; }
     __threadfence_block();
     __syncthreads();
-    while (head < tail) {  // one level of divideTree per round
+    while (head < tail) {  // one level of divideTree per round, big nodes only (children are appended behind `tail`)
         const int h = head, t = tail;
-        // big nodes first, one after the other, by the whole workgroup (they only exist in the top levels: a level wider
-        // than 64 nodes is not searched for them -- a big node down there, on pathological data, is split by a wave)
-        const bool look = t - h <= 64;
-        if (look)
-            for (int id = h; id < t; ++id)
-                if (T.right[id] - T.left[id] > (unsigned)kExactBigNode) exact_process_node(gb, T, id, &n_nodes_lds, &overflow);
+        if (tid == 0) any_big = 0;
+        __syncthreads();
+        for (int id = h; id < t; ++id)
+            if (T.right[id] - T.left[id] > (unsigned)kExactBigNode) {
+                exact_process_big_node(T, id, &n_nodes_lds, &overflow, &big);
+                if (tid == 0) any_big = 1;
+            }
         __threadfence_block();
         __syncthreads();
+        if (tid == 0) { head = t; tail = (overflow || !any_big) ? t : n_nodes_lds; }
+        __syncthreads();
+    }
+    if (tid == 0) *T.n_nodes = overflow ? -1 : n_nodes_lds;
+}
+
+__device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
+    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = kExactThreads / 64;
+    __shared__ int n_nodes_lds, overflow, head, tail;
+    __shared__ ExactSubLds sub[kExactThreads / 64];
+    const WaveCoop gw{};
+    if (tid == 0) {
+        const int nn = *T.n_nodes;
+        n_nodes_lds = nn < 0 ? 0 : nn; overflow = nn < 0 ? 1 : 0; head = 0; tail = nn < 0 ? 0 : nn;   // every node the top kernel left
+    }
+    __syncthreads();
+    (void)n;
+    while (head < tail) {   // one level of divideTree per round
+        const int h = head, t = tail;
         for (int id = h + w; id < t; id += nw) {
-            if (T.feat[id] != kExactTodo) continue;   // built by the wavefront that built its ancestor
+            if (T.feat[id] != kExactTodo) continue;   // split by the top kernel, or built by the wavefront that built its ancestor
             const unsigned cnt = T.right[id] - T.left[id];
             if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
-            else if (!look || cnt <= (unsigned)kExactBigNode) exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+            else exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
         }
         __threadfence_block();
         __syncthreads();

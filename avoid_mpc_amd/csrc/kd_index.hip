@@ -351,9 +351,13 @@ __global__ __launch_bounds__(256) void kd_tie_flags_kernel(amk::GridPtrs gpt, co
 // ------------------------------------------------------------------------------------------------
 // opt-in nanoflann tie order (kd_exact.h): the reference's own tree beside the bucketed index
 // ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(amk::kExactTopThreads) void kd_exact_build_top_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes) {
+    const int s = blockIdx.x;
+    amk::exact_build_top(ep.scene(s), sizes[s]);
+}
 __global__ __launch_bounds__(amk::kExactThreads) void kd_exact_build_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes) {
     const int s = blockIdx.x;
-    amk::exact_build_scene(ep.scene(s), sizes[s]);
+    amk::exact_build_rest(ep.scene(s), sizes[s]);
 }
 
 // one WAVEFRONT per (scene, query): nanoflann's own traversal (kd_exact.h: exact_knn_wave).  Overwrites the outputs of the
@@ -408,6 +412,7 @@ static int exact_build(amk_kd *kd, hipStream_t stream) {
     }
     const int st = ensure_soa(kd, stream);
     if (st != AMK_OK) return st;
+    hipLaunchKernelGGL(kd_exact_build_top_kernel, dim3(kd->n_scenes), dim3(amk::kExactTopThreads), 0, stream, exact_ptrs(kd), kd->size.p);
     hipLaunchKernelGGL(kd_exact_build_kernel, dim3(kd->n_scenes), dim3(amk::kExactThreads), 0, stream, exact_ptrs(kd),
                        kd->size.p);
     AMK_HIP(hipGetLastError());
