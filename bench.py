@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # amk_common.h KernelClass: what the library's HIP-event timing (amk__timing_*) can bracket
 KCLASS = [None, "step_knn_grid_kernel", "step_scan_kernel (cross-check mode only)", "step_plan_pack_kernel", None,
           "mpc_solve_kernel", "step_begin_kernel", "kd_build_kernel"]
-PROFILE_TAG = "r03"
+PROFILE_TAG = "r04"
 N_CU, N_SIMD, CLOCK_GHZ = 256, 4, 2.4   # MI355X: /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -600,7 +600,7 @@ def main():
     # The kernels' OWN durations: a pass with ONE step on the chip at a time (submit, wait, submit, ...), every kernel class
     # bracketed by HIP events on its launch stream.  Nothing else is resident, so submit-to-complete is the kernel's duration
     # (+ a few us of launch latency) -- the number `rocprofv3 --kernel-trace` of `bench.py --streams 1` reports
-    # (profiles/r03_kernel_stats_streams1.md; same scenes: the frames of in-flight slot 0).  In the timed region above the same events also contain the wait for CUs the
+    # (profiles/r04_kernel_stats_streams1.md; same scenes: the frames of in-flight slot 0).  In the timed region above the same events also contain the wait for CUs the
     # other launches in flight occupy, which is why that figure is reported separately as in_flight_submit_to_complete_ms.
     lone = None
     ticket_of_frames0 = None
@@ -681,7 +681,7 @@ def main():
             return k["avg_us"] if k else None
         # what bounds the dominant kernel (SQ counters of the committed profile): VALU issue slots.  Live part: how many
         # solves the timed region ran per second; committed part: VALU instructions per wave-solve (a property of the
-        # kernel on this workload, profiles/r03_pmc_solve_issue.json), 4 issue cycles each on one of 1024 SIMDs.
+        # kernel on this workload, profiles/r04_pmc_solve_issue.json), 4 issue cycles each on one of 1024 SIMDs.
         issue = prof.get("issue")
         valu_per_solve = issue["valu_instructions_per_wave_solve"] if issue else None
         solves_per_s = value * solves
@@ -747,12 +747,17 @@ def main():
                                   "alg_bytes_per_launch": build_alg, "avg_launch_us": build_us,
                                   "achieved": hbm(build_alg, build_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": frac(hbm(build_alg, build_us)), "traffic": build_traffic,
+                                  "alg_bytes_per_launch_survey_8d": 12 * S * gang * (n + ne),
+                                  "frac_survey_8d": frac(hbm(12 * S * gang * (n + ne), build_us)),
                                   "rocprof_avg_us_same_command": rocprof_us("kt1", "kd_build_kernel"),
                                   "in_flight_submit_to_complete_ms": round(inflight_build_ms, 4), "in_flight_launches": cnt[7],
                                   "in_flight_rocprof_avg_us": rocprof_us("kt20", "kd_build_kernel"),
-                                  "note": "the HBM-heavy kernel: algorithmic 28 B per point (12 read, 16 written as a bucket "
-                                          "record), both trees of a frame in one launch (grid.y = tree); "
-                                          "avg_launch_us with one step on the chip at a time"},
+                                  "note": "the HBM-heavy kernel: 28 B per point (12 read, 16 written as an (x, y, z, index) bucket "
+                                          "record), both trees of a frame in one launch (grid.y = tree); avg_launch_us with one step "
+                                          "on the chip at a time.  frac_survey_8d is the same duration against SURVEY 8(d)'s own accounting "
+                                          "(inputs read once: 12 B per point; the survey's K1 budgeted a 4-byte permutation, 16 B per point): "
+                                          "the 16-byte record is this design's choice -- it makes every search a run of contiguous records "
+                                          "instead of a gather through a permutation (DESIGN.md section 4)"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
                                     "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},

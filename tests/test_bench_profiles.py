@@ -1,6 +1,6 @@
-"""CPU: the committed bench line (profiles/r03_bench.json) carries the contract's fields, and every roofline fraction in it
-follows from the committed rocprofv3 summaries of the same commands (profiles/r03_kernel_stats_streams1.json, r03_pmc_*.json)
-within 10 % -- VERDICT r2 item 2 ("my recomputation from profiles/r03_* lands within 10 % of every frac")."""
+"""CPU: the committed bench line (profiles/r04_bench.json) carries the contract's fields, and every roofline fraction in it
+follows from the committed rocprofv3 summaries of the same commands (profiles/r04_kernel_stats_streams1.json, r04_pmc_*.json)
+within 10 % -- VERDICT r2 item 2, kept current every round ("my recomputation from profiles/r04_* lands within 10 % of every frac")."""
 import json
 import os
 
@@ -9,16 +9,16 @@ P = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
 
 
 def test_bench_line_has_the_contract_fields_and_consistent_rooflines():
-    line = P("r03_bench.json")["default_run"]
+    line = P("r04_bench.json")["default_run"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert "workload" in line["config"] and line["config"]["scenes_per_gpu"] == 256 and line["config"]["points"] == 50000
     assert abs(line["value"] - 256 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-3
-    kt1 = P("r03_kernel_stats_streams1.json")["kernels"]
-    issue = P("r03_pmc_solve_issue.json")
-    traffic = P("r03_pmc_traffic.json")["kernels"]
+    kt1 = P("r04_kernel_stats_streams1.json")["kernels"]
+    issue = P("r04_pmc_solve_issue.json")
+    traffic = P("r04_pmc_traffic.json")["kernels"]
     within = lambda a, b, tol=0.10: abs(a - b) <= tol * abs(b)
     # dominant kernel, HBM view: algorithmic bytes / rocprof's single-stream duration / 8 TB/s
     h = line["roofline_hbm"]
