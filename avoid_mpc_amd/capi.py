@@ -82,7 +82,8 @@ class PipelineFrame(C.Structure):
                 ("point_stride", C.c_int), ("keep_warm_start", C.c_int), ("d_state_quad", C.c_void_p), ("d_pos_x", C.c_void_p),
                 ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p), ("d_odom", C.c_void_p), ("odom_age", C.c_double),
                 ("d_cmd_out", C.c_void_p), ("d_depth", C.c_void_p), ("depth_type", C.c_int), ("depth_rows", C.c_int), ("depth_cols", C.c_int),
-                ("reserved", C.c_int), ("d_Twb", C.c_void_p), ("input_ready", C.c_void_p)]
+                ("reserved", C.c_int), ("d_Twb", C.c_void_p), ("kf_obstacle", C.c_void_p), ("kf_edge", C.c_void_p), ("n_keyframes", C.c_int),
+                ("reserved2", C.c_int), ("d_Twc_cur", C.c_void_p), ("camera", C.c_void_p), ("input_ready", C.c_void_p)]
 
 
 class FrameCamera(C.Structure):

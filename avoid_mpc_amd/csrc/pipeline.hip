@@ -37,6 +37,11 @@ struct amk_pipeline {
         const void *depth;                  // raw depth image (amk_pipeline_frame.d_depth): ProcessDepth / BuildEdgeCloud on the device
         int depth_type, depth_rows, depth_cols;
         const double *Twb;
+        // multi-frame map (gang 1 only): the caller's keyframe handles behind the slot's own indices of this frame
+        std::vector<amk_kd *> kf_obstacle, kf_edge;
+        const double *Twc_cur;
+        bool has_camera;
+        amk_frame_camera camera;
     };
     struct Slot {
         hipStream_t stream = nullptr;
@@ -289,7 +294,17 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     double *u = (G == 1 && s.open[0].u_out && !any_task) ? s.open[0].u_out : s.u.p;
     const double *sq = own_inputs ? s.state_quad.p : s.open[0].state_quad, *px = own_inputs ? s.pos_x.p : s.open[0].pos_x;
     s.mpc->run_scenes = filled * S;
-    rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
+    if (!s.open[0].kf_obstacle.empty()) {   // mVecQueryVector = [this frame, keyframes ...] (gang 1: submit() checked)
+        const amk_pipeline::Staged &f = s.open[0];
+        std::vector<amk_kd *> ob{s.obstacle}, ed2{s.edge};
+        ob.insert(ob.end(), f.kf_obstacle.begin(), f.kf_obstacle.end());
+        ed2.insert(ed2.end(), f.kf_edge.begin(), f.kf_edge.end());
+        const double *twc = f.Twc_cur ? f.Twc_cur : (f.depth ? s.Twc.p : nullptr);
+        rc = amk_step_batch_frames(ob.data(), ed2.data(), (int)ob.size(), twc, f.has_camera ? &f.camera : nullptr, s.mpc, &c.step, sq, px,
+                                   s.ref_path.p, u, s.x0array.p, s.flags.p, st);
+    } else {
+        rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
+    }
     s.mpc->run_scenes = 0;
     if (rc != AMK_OK) return rc;
     if (G > 1 || any_task) {
@@ -425,6 +440,13 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     if (!f->d_odom && (!f->d_state_quad || !f->d_pos_x || !f->d_ref_path_init)) return AMK_ERR_INVALID_ARG;
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
+    if (f->n_keyframes < 0 || f->n_keyframes > AMK_MAX_FRAMES - 1) return AMK_ERR_INVALID_ARG;
+    if (f->n_keyframes > 0) {
+        if (p->gang != 1) return AMK_ERR_UNSUPPORTED;   // keyframe handles hold n_scenes scenes, a gang's handles gang x n_scenes
+        if (!f->kf_obstacle || !f->kf_edge) return AMK_ERR_INVALID_ARG;
+        for (int i = 0; i < f->n_keyframes; ++i)
+            if (!f->kf_obstacle[i] || !f->kf_edge[i]) return AMK_ERR_INVALID_ARG;
+    }
     const int stride = f->d_depth ? 3 : (f->point_stride ? f->point_stride : 3);
     if (stride != 3 && stride != 4) return AMK_ERR_INVALID_ARG;
     if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
@@ -443,7 +465,12 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     // staged: the frame's inputs are read when its gang is launched (they stay the caller's until then)
     s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
                                            f->d_ref_path_init, f->d_u_out, f->keep_warm_start, (hipEvent_t)f->input_ready,
-                                           f->d_odom, f->odom_age, f->d_cmd_out, f->d_depth, f->depth_type, f->depth_rows, f->depth_cols, f->d_Twb});
+                                           f->d_odom, f->odom_age, f->d_cmd_out, f->d_depth, f->depth_type, f->depth_rows, f->depth_cols, f->d_Twb,
+                                           {}, {}, f->d_Twc_cur, f->camera != nullptr, f->camera ? *f->camera : amk_frame_camera{}});
+    if (f->n_keyframes > 0) {
+        s.open.back().kf_obstacle.assign(f->kf_obstacle, f->kf_obstacle + f->n_keyframes);
+        s.open.back().kf_edge.assign(f->kf_edge, f->kf_edge + f->n_keyframes);
+    }
     if (ticket_out) *ticket_out = g * ns + si;
     ++p->submitted;
     if ((int)s.open.size() == p->gang) return launch_slot(p, s);

@@ -270,7 +270,8 @@ class Pipeline:
     __del__ = close
 
     def submit(self, clouds, edges, state_quad=None, pos_x=None, ref_path_init=None, cloud_counts=None, edge_counts=None, u_out=None,
-               keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None, depth=None, Twb=None):
+               keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None, depth=None, Twb=None,
+               keyframes=None, Twc_cur=None, cam=None):
         """One fresh frame + control step on the next slot; returns its ticket at once (blocks only when that slot's queue
         is full).  ticket % n_slots = slot; with a gang the frame is staged until the gang is full (or wait / drain).
         All tensors are device tensors that must stay alive until the frame finished.  A slot runs on its own stream: by default
@@ -289,6 +290,12 @@ class Pipeline:
             dinfo = (depth.data_ptr(), kind, int(depth.shape[1]), int(depth.shape[2]), 0, Twb.data_ptr())
         else:
             assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
+        kinfo = (None, None, 0, 0, None, None)
+        if keyframes:   # [(KdBatch obstacle, KdBatch edge), ...]: the multi-frame map [this frame, keyframes ...] (gang 1 only)
+            ko = (C.c_void_p * len(keyframes))(*[k[0].h for k in keyframes]); ke = (C.c_void_p * len(keyframes))(*[k[1].h for k in keyframes])
+            self._kf_keep = (ko, ke, cam)
+            kinfo = (C.cast(ko, C.c_void_p), C.cast(ke, C.c_void_p), len(keyframes), 0, opt(Twc_cur),
+                     C.cast(C.pointer(cam), C.c_void_p) if cam is not None else None)
         ev_ptr = None
         if order_after_current_stream:
             ev = torch.cuda.Event()
@@ -299,7 +306,7 @@ class Pipeline:
                 del self._events[:len(self._events) // 2]
         fr = capi.PipelineFrame(opt(clouds), opt(cloud_counts), opt(edges), opt(edge_counts),
                                 int(clouds.shape[2]) if clouds is not None else 3, int(bool(keep_warm_start)), opt(state_quad), opt(pos_x),
-                                opt(ref_path_init), opt(u_out), opt(odom), float(odom_age), opt(cmd_out), *dinfo, ev_ptr)
+                                opt(ref_path_init), opt(u_out), opt(odom), float(odom_age), opt(cmd_out), *dinfo, *kinfo, ev_ptr)
         slot = C.c_int(-1)
         capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
         return slot.value

@@ -383,6 +383,19 @@ typedef struct amk_pipeline_frame {
     const void *d_depth;           /* [S][rows][cols] uint16 / float32 (depth_type: AMK_DEPTH_U16 / AMK_DEPTH_F32) or NULL */
     int depth_type, depth_rows, depth_cols, reserved;
     const double *d_Twb;           /* [S][16] world <- body, row-major (DepthCallback, AvoidanceStateMachine.cpp:153-164) */
+    /* A multi-frame map: mVecQueryVector = [this frame, keyframes ...] (FrameKDMap.cpp:64-74).  With n_keyframes > 0 the slot  */
+    /* runs amk_step_batch_frames over [its own two indices of this frame, kf_obstacle[i] / kf_edge[i] ...] instead of          */
+    /* amk_step_batch (PtIsInFrame fast path, per-frame merge, minimum distance over the frames: :215-231,254-427).  The         */
+    /* keyframe handles are the caller's (built with amk_kd_build, maintained with amk_kd_keyframe_sweep), hold n_scenes        */
+    /* scenes and must not be rebuilt while the frame is in flight; gang == 1 only (AMK_ERR_UNSUPPORTED otherwise);             */
+    /* n_keyframes <= AMK_MAX_FRAMES - 1.  d_Twc_cur: mCurFrame.Twc per scene for PtIsInFrame (NULL: the slot's own Twc for a   */
+    /* depth frame, else every query counts as inside the current frame); camera: host pointer, copied at submit (NULL: no     */
+    /* frustum test).                                                                                                        */
+    amk_kd *const *kf_obstacle;
+    amk_kd *const *kf_edge;
+    int n_keyframes, reserved2;
+    const double *d_Twc_cur;
+    const struct amk_frame_camera *camera;
     void *input_ready;             /* hipEvent_t or NULL: recorded by the caller on the stream that produces this       */
                                    /* frame's inputs; the slot's stream waits for it before it reads them.  The event   */
                                    /* must stay alive (and must not be re-recorded) until the frame has been launched   */

@@ -318,3 +318,55 @@ def test_task_mode_slow_down_command():
     assert np.array_equal(cmd.cpu().numpy(), want)
     assert np.abs(want[0] - o["u"][0, :3]).max() > 1e-3      # the slow-down command is not the solver's
     pl.close()
+
+
+def test_pipeline_with_keyframes_equals_step_batch_frames():
+    """amk_pipeline_frame.kf_*: the slot's own indices of the frame + the caller's keyframe handles = amk_step_batch_frames over
+    [cur, keyframes ...] (FrameKDMap.cpp:64-74,215-231,254-427), bit for bit; a gang refuses keyframes."""
+    import torch
+    from avoid_mpc_amd.host import KdBatch, MpcBatch, Pipeline, step_batch_frames
+    from tests import _oracle
+    prm = synth.MpcParams(T=0.66, K=8)
+    S, n = 6, 20000
+    scenes = [synth.make_scene(n, 900 + i, prm) for i in range(S)]
+    spans = [(6.0, 30.0), (0.0, 8.0), (3.0, 12.0)]
+    Twc = np.array([[0, 0, 1, -2.0], [-1, 0, 0, 0.0], [0, -1, 0, 1.5], [0, 0, 0, 1.0]])
+    cam = capi.FrameCamera(32.0, 32.0, 32.0, 24.0, 6.0, 64, 48)
+
+    def packed(lst, cap):
+        buf = np.zeros((S, cap, 3), np.float32); cnt = np.zeros(S, np.int32)
+        for s, x in enumerate(lst):
+            buf[s, :len(x)] = x; cnt[s] = len(x)
+        return torch.from_numpy(buf).cuda(), torch.from_numpy(cnt).cuda()
+
+    ne = n // 10
+    clouds = [packed([sc["cloud"][(sc["cloud"][:, 0] >= a) & (sc["cloud"][:, 0] < b)] for sc in scenes], n) for a, b in spans]
+    edges = [packed([sc["edge"][(sc["edge"][:, 0] >= a) & (sc["edge"][:, 0] < b)] for sc in scenes], ne) for a, b in spans]
+    kd_o = [KdBatch(S, n) for _ in spans]; kd_e = [KdBatch(S, ne) for _ in spans]
+    for f in range(3):
+        kd_o[f].build(*clouds[f]); kd_e[f].build(*edges[f])
+    sq = torch.from_numpy(np.stack([_oracle.scene_state_quads(sc, prm) for sc in scenes])).cuda()
+    pos_x = torch.from_numpy(np.array([sc["pos"][0] for sc in scenes])).cuda()
+    ref0 = torch.from_numpy(np.stack([sc["ref_path"] for sc in scenes])).cuda()
+    Tw = torch.from_numpy(np.repeat(Twc[None], S, 0).copy()).cuda()
+    mpc = MpcBatch(prm.T, prm.dt, prm.K, S); mpc.configure(prm)
+    ref = ref0.clone()
+    want = step_batch_frames(kd_o, kd_e, mpc, prm, sq, pos_x, ref, Twc=Tw, cam=cam)
+    torch.cuda.synchronize()
+    pl = Pipeline(1, S, n, ne, prm)
+    t = pl.submit(clouds[0][0], edges[0][0], sq, pos_x, ref0, cloud_counts=clouds[0][1], edge_counts=edges[0][1],
+                  keyframes=[(kd_o[1], kd_e[1]), (kd_o[2], kd_e[2])], Twc_cur=Tw, cam=cam)
+    pl.wait(t)
+    o = pl.outputs(t)
+    assert np.array_equal(o["u"], want["u"].cpu().numpy()) and np.array_equal(o["flags"], want["flags"].cpu().numpy())
+    assert np.array_equal(o["ref_path"], ref.cpu().numpy())
+    mpc1 = MpcBatch(prm.T, prm.dt, prm.K, S); mpc1.configure(prm)       # and the keyframes matter on these scenes
+    ref1 = ref0.clone()
+    single = step_batch_frames(kd_o[:1], kd_e[:1], mpc1, prm, sq, pos_x, ref1, Twc=Tw, cam=cam)
+    torch.cuda.synchronize()
+    assert not torch.equal(single["u"], want["u"])
+    pl.close()
+    pg = Pipeline(1, S, n, ne, prm, gang=2)
+    with pytest.raises(capi.AmkError):
+        pg.submit(clouds[0][0], edges[0][0], sq, pos_x, ref0, keyframes=[(kd_o[1], kd_e[1])])
+    pg.close()
