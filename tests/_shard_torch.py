@@ -1,4 +1,4 @@
-"""Multi-GPU sharding of the batched-scenes sweep: scenes are independent, so
+"""TEST INFRASTRUCTURE (round 2's torch.distributed twin of csrc/shard.hip; the product path is amk_shard_*).  Multi-GPU sharding of the batched-scenes sweep: scenes are independent, so
 they are block-partitioned over ranks (one process per GPU) with no data-path collective; the one
 exchange step is the gather of the per-scene results (4 doubles of control + flags) so that every
 rank -- the reference's single FSM would be rank 0 -- holds all controls.  RCCL over xGMI on the

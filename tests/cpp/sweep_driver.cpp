@@ -130,7 +130,7 @@ int main(int argc, char **argv) {
     rd(f, weights.data(), 25); rd(f, tau.data(), 4); rd(f, gains.data(), 4); rd(f, lim.data(), 5);
     int first = 0, count = 0;
     CHECK(amk_shard_scene_range(rank, world, total, &first, &count));
-    const int S = (total + world - 1) / world;  // equal shards for the collective: the last ranks pad with their last scene
+    const int S = amk_shard_padded_count(world, total);  // equal shards for the collective (ncclAllGather): the last ranks pad with their last scene
     const size_t per_scene = sizeof(float) * 3 * ((size_t)n + ne) + sizeof(double) * ((size_t)max_iter * 10 + 1 + (size_t)N * 10);
     std::vector<float> cl((size_t)S * n * 3), ed((size_t)S * ne * 3);
     std::vector<double> sq((size_t)S * max_iter * 10), posx(S), ref((size_t)S * N * 10);

@@ -29,3 +29,20 @@ def test_bench_line(extra):
     assert d["parity"]["fixtures"]["ok"], d["parity"]["fixtures"]
     chk = d["parity"]["timed_workload_vs_cpu_oracle"]
     assert chk["ok"] and chk["scenes"] == d["config"]["scenes_per_gpu"], chk
+
+
+def test_bench_flight_line():
+    """bench.py --workload flight (closed-loop flights in the pipeline's TASK mode), small shape: one JSON
+    line, warm-started steps, parity block green (the timed run's own flights on the CPU oracle)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "flight", "--streams", "2", "--gang", "2",
+                        "--scenes", "32", "--periods", "12", "--points", "20000", "--warmup", "2"], capture_output=True, text=True,
+                       timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["n_gpus"] == 1 and d["steps"] == 4 * 12 and "flight" in d["config"]["workload"]
+    f = d["flight"]
+    assert f["flights"] == 4 * 32 and f["solves_per_step"] >= 1.0 and f["ipm_iters_per_step"] < f["ipm_iters_first_period"] * 2
+    p = d["parity"]["flights_vs_cpu_oracle"]
+    assert p["ok"] and p["dpos_max_while_flags_agree_m"] <= 1e-6, p

@@ -17,7 +17,7 @@ import os, sys
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch, torch.distributed as dist
-from avoid_mpc_amd import shard
+from tests import _shard_torch as shard
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % PORT, rank=0, world_size=1,
                         device_id=torch.device("cuda", 0))

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from avoid_mpc_amd import shard
+from tests import _shard_torch as shard
 
 
 def _free_port():

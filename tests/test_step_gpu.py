@@ -147,8 +147,8 @@ def test_step_in_nanoflann_tie_order_on_quantised_clouds(torch_cuda):
 def test_full_batch_c3_and_a_c4_shard(torch_cuda):
     """BASELINE configs[2] at its full batch (256 scenes x 50k points in ONE call: the XCD-aware scene mapping
     s = (j / bps) * 8 + xcd and every size_t stride at S = 256) and the scenes a rank of configs[3] owns (2048 scenes
-    block-partitioned over 8 ranks, avoid_mpc_amd/shard.py: rank 5 holds scenes 1280..1535; its first 64)."""
-    from avoid_mpc_amd import shard
+    block-partitioned over 8 ranks, tests/_shard_torch.py: rank 5 holds scenes 1280..1535; its first 64)."""
+    from tests import _shard_torch as shard
     prm = synth.MpcParams(T=0.66, K=8)
     scenes = [synth.make_scene(50000, 100000 + s, prm) for s in range(256)]
     gpu, cpu = run_both(torch_cuda, scenes, prm, n_steps=1)
