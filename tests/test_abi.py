@@ -96,3 +96,32 @@ def test_default_path_kernels_use_no_scratch_memory(lib):
     solve20 = [r for n, r in table.items() if "mpc_solve_kernelILi20" in n][0]
     g = lambda v: (v + 7) // 8 * 8        # allocation granule
     assert 2 * g(build["vgprs"]) + g(solve20["vgprs"]) <= 512, (build, solve20)
+
+
+def test_struct_layouts_of_the_header_equal_the_ctypes_mirrors(tmp_path):
+    """The structs that cross the C ABI by value or by pointer (amk_pipeline_config / _frame, amk_task_params, amk_depth_params,
+    amk_step_params, amk_frame_camera) are mirrored by hand in avoid_mpc_amd/capi.py: a C program compiled against the header
+    prints sizeof and every offsetof, and they must equal the ctypes classes' -- a field added on one side only would
+    silently shift every argument behind it."""
+    import ctypes as C
+    import subprocess
+    pairs = {"amk_step_params": capi.StepParams, "amk_task_params": capi.TaskParams, "amk_depth_params": capi.DepthParams,
+             "amk_frame_camera": capi.FrameCamera, "amk_pipeline_config": capi.PipelineConfig, "amk_pipeline_frame": capi.PipelineFrame}
+    src = ['#include <stddef.h>', '#include <stdio.h>', '#include "avoid_mpc_amd.h"', 'int main(void) {']
+    for cname, cls in pairs.items():
+        src.append(f'printf("{cname} %zu", sizeof({cname}));')
+        for fname, _t in cls._fields_:
+            src.append(f'printf(" {fname}=%zu", offsetof({cname}, {fname}));')
+        src.append('printf("\\n");')
+    src += ['return 0; }']
+    cfile, exe = tmp_path / "layout.c", tmp_path / "layout"
+    cfile.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(cfile), "-o", str(exe)])   # plain C: the header is a C header
+    out = subprocess.check_output([str(exe)], text=True)
+    for line in out.splitlines():
+        tok = line.split()
+        cls = pairs[tok[0]]
+        assert int(tok[1]) == C.sizeof(cls), (tok[0], tok[1], C.sizeof(cls))
+        for kv in tok[2:]:
+            k, v = kv.split("=")
+            assert int(v) == getattr(cls, k).offset, (tok[0], k, v, getattr(cls, k).offset)

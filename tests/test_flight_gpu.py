@@ -94,3 +94,44 @@ def test_flights_from_the_raw_depth_image():
         print("\ndepth-image flights, gang %d:" % gang, {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")},
               _flight.flight_stats(g, prm))
         assert cmp["dpos_max_while_together"] <= 1e-9 and cmp["separated"] <= 1
+
+
+def test_cpp_fleet_host_on_task_mode(tmp_path):
+    """tests/cpp/flight_driver.cpp: a C++ host that only knows include/avoid_mpc_amd.h flies the flights of the Python driver --
+    frames and odometry in, commands out, GetInitPath / warm start / re-plan loop inside the slot -- bit for bit."""
+    import struct
+    import subprocess
+    from avoid_mpc_amd import flight
+    exe = str(tmp_path / "flight_driver")
+    libdir = os.path.join(ROOT, "avoid_mpc_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "flight_driver.cpp"), "-o", exe, "-L", libdir, "-lavoid_mpc_amd",
+                           f"-Wl,-rpath,{libdir}"])
+    seeds = list(range(700, 708))
+    kw = dict(cyl_per_m=2.0, x_first=3.0)
+    P = 30
+    prm, n = _flight.make_prm("C1")
+    want = _flight.gpu_flights(seeds, "C1", P, world_kw=kw, mode="task")
+    worlds = [flight.FlightWorld(s, prm, n, **kw) for s in seeds]
+    st = [flight.initial_state(s, prm) for s in seeds]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("6i", len(seeds), P, n, n // 10, prm.K, prm.max_iter))
+        f.write(np.array([prm.T, prm.dt, prm.speed, prm.safety_distance, prm.decay, prm.height, 500.0, 0.3, 0.3]).tobytes())
+        f.write(np.array(prm.weights, np.float64).tobytes()); f.write(np.array(prm.tau, np.float64).tobytes())
+        f.write(np.array(prm.gain, np.float64).tobytes())
+        f.write(np.array([prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot, prm.radius]).tobytes())
+        f.write(np.stack([a for a, _ in st]).tobytes()); f.write(np.stack([b for _, b in st]).tobytes())
+        for t in range(P):
+            fr = [w.frame(t) for w in worlds]
+            f.write(np.stack([c for c, _ in fr]).tobytes()); f.write(np.stack([e for _, e in fr]).tobytes())
+    subprocess.check_call([exe, fin, fout])
+    buf = open(fout, "rb").read()
+    S, off = len(seeds), 0
+    for t in range(P):
+        x = np.frombuffer(buf, np.float64, S * 10, off).reshape(S, 10); off += x.nbytes
+        cmd = np.frombuffer(buf, np.float64, S * 3, off).reshape(S, 3); off += cmd.nbytes
+        fl = np.frombuffer(buf, np.int32, S * 4, off).reshape(S, 4); off += fl.nbytes
+        assert np.array_equal(fl, want["flags"][:, t]) and np.array_equal(cmd, want["cmd"][:, t]), t
+        assert np.array_equal(x, want["x"][:, t + 1]), t
+    assert off == len(buf)
