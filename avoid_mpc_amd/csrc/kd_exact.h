@@ -678,30 +678,90 @@ __device__ __forceinline__ void exact_build_top(const ExactTree T, int n) {
     if (tid == 0) *T.n_nodes = overflow ? -1 : n_nodes_lds;
 }
 
+constexpr int kExactMaxIdleSpins = 200000;
+constexpr int kExactQueue = 4096;   // ring of open nodes of more than kExactSubtree points (the frontier of a 200 k-point tree holds ~3 k)
 __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
-    const int tid = threadIdx.x, w = __builtin_amdgcn_readfirstlane(tid >> 6), nw = kExactThreads / 64;
-    __shared__ int n_nodes_lds, overflow, head, tail;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    __shared__ int n_nodes_lds, overflow, q_head, q_tail, pending;
+    __shared__ int queue[kExactQueue];
     __shared__ ExactSubLds sub[kExactThreads / 64];
     const WaveCoop gw{};
     if (tid == 0) {
         const int nn = *T.n_nodes;
-        n_nodes_lds = nn < 0 ? 0 : nn; overflow = nn < 0 ? 1 : 0; head = 0; tail = nn < 0 ? 0 : nn;   // every node the top kernel left
+        n_nodes_lds = nn < 0 ? 0 : nn; overflow = nn < 0 ? 1 : 0; q_head = 0; q_tail = 0; pending = 0;
     }
+    for (int i = tid; i < kExactQueue; i += kExactThreads) queue[i] = -1;
     __syncthreads();
     (void)n;
-    while (head < tail) {   // one level of divideTree per round
-        const int h = head, t = tail;
-        for (int id = h + w; id < t; id += nw) {
-            if (T.feat[id] != kExactTodo) continue;   // split by the top kernel, or built by the wavefront that built its ancestor
-            const unsigned cnt = T.right[id] - T.left[id];
-            if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
-            else exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+    // The nodes the top kernel left.  No level loop below them (rounds 2-3 and the first half of round 4 had one: the barrier
+    // per level cost 29 % of this kernel in waiting for the level's slowest wavefront, and every wavefront re-read feat[] of
+    // the nodes other wavefronts had already built, 6 %): a ring of open nodes in LDS.  A wavefront pops a node, splits it (or
+    // builds its whole subtree when it holds <= kExactSubtree points) and pushes the two children; `pending` counts the nodes
+    // pushed and not yet finished, the kernel ends when it reaches zero.  Slot i of the ring holds -1 while it is empty or
+    // reserved; a push that would lap the consumers marks the scene's tree unavailable (the bucketed index answers).
+    const int nn0 = n_nodes_lds;
+    for (int id = tid; id < nn0; id += kExactThreads)
+        if (T.feat[id] == kExactTodo) {
+            const int pos = atomicAdd(&q_tail, 1);
+            if (pos < kExactQueue) { queue[pos] = id; atomicAdd(&pending, 1); }
+            else overflow = 1;
         }
-        __threadfence_block();
-        __syncthreads();
-        if (tid == 0) { head = t; tail = overflow ? t : n_nodes_lds; }
-        __syncthreads();
+    __syncthreads();
+    if (overflow) {   // (more open nodes than the ring holds, or the top kernel ran out of node capacity)
+        if (tid == 0) *T.n_nodes = -1;
+        return;
     }
+    int spins = 0;
+    for (;;) {
+        int id = -1, idle = 0;
+        if (++spins > kExactMaxIdleSpins) {   // bounded waiting: ~0.1 s of idle polling means something is wrong (it never
+            overflow = 1;                     // happened in any test): give up, the scene keeps the bucketed index's answer.
+            break;                            // (Without this bound an earlier build of this loop hung on the hardware; with it
+        }                                     // the loop provably ends, and the compiler cannot treat it as endless either.)
+        if (lane == 0) {
+            for (;;) {
+                const int hd = __atomic_load_n(&q_head, __ATOMIC_RELAXED);
+                if (hd >= __atomic_load_n(&q_tail, __ATOMIC_RELAXED)) break;
+                if (atomicCAS(&q_head, hd, hd + 1) == hd) {
+                    const int slot = hd & (kExactQueue - 1);
+                    do { id = __atomic_load_n(&queue[slot], __ATOMIC_RELAXED); } while (id < 0);   // (reserved, being written)
+                    __atomic_store_n(&queue[slot], -1, __ATOMIC_RELAXED);
+                    break;
+                }
+            }
+            if (id < 0) idle = __atomic_load_n(&pending, __ATOMIC_RELAXED) == 0 || __atomic_load_n(&overflow, __ATOMIC_RELAXED);
+        }
+        id = __builtin_amdgcn_readfirstlane(id);
+        idle = __builtin_amdgcn_readfirstlane(idle);
+        if (id < 0) {
+            if (idle) break;
+            __builtin_amdgcn_s_sleep(8);
+            continue;
+        }
+        spins = 0;
+        const unsigned cnt = T.right[id] - T.left[id];
+        if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
+        else {
+            exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+            __threadfence_block();   // the children's range / box and the permuted window are in memory before anyone can pop them
+            if (lane == 0 && T.feat[id] >= 0) {   // split: the two children are open nodes
+                const int c = T.child[id];
+                const int pos = atomicAdd(&q_tail, 2);
+                if (pos + 2 - __atomic_load_n(&q_head, __ATOMIC_RELAXED) <= kExactQueue) {
+                    atomicAdd(&pending, 2);
+                    for (int e = 0; e < 2; ++e) {
+                        int *slot = &queue[(pos + e) & (kExactQueue - 1)];
+                        while (__atomic_load_n(slot, __ATOMIC_RELAXED) != -1) {}   // (a lapped slot whose consumer has claimed it but not read it yet)
+                        __atomic_store_n(slot, c + e, __ATOMIC_RELAXED);
+                    }
+                } else {
+                    __atomic_store_n(&overflow, 1, __ATOMIC_RELAXED);
+                }
+            }
+        }
+        if (lane == 0) atomicSub(&pending, 1);
+    }
+    __syncthreads();
     if (tid == 0) *T.n_nodes = overflow ? -1 : n_nodes_lds;
 }
 
