@@ -109,7 +109,7 @@ __device__ __forceinline__ double wave_minmax_f64(double v) {
 __device__ __forceinline__ double wave_min_f64(double v) { return wave_minmax_f64<false>(v); }
 __device__ __forceinline__ double wave_max_f64(double v) { return wave_minmax_f64<true>(v); }
 
-// ---- who works on a node: one wavefront, or the whole workgroup.  Both expose the same five collectives.
+// ---- the collectives of the wavefront that works on a node (nodes of more than kExactBigNode points: exact_process_big_node)
 struct WaveCoop {
     static constexpr int kN = 64;
     __device__ __forceinline__ int tid() const { return threadIdx.x & 63; }
@@ -133,89 +133,24 @@ struct WaveCoop {
     __device__ __forceinline__ double max(double v) const { return wave_max_f64(v); }
     __device__ __forceinline__ int bcast(int v) const { return __builtin_amdgcn_readfirstlane(v); }
 };
-struct BlockCoop {  // every thread of the kExactThreads workgroup; scratch in LDS (exact_build_scene owns it)
-    static constexpr int kN = kExactThreads;
-    unsigned *wcnt;   // [kExactThreads / 64 + 1]
-    double *wred;     // [kExactThreads / 64]
-    __device__ __forceinline__ int tid() const { return threadIdx.x; }
-    __device__ __forceinline__ void sync() const { __threadfence_block(); __syncthreads(); }
-    __device__ __forceinline__ unsigned scan(bool f, unsigned &total) const {
-        const int w = threadIdx.x >> 6, nw = kExactThreads / 64;
-        const unsigned long long m = __ballot(f);
-        if ((threadIdx.x & 63) == 0) wcnt[w] = __popcll(m);
-        __syncthreads();
-        unsigned before = 0, tot = 0;
-#pragma unroll
-        for (int j = 0; j < nw; ++j) { const unsigned c = wcnt[j]; before += j < w ? c : 0u; tot += c; }
-        __syncthreads();   // wcnt is reused by the next call
-        total = tot;
-        return before + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
-    }
-    __device__ __forceinline__ unsigned sum(unsigned v) const {
-        unsigned t;
-        // every thread contributes its own value: reduce inside the wave first
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-        if ((threadIdx.x & 63) == 0) wcnt[threadIdx.x >> 6] = v;
-        __syncthreads();
-        t = 0;
-#pragma unroll
-        for (int j = 0; j < kExactThreads / 64; ++j) t += wcnt[j];
-        __syncthreads();
-        return t;
-    }
-    template <bool MAX>
-    __device__ __forceinline__ double red(double v) const {
-        v = MAX ? wave_max_f64(v) : wave_min_f64(v);
-        if ((threadIdx.x & 63) == 0) wred[threadIdx.x >> 6] = v;
-        __syncthreads();
-        double t = wred[0];
-#pragma unroll
-        for (int j = 1; j < kExactThreads / 64; ++j) t = MAX ? fmax(t, wred[j]) : fmin(t, wred[j]);
-        __syncthreads();
-        return t;
-    }
-    __device__ __forceinline__ double min(double v) const { return red<false>(v); }
-    __device__ __forceinline__ double max(double v) const { return red<true>(v); }
-    __device__ __forceinline__ int bcast(int v) const {
-        if (threadIdx.x == 0) wcnt[kExactThreads / 64] = (unsigned)v;
-        __syncthreads();
-        const int r = (int)wcnt[kExactThreads / 64];
-        __syncthreads();
-        return r;
-    }
-};
-
-// computeMinMax over positions [lo, hi) of the node (nanoflann_two.hpp:1037-1052)
-template <class G>
-__device__ __forceinline__ void node_minmax(const G &g, const ExactTree &T, unsigned lo, unsigned hi, int dim, double &mn,
-                                            double &mx) {
-    double a = DBL_MAX, b = -DBL_MAX;
-#pragma unroll 4
-    for (unsigned i = lo + g.tid(); i < hi; i += G::kN) {
-        const double v = T.val(i, dim);
-        a = fmin(a, v);
-        b = fmax(b, v);
-    }
-    mn = g.min(a);
-    mx = g.max(b);
-}
-
 // One Hoare partition of planeSplit on the node positions [lo, hi) (absolute positions in vind): elements with
 // pred = true end up in front.  STRICT selects the predicate of the first loop (val < cutval), else the second
 // (val <= cutval).  Returns the number of pred elements (lim - lo).
 template <bool STRICT, class G>
 __device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree &T, unsigned lo, unsigned hi, int dim,
-                                                    double cutval) {
+                                                    double cutval, int known_cnt = -1) {
     const unsigned tid = (unsigned)g.tid();
     auto pred = [&](unsigned i) {
         const double v = T.val(i, dim);
         return STRICT ? v < cutval : v <= cutval;
     };
-    unsigned mine = 0;
+    unsigned cnt = (unsigned)known_cnt;
+    if (known_cnt < 0) {   // (the caller's statistics pass already counted)
+        unsigned mine = 0;
 #pragma unroll 4
-    for (unsigned i = lo + tid; i < hi; i += G::kN) mine += pred(i) ? 1u : 0u;
-    const unsigned cnt = g.sum(mine);
+        for (unsigned i = lo + tid; i < hi; i += G::kN) mine += pred(i) ? 1u : 0u;
+        cnt = g.sum(mine);
+    }
     const unsigned lim = lo + cnt;
     // misplaced on the left: positions in [lo, lim) with !pred, ascending  -> sa[lo + j]
     unsigned ml = 0;
@@ -251,7 +186,11 @@ __device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree 
     return cnt;
 }
 
-// divideTree for node `id` (by the group g): a leaf is marked, an inner node is split and its two children are appended
+// divideTree for node `id` (by the group g): a leaf is marked, an inner node is split and its two children are appended.
+// Eight passes over the node (round 3: thirteen): min / max of the three dimensions in ONE pass (the reference computes only
+// the dimensions whose box span qualifies, :1201-1225 -- the others are simply not used), ONE statistics pass on the cut
+// dimension -- #{v < cut}, #{v == cut}, max{v < cut}, min{v > cut} -- that gives both partition sizes and divlow / divhigh
+// (see exact_process_big_node), then the two Hoare partitions (two list passes and a swap each).
 template <class G>
 __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &T, int id, int *n_nodes_lds, int *overflow) {
     const int tid = g.tid();
@@ -266,6 +205,13 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
                  b1h = T.nbbox[(size_t)id * 6 + 3], b2l = T.nbbox[(size_t)id * 6 + 4], b2h = T.nbbox[(size_t)id * 6 + 5];
 #define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
 #define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
+    double mn0 = DBL_MAX, mn1 = DBL_MAX, mn2 = DBL_MAX, mx0 = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
+#pragma unroll 2
+    for (unsigned i = l + tid; i < r; i += G::kN) {
+        const double x = T.val(i, 0), y = T.val(i, 1), z = T.val(i, 2);
+        mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z);
+    }
+    mn0 = g.min(mn0); mn1 = g.min(mn1); mn2 = g.min(mn2); mx0 = g.max(mx0); mx1 = g.max(mx1); mx2 = g.max(mx2);
     // middleSplit_ (:1197-1245)
     const double EPS = 0.00001;
     double max_span = b0h - b0l;
@@ -280,23 +226,32 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
     for (int d = 0; d < 3; ++d) {
         const double span = bhi(d) - blo(d);
         if (span > (1 - EPS) * max_span) {
-            double mn, mx;
-            node_minmax(g, T, l, r, d, mn, mx);
+            const double mn = d == 0 ? mn0 : (d == 1 ? mn1 : mn2), mx = d == 0 ? mx0 : (d == 1 ? mx1 : mx2);
             const double spread = mx - mn;
             if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
         }
     }
     const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
     const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
+    // the statistics of the cut
+    unsigned na = 0, nb = 0;
+    double maxa = -DBL_MAX, minc = DBL_MAX;
+#pragma unroll 4
+    for (unsigned i = l + tid; i < r; i += G::kN) {
+        const double v = T.val(i, cutfeat);
+        na += v < cutval ? 1u : 0u; nb += v == cutval ? 1u : 0u;
+        maxa = v < cutval ? fmax(maxa, v) : maxa;
+        minc = v > cutval ? fmin(minc, v) : minc;
+    }
+    na = g.sum(na); nb = g.sum(nb); maxa = g.max(maxa); minc = g.min(minc);
     // planeSplit (:1256-1294)
-    const unsigned lim1 = hoare_partition<true>(g, T, l, r, cutfeat, cutval);
-    const unsigned lim2 = lim1 + hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval);
+    const unsigned lim1 = hoare_partition<true>(g, T, l, r, cutfeat, cutval, (int)na);
+    const unsigned lim2 = lim1 + hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval, (int)nb);
     const unsigned half = count / 2;
     const unsigned idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
     // refined boxes of the children on the cut dimension (:1086,1096-1102)
-    double dlo, dhi, t0, t1;
-    node_minmax(g, T, l, l + idx, cutfeat, t0, dlo);      // divlow  = left child's high
-    node_minmax(g, T, l + idx, r, cutfeat, dhi, t1);      // divhigh = right child's low
+    const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = the left child's high
+    const double dhi = idx < lim2 ? cutval : minc;     // divhigh = the right child's low
     int c = 0;
     if (tid == 0) {
         c = atomicAdd(n_nodes_lds, 2);
