@@ -370,3 +370,37 @@ def test_pipeline_with_keyframes_equals_step_batch_frames():
     with pytest.raises(capi.AmkError):
         pg.submit(clouds[0][0], edges[0][0], sq, pos_x, ref0, keyframes=[(kd_o[1], kd_e[1])])
     pg.close()
+
+
+@pytest.mark.parametrize("use_odom_est,age,iter_time", [(True, 0.004, 0.007), (False, 0.0, 0.0)])
+def test_task_mode_clock_model_and_odometry_age(use_odom_est, age, iter_time):
+    """TASK mode's prologue against the host twins for the non-default settings: odometry that is `age` seconds old
+    (GetCurStateQuad extrapolates over now + decay - mTimePos, AvoidanceStateMachine.cpp:183-184,330), a pass duration other
+    than `decay`, and use_odom_est = false (:186-191)."""
+    import torch
+    from avoid_mpc_amd import flight, fsm
+    from avoid_mpc_amd.host import Pipeline
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne = 5, 5000, 500
+    fr = _frames(torch, prm, 1, S, n)[0]
+    rng = np.random.default_rng(8)
+    x = np.zeros((S, 10)); x[:, 0:3] = [0.0, 0.1, prm.height]; x[:, 3] = 0.02; x[:, 4:7] = [prm.speed, 0.3, -0.1] + rng.normal(size=(S, 3)) * 0.2
+    x[:, 7:10] = rng.normal(size=(S, 3))
+    ref0 = np.stack([synth.make_ref_path(x[s, 0:3], prm) for s in range(S)])
+    # host twin: GetInitPath, then the per-pass states
+    ref_h = ref0.copy()
+    it = iter_time if iter_time > 0 else prm.decay
+    sq = np.zeros((S, prm.max_iter, 10))
+    for s in range(S):
+        fsm.get_init_path(ref_h[s], prm.speed, prm.T, x[s, 0], 500.0, prm.height)
+        sq[s] = np.stack([fsm.cur_state_quad(x[s, 0:3], x[s, 4:7], x[s, 7:10], x[s, 3], age + prm.decay + i * it, use_odom_est)
+                          for i in range(prm.max_iter)])
+    ph = Pipeline(1, S, n, ne, prm)
+    t = ph.submit(fr["cl"], fr["ed"], torch.from_numpy(sq).cuda(), torch.from_numpy(x[:, 0].copy()).cuda(), torch.from_numpy(ref_h).cuda())
+    ph.wait(t); want = ph.outputs(t); ph.close()
+    pt = Pipeline(1, S, n, ne, prm, iter_time=iter_time, use_odom_est=use_odom_est)
+    cmd = torch.zeros((S, 3), dtype=torch.float64, device="cuda")
+    t = pt.submit(fr["cl"], fr["ed"], ref_path_init=torch.from_numpy(ref0).cuda(), odom=torch.from_numpy(x).cuda(), odom_age=age, cmd_out=cmd)
+    pt.wait(t); got = pt.outputs(t); pt.close()
+    assert np.array_equal(got["u"], want["u"]) and np.array_equal(got["flags"], want["flags"]) and np.array_equal(got["ref_path"], want["ref_path"])
+    assert np.array_equal(cmd.cpu().numpy(), flight.command(got["u"], got["flags"], x, prm))
