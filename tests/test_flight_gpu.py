@@ -135,3 +135,72 @@ def test_cpp_fleet_host_on_task_mode(tmp_path):
         assert np.array_equal(fl, want["flags"][:, t]) and np.array_equal(cmd, want["cmd"][:, t]), t
         assert np.array_equal(x, want["x"][:, t + 1]), t
     assert off == len(buf)
+
+
+def test_depth_frames_that_yield_no_point():
+    """FrameKDMap::AddVertex returns before both InitializeNew calls (and before Twc is updated) when ProcessDepth yields no point
+    (FrameKDMap.cpp:39-41): a robot whose FIRST frame is empty flies on an empty map (no neighbours: obstacles padded with 1e4,
+    every pass re-plans, AvoidanceStateMachine.cpp:223-231), a robot whose LATER frame is empty keeps the previous frame's
+    indices and Twc.  Three periods, robot 1 blind in period 0, robot 2 blind in period 1, against the oracle chain."""
+    import torch
+    from avoid_mpc_amd import flight
+    from avoid_mpc_amd.host import Pipeline, depth_params
+    from tests import _oracle
+    c = _flight.DEPTH_CAM
+    prm, _ = _flight.make_prm("C1")
+    S, P = 3, 3
+    kw = dict(cyl_per_m=2.0, x_first=3.0, length=40.0)
+    worlds = [flight.FlightWorld(950 + s, prm, 1000, **kw) for s in range(S)]
+    st = [flight.initial_state(950 + s, prm) for s in range(S)]
+    blind = {(0, 1), (1, 2)}            # (period, robot) pairs that see nothing
+    cap = int(c["cols"] / c["resize_scale"]) * int(c["rows"] / c["resize_scale"])
+    dp = depth_params(c["pixel2meter"], c["depth_min"], c["depth_max"], c["resize_scale"], c["fx"], c["fy"], c["cx"], c["cy"], c["Tbc"])
+
+    def frame(t, s, x):
+        img, Twb = _flight._depth_frame(worlds[s], x)
+        return (np.zeros_like(img) if (t, s) in blind else img), Twb
+
+    # ---- oracle chain
+    xo = np.stack([a for a, _ in st]); refo = np.stack([b for _, b in st])
+    mp = [_oracle.MpcOracle(prm.T, prm.dt, prm.K) for _ in range(S)]
+    for m in mp:
+        m.configure(prm)
+    empty = np.zeros((0, 3), np.float32)
+    kd = [_oracle.kd_oracle(empty) for _ in range(S)]; ke = [_oracle.kd_oracle(empty) for _ in range(S)]; Twc = [np.eye(4) for _ in range(S)]
+    want = []
+    for t in range(P):
+        row = []
+        for s in range(S):
+            img, Twb = frame(t, s, xo[s])
+            cloud, _ = _oracle.depth_oracle(img, c, Twb)
+            if len(cloud):
+                kd[s], ke[s] = _oracle.kd_oracle(cloud), _oracle.kd_oracle(_oracle.depth_edge_oracle(img, c, Twc[s])[0])
+                Twc[s] = Twb @ c["Tbc"]
+            sq, px = flight.period_inputs(xo[s][None], refo[s][None], prm)
+            r = _oracle.step_oracle(kd[s], ke[s], mp[s], prm, sq[0], px[0], refo[s])
+            a = flight.command(r["u"][None], r["flags"][None], xo[s][None], prm)
+            xo[s] = flight.apply_command(xo[s][None], a, prm)[0]
+            row.append((r["flags"].copy(), r["u"].copy(), a[0].copy(), kd[s].size()))
+        want.append(row)
+    assert want[0][1][3] == 0 and want[0][1][0][1] == prm.max_iter        # the blind first frame: empty map, every pass re-plans
+    assert want[1][2][3] == want[0][2][3] > 300                           # the blind later frame: the previous index stays
+    # ---- the pipeline
+    dev = torch.device("cuda", torch.cuda.current_device())
+    pl = Pipeline(1, S, cap, cap, prm, depth=dp)
+    x = np.stack([a for a, _ in st]); ref0 = np.stack([b for _, b in st])
+    for t in range(P):
+        fr = [frame(t, s, x[s]) for s in range(S)]
+        depth = torch.from_numpy(np.stack([d for d, _ in fr]).view(np.int16)).to(dev); Twb = torch.from_numpy(np.stack([T for _, T in fr])).to(dev)
+        odom = torch.from_numpy(x).to(dev); cmd = torch.empty((S, 3), dtype=torch.float64, device=dev)
+        tk = pl.submit(None, None, ref_path_init=torch.from_numpy(ref0).to(dev) if t == 0 else None, odom=odom, cmd_out=cmd,
+                       keep_warm_start=t > 0, depth=depth, Twb=Twb)
+        pl.wait(tk)
+        o = pl.outputs(tk)
+        a = cmd.cpu().numpy()
+        sizes = pl.kd(0, 0).sizes()
+        for s in range(S):
+            assert np.array_equal(o["flags"][s], want[t][s][0]), (t, s, o["flags"][s], want[t][s][0])
+            assert np.abs(o["u"][s] - want[t][s][1]).max() <= 1e-6 and np.abs(a[s] - want[t][s][2]).max() <= 1e-6
+            assert sizes[s] == want[t][s][3], (t, s, sizes[s], want[t][s][3])
+        x = flight.apply_command(x, a, prm)
+    pl.close()
