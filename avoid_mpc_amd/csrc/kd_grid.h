@@ -207,6 +207,10 @@ __device__ __forceinline__ void grid_build_scene(int s, const float *__restrict_
 #endif
 constexpr int kTileP = AMK_TILE_P;                                     // points per thread and tile (in registers from load to store)
 constexpr int kTilePoints = kGridBuildThreads * kTileP;        // 4096
+#ifndef AMK_STAGE_RECORDS
+#define AMK_STAGE_RECORDS 4096   // same-box A/B, 256 obstacle builds alone / step steady / flight: 1024 (16 KB) 78.8 us / 547 k / 1.02 M,
+#endif                           // 2048 71.1 / 555 k / 1.05 M, 4096 (the whole tile in one run, 64 KB) 68.7 / 556 k / 1.06 M; unstaged 85-88 / 555 k / 1.04 M
+constexpr int kStageRecords = AMK_STAGE_RECORDS;               // LDS per build block: 16 B x this (two blocks per CU hold 138 of 160 KB)
 __host__ __device__ constexpr int grid_tiles(int max_points) { return max_points <= 0 ? 1 : (max_points + kTilePoints - 1) / kTilePoints; }
 
 __device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__restrict__ src, int stride, int cap, int nvis,
@@ -221,6 +225,7 @@ __device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__res
     __shared__ int hist[kGridMaxCells + 2];
     __shared__ int wsum[NW];
     __shared__ int wcnt[kTileP * NW + 1];   // kept points per (round j, wave), then before it; [kTileP * NW] = kept in the tile
+    __shared__ float4 stage[kStageRecords]; // the records of kStageRecords consecutive positions of the tile's window, on their way out
     __shared__ float wmax[NW];
     __shared__ double geo[kGridParamDoubles];
     if (tid == 0) grid_geometry(bbox + 6 * s, nvis, geo, gp);
@@ -322,17 +327,34 @@ __device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__res
             if (tid == 0) cs[ncell + 1] = kept_before + kept_tile;
         }
         __syncthreads();
-        // records into the tile's window (order inside a bucket is irrelevant: results are ordered by (distance, index))
+        // records into the tile's window (order inside a bucket is irrelevant: results are ordered by (distance, index)).
+        // Round 4: through LDS.  Rounds 2-3 stored every record straight to its bucket position -- 64 lanes, 64 different
+        // buckets, 64 separate 16-byte transactions per store instruction: with the stores made (wrongly) consecutive the
+        // build ran 27 % faster, i.e. the write path was transaction-bound.  Now every point takes its position once (LDS
+        // atomic on its bucket's cursor), the records of kStageRecords consecutive positions are put in place in LDS, and
+        // the staged run leaves as whole 1 KB stores per wavefront.
+        // position inside the tile's window (< kTilePoints; kept points only) in place of the cell id: two 16-bit values per register
 #pragma unroll
         for (int j = 0; j < kTileP; ++j) {
-            const bool keep = keepbits >> j & 1;
-            const unsigned long long m = __ballot(keep);
-            if (keep) {
-                const int idx = kept_before + wcnt[j * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
-                const int pos = atomicAdd(&hist[cell2[j / 2] >> (16 * (j & 1)) & 0xffffu], 1);
-                gpt4[pos] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
+            unsigned r = 0;
+            if (keepbits >> j & 1) r = (unsigned)(atomicAdd(&hist[cell2[j / 2] >> (16 * (j & 1)) & 0xffffu], 1) - kept_before);
+            cell2[j / 2] = (j & 1) ? ((cell2[j / 2] & 0xffffu) | r << 16) : ((cell2[j / 2] & 0xffff0000u) | r);
+        }
+        for (int h0 = 0; h0 < kept_tile; h0 += kStageRecords) {
+#pragma unroll
+            for (int j = 0; j < kTileP; ++j) {
+                const bool keep = keepbits >> j & 1;
+                const unsigned long long m = __ballot(keep);
+                const int r = (int)(cell2[j / 2] >> (16 * (j & 1)) & 0xffffu) - h0;
+                if (keep && r >= 0 && r < kStageRecords) {
+                    const int idx = kept_before + wcnt[j * NW + w] + __popcll(m & ((1ull << lane) - 1ull));
+                    stage[r] = make_float4(x[j], y[j], z[j], __int_as_float(idx));
+                }
             }
-            asm volatile("" ::: "memory");   // one record's register quadruple at a time
+            __syncthreads();
+            const int nrec = min(kStageRecords, kept_tile - h0);
+            for (int i = tid; i < nrec; i += kGridBuildThreads) gpt4[kept_before + h0 + i] = stage[i];
+            __syncthreads();   // the staging buffer is refilled by the next run
         }
         kept_before += kept_tile;
         __syncthreads();   // hist / wcnt are rewritten by the next tile
