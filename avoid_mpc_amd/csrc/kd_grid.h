@@ -11,6 +11,7 @@
 // to everything not yet visited.  That is the same branch-and-bound argument as nanoflann's
 // searchLevel (mindist <= worstDist, :1780-1790), applied to rings instead of half-spaces.
 #pragma once
+#include <type_traits>
 #include "kd_device.h"
 
 namespace amk {
@@ -432,6 +433,20 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
     return v;
 }
 
+// minimum over the 64 lanes (every lane gets it): DPP inside the rows of 16, v_readlane across them
+__device__ __forceinline__ double grid_wave_min_f64(double v) {
+    auto dpp = [](double x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), C, 0xF, 0xF, true),
+                                __builtin_amdgcn_update_dpp(0, __double2loint(x), C, 0xF, 0xF, true));
+    };
+    v = fmin(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm:[1,0,3,2]
+    v = fmin(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm:[2,3,0,1]
+    v = fmin(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = fmin(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+    return fmin(fmin(readlane_f64(v, 0), readlane_f64(v, 16)), fmin(readlane_f64(v, 32), readlane_f64(v, 48)));
+}
+
 // Exact k nearest neighbours of (qx,qy,qz).  On return lane i < k holds the i-th best (squared
 // distance, index) in (ld, li) and the position of its record in gs.pt in lpos (the neighbour's coordinates are
 // gs.pt[lpos]: the index build keeps no index-ordered copy of the points); empty slots hold (DBL_MAX, kNoIndex, 0).
@@ -547,10 +562,19 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             fetch(lane, d, ic, ip);
             for (int t0 = 0; t0 < total; t0 += 64) {
                 if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn, ipn);  // next batch in flight while this one is merged
-                unsigned long long m = __ballot(d <= tau);
-                while (m) {  // a lane beats (or ties) the current k-th best
-                    const int src = __ffsll((long long)m) - 1;
-                    m &= m - 1;
+                // candidates that beat (or tie) the current k-th best enter BEST FIRST: the k nearest of a batch tighten tau as
+                // fast as it can be tightened, so a batch costs about as many insertions as it has entries that end up in the
+                // list (<= k) plus exact ties -- rounds 1-3 offered every lane that passed the ballot at the batch's start in
+                // lane order: 64 serial insertions for the first batch of every query, whose tau is still infinite.
+                bool live = d <= tau;   // (NaN: no candidate)
+                for (;;) {
+                    const unsigned long long m = __ballot(live);
+                    if (!m) break;
+                    int src = __ffsll((long long)m) - 1;
+                    if (m & (m - 1)) {   // several: the nearest of them (equal distances: any; the insertion ranks by (distance, index))
+                        const double dmin = grid_wave_min_f64(live ? d : DBL_MAX);
+                        src = __ffsll((long long)__ballot(live && d == dmin)) - 1;
+                    }
                     const double dc = readlane_f64(d, src);
                     const int icc = __builtin_amdgcn_readlane(ic, src);
                     const int ipc = __builtin_amdgcn_readlane(ip, src);
@@ -571,6 +595,7 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                         }
                         tau = readlane_f64(ld, k - 1);
                     }
+                    live = live && lane != src && d <= tau;
                 }
                 d = dn;
                 ic = icn;
