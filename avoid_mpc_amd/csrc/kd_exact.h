@@ -205,14 +205,7 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
                  b1h = T.nbbox[(size_t)id * 6 + 3], b2l = T.nbbox[(size_t)id * 6 + 4], b2h = T.nbbox[(size_t)id * 6 + 5];
 #define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
 #define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
-    double mn0 = DBL_MAX, mn1 = DBL_MAX, mn2 = DBL_MAX, mx0 = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
-#pragma unroll 2
-    for (unsigned i = l + tid; i < r; i += G::kN) {
-        const double x = T.val(i, 0), y = T.val(i, 1), z = T.val(i, 2);
-        mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z);
-    }
-    mn0 = g.min(mn0); mn1 = g.min(mn1); mn2 = g.min(mn2); mx0 = g.max(mx0); mx1 = g.max(mx1); mx2 = g.max(mx2);
-    // middleSplit_ (:1197-1245)
+    // middleSplit_ (:1197-1245): computeMinMax only of the dimensions whose box span qualifies (usually one), in one pass
     const double EPS = 0.00001;
     double max_span = b0h - b0l;
 #pragma unroll
@@ -220,6 +213,17 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
         const double span = bhi(d) - blo(d);
         if (span > max_span) max_span = span;
     }
+    const bool q0 = (b0h - b0l) > (1 - EPS) * max_span, q1 = (b1h - b1l) > (1 - EPS) * max_span, q2 = (b2h - b2l) > (1 - EPS) * max_span;
+    double mn0 = DBL_MAX, mn1 = DBL_MAX, mn2 = DBL_MAX, mx0 = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
+#pragma unroll 4
+    for (unsigned i = l + tid; i < r; i += G::kN) {
+        if (q0) { const double x = T.val(i, 0); mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); }
+        if (q1) { const double y = T.val(i, 1); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); }
+        if (q2) { const double z = T.val(i, 2); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z); }
+    }
+    if (q0) { mn0 = g.min(mn0); mx0 = g.max(mx0); }
+    if (q1) { mn1 = g.min(mn1); mx1 = g.max(mx1); }
+    if (q2) { mn2 = g.min(mn2); mx2 = g.max(mx2); }
     double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
     int cutfeat = 0;
 #pragma unroll
@@ -245,8 +249,10 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
     }
     na = g.sum(na); nb = g.sum(nb); maxa = g.max(maxa); minc = g.min(minc);
     // planeSplit (:1256-1294)
-    const unsigned lim1 = hoare_partition<true>(g, T, l, r, cutfeat, cutval, (int)na);
-    const unsigned lim2 = lim1 + hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval, (int)nb);
+    const unsigned lim1 = na > 0 ? hoare_partition<true>(g, T, l, r, cutfeat, cutval, (int)na) : 0u;
+    // (no element equal to the cut -- the rule on continuous coordinates, where the cut is a box midpoint: the second loop of
+    // planeSplit finds everything in place)
+    const unsigned lim2 = lim1 + (nb > 0 ? hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval, (int)nb) : 0u);
     const unsigned half = count / 2;
     const unsigned idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
     // refined boxes of the children on the cut dimension (:1086,1096-1102)
@@ -313,6 +319,7 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
         const int cnt = __popcll(mp), lim = a + cnt;
         const bool ml = in && lane < lim && !pred, mr = in && lane >= lim && pred;
         const unsigned long long mml = __ballot(ml), mmr = __ballot(mr);
+        if (mml == 0) return cnt;   // nothing misplaced (as many on the right as on the left): e.g. no element equals the cut
         if (ml) ws->il[__popcll(mml & ((1ull << lane) - 1ull))] = (unsigned char)lane;              // ascending
         if (mr) ws->ir[__popcll(mmr & ~((2ull << lane) - 1ull))] = (unsigned char)lane;             // descending
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the two lists: written and read by lanes of this wave
@@ -354,13 +361,21 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
             const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
             const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
             // planeSplit (:1256-1294)
+            // divlow / divhigh from the values on both sides of the cut, as exact_process_node does: the left child is
+            // [all v < cut | idx - lim1 elements equal to cut]
+            double maxa, minc;
+            {
+                const bool in = lane >= l && lane < r;
+                const double v = coord(cutfeat);
+                maxa = wave_max_f64(in && v < cutval ? v : -DBL_MAX);
+                minc = wave_min_f64(in && v > cutval ? v : DBL_MAX);
+            }
             const int lim1 = partition(l, r, cutfeat, cutval, true);
             const int lim2 = lim1 + partition(l + lim1, r, cutfeat, cutval, false);
             const int half = count / 2;
             const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
-            double dlo, dhi, t0, t1;
-            minmax(l, l + idx, cutfeat, t0, dlo);      // divlow  = left child's high
-            minmax(l + idx, r, cutfeat, dhi, t1);      // divhigh = right child's low
+            const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = left child's high
+            const double dhi = idx < lim2 ? cutval : minc;     // divhigh = right child's low
             int c = 0;
             if (lane == 0) {
                 c = atomicAdd(n_nodes_lds, 2);
@@ -546,8 +561,8 @@ __device__ __forceinline__ void exact_process_big_node(const ExactTree &T, int i
     __syncthreads();
     // planeSplit (:1256-1294): the two Hoare partitions
     const unsigned lim1 = na, lim2 = na + nb;
-    block_partition<true>(T, l, r, cutfeat, cutval, na, B);
-    block_partition<false>(T, l + lim1, r, cutfeat, cutval, nb, B);
+    if (na > 0) block_partition<true>(T, l, r, cutfeat, cutval, na, B);
+    if (nb > 0) block_partition<false>(T, l + lim1, r, cutfeat, cutval, nb, B);   // (block-uniform: na, nb come from LDS)
     const unsigned half = count / 2;
     const unsigned idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
     const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = the left child's high on the cut dimension
