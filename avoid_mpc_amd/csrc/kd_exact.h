@@ -29,7 +29,10 @@
 namespace amk {
 
 constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
-constexpr int kExactThreads = 1024; // 16 wavefronts per scene (exact_build_rest)
+#ifndef AMK_EXACT_THREADS
+#define AMK_EXACT_THREADS 1024
+#endif
+constexpr int kExactThreads = AMK_EXACT_THREADS; // 16 wavefronts per scene (exact_build_rest)
 constexpr int kExactTopThreads = 512; // exact_build_top: 8 wavefronts with a 256-register budget (at 1024 threads / 128 registers the
                                       // block-wide split spilled ~500 B per lane to scratch)
 constexpr int kExactBigNode = 4096; // more points than this: the node is split by the whole workgroup
