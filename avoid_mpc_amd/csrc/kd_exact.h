@@ -295,6 +295,29 @@ struct ExactSubLds {   // per wavefront
     int l[kExactSubStack], r[kExactSubStack], id[kExactSubStack];
     double bb[kExactSubStack][6];
 };
+// min / max of a float over the wavefront (every lane gets it): the coordinates ARE floats, min / max do not round, so the
+// reductions of the register-resident subtrees run on one register per value (v_min_f32 / v_max_f32 with a DPP operand: one
+// instruction per level where the double version needs two moves and the operation) and are widened afterwards.
+template <bool MAX>
+__device__ __forceinline__ float wave_minmax_f32(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : fminf(a, b); };
+    auto dpp = [](float x, auto ctrl) {
+        constexpr int C = decltype(ctrl)::value;
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), C, 0xF, 0xF, true));
+    };
+    v = op(v, dpp(v, std::integral_constant<int, 0xB1>{}));    // quad_perm:[1,0,3,2]
+    v = op(v, dpp(v, std::integral_constant<int, 0x4E>{}));    // quad_perm:[2,3,0,1]
+    v = op(v, dpp(v, std::integral_constant<int, 0x141>{}));   // row_half_mirror
+    v = op(v, dpp(v, std::integral_constant<int, 0x140>{}));   // row_mirror
+    const int b = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
+                r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+    return op(op(r0, r1), op(r2, r3));
+}
+// set bits of a wave mask below this lane (v_mbcnt_lo / _hi)
+__device__ __forceinline__ int mask_rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root, int *n_nodes_lds, int *overflow, ExactSubLds *ws) {
     const int lane = threadIdx.x & 63;
     const unsigned L0 = T.left[root];
@@ -306,116 +329,121 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
     int l = 0, r = W, id = root;
     double b0l = T.nbbox[(size_t)root * 6 + 0], b0h = T.nbbox[(size_t)root * 6 + 1], b1l = T.nbbox[(size_t)root * 6 + 2],
            b1h = T.nbbox[(size_t)root * 6 + 3], b2l = T.nbbox[(size_t)root * 6 + 4], b2h = T.nbbox[(size_t)root * 6 + 5];
-    auto coord = [&](int d) { return (double)(d == 0 ? px : (d == 1 ? py : pz)); };
-    auto minmax = [&](int a, int b, int d, double &mn, double &mx) {   // computeMinMax over lanes [a, b)
-        const bool in = lane >= a && lane < b;
-        const double v = coord(d);
-        mn = wave_min_f64(in ? v : DBL_MAX);
-        mx = wave_max_f64(in ? v : -DBL_MAX);
-    };
+    auto coordf = [&](int d) { return d == 0 ? px : (d == 1 ? py : pz); };
     // one Hoare partition of planeSplit over lanes [a, b): returns the number of pred lanes; the registers are permuted
-    auto partition = [&](int a, int b, int d, double cutval, bool strict) {
+    auto partition = [&](int a, int b, float v, double cutval, bool strict) {
         const bool in = lane >= a && lane < b;
-        const double v = coord(d);
-        const bool pred = in && (strict ? v < cutval : v <= cutval);
+        const bool pred = in && (strict ? (double)v < cutval : (double)v <= cutval);
         const unsigned long long mp = __ballot(pred);
         const int cnt = __popcll(mp), lim = a + cnt;
         const bool ml = in && lane < lim && !pred, mr = in && lane >= lim && pred;
         const unsigned long long mml = __ballot(ml), mmr = __ballot(mr);
         if (mml == 0) return cnt;   // nothing misplaced (as many on the right as on the left): e.g. no element equals the cut
-        if (ml) ws->il[__popcll(mml & ((1ull << lane) - 1ull))] = (unsigned char)lane;              // ascending
-        if (mr) ws->ir[__popcll(mmr & ~((2ull << lane) - 1ull))] = (unsigned char)lane;             // descending
+        const int jl = mask_rank_below(mml);                                   // ascending rank among the misplaced on the left
+        const int jr = __popcll(mmr) - mask_rank_below(mmr) - 1;               // descending rank among the misplaced on the right
+        if (ml) ws->il[jl] = (unsigned char)lane;
+        if (mr) ws->ir[jr] = (unsigned char)lane;
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // the two lists: written and read by lanes of this wave
         int partner = lane;
-        if (ml) partner = ws->ir[__popcll(mml & ((1ull << lane) - 1ull))];
-        if (mr) partner = ws->il[__popcll(mmr & ~((2ull << lane) - 1ull))];
+        if (ml) partner = ws->ir[jl];
+        if (mr) partner = ws->il[jr];
         vi = __shfl(vi, partner); px = __shfl(px, partner); py = __shfl(py, partner); pz = __shfl(pz, partner);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");   // (the lists are rewritten by the next partition)
         return cnt;
     };
     for (;;) {
-        const int count = r - l;
-        bool descend = false;
+        const int count = r - l;   // > kExactLeaf, except possibly at the root: a leaf child is marked when its parent is split
         if (count <= kExactLeaf) {
             if (lane == 0) T.feat[id] = -1;
-        } else {
+            break;                 // (only the root can get here: nothing is pending)
+        }
 #define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
 #define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
-            // middleSplit_ (:1197-1245)
-            const double EPS = 0.00001;
-            double max_span = b0h - b0l;
+        // middleSplit_ (:1197-1245)
+        const double EPS = 0.00001;
+        double max_span = b0h - b0l;
 #pragma unroll
-            for (int d = 1; d < 3; ++d) {
-                const double span = bhi(d) - blo(d);
-                if (span > max_span) max_span = span;
-            }
-            double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
-            int cutfeat = 0;
+        for (int d = 1; d < 3; ++d) {
+            const double span = bhi(d) - blo(d);
+            if (span > max_span) max_span = span;
+        }
+        const bool in = lane >= l && lane < r;
+        double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
+        int cutfeat = 0;
 #pragma unroll
-            for (int d = 0; d < 3; ++d) {
-                const double span = bhi(d) - blo(d);
-                if (span > (1 - EPS) * max_span) {
-                    double mn, mx;
-                    minmax(l, r, d, mn, mx);
-                    const double spread = mx - mn;
-                    if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
-                }
+        for (int d = 0; d < 3; ++d) {
+            const double span = bhi(d) - blo(d);
+            if (span > (1 - EPS) * max_span) {   // computeMinMax over the lanes of the node
+                const float v = coordf(d);
+                const double mn = (double)wave_minmax_f32<false>(in ? v : __builtin_inff());
+                const double mx = (double)wave_minmax_f32<true>(in ? v : -__builtin_inff());
+                const double spread = mx - mn;
+                if (spread > max_spread) { cutfeat = d; max_spread = spread; min_elem = mn; max_elem = mx; }
             }
-            const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
-            const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
-            // planeSplit (:1256-1294)
-            // divlow / divhigh from the values on both sides of the cut, as exact_process_node does: the left child is
-            // [all v < cut | idx - lim1 elements equal to cut]
-            double maxa, minc;
-            {
-                const bool in = lane >= l && lane < r;
-                const double v = coord(cutfeat);
-                maxa = wave_max_f64(in && v < cutval ? v : -DBL_MAX);
-                minc = wave_min_f64(in && v > cutval ? v : DBL_MAX);
+        }
+        const double split_val = (blo(cutfeat) + bhi(cutfeat)) / 2;
+        const double cutval = split_val < min_elem ? min_elem : (split_val > max_elem ? max_elem : split_val);
+        // divlow / divhigh from the values on both sides of the cut, as exact_process_node does: the left child is
+        // [all v < cut | idx - lim1 elements equal to cut]  (an empty side's +-inf is never used: see dlo / dhi)
+        const float vc = coordf(cutfeat);
+        const double maxa = (double)wave_minmax_f32<true>(in && (double)vc < cutval ? vc : -__builtin_inff());
+        const double minc = (double)wave_minmax_f32<false>(in && (double)vc > cutval ? vc : __builtin_inff());
+        // planeSplit (:1256-1294)
+        const int lim1 = partition(l, r, vc, cutval, true);
+        const int lim2 = lim1 + partition(l + lim1, r, coordf(cutfeat), cutval, false);
+        const int half = count / 2;
+        const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
+        const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = left child's high
+        const double dhi = idx < lim2 ? cutval : minc;     // divhigh = right child's low
+        int c = 0;
+        if (lane == 0) {
+            c = atomicAdd(n_nodes_lds, 2);
+            if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
+        }
+        c = __builtin_amdgcn_readfirstlane(c);
+        if (c < 0) break;
+        // A child of at most kExactLeaf points is a leaf: marked here, never pushed (nanoflann_two.hpp:1061).  The stack therefore
+        // only ever holds children of more than kExactLeaf points whose sibling is one too: <= 64 / 11 entries.
+        const bool left_leaf = idx <= kExactLeaf, right_leaf = count - idx <= kExactLeaf;
+        {   // the node's record and its children's ranges: one store, lane j writes field j
+            int *ptr = T.feat + id;
+            int val = cutfeat;
+            if (lane == 1) { ptr = T.child + id; val = c; }
+            if (lane == 2) { ptr = (int *)T.left + c; val = (int)(L0 + l); }
+            if (lane == 3) { ptr = (int *)T.right + c; val = (int)(L0 + l + idx); }
+            if (lane == 4) { ptr = (int *)T.left + c + 1; val = (int)(L0 + l + idx); }
+            if (lane == 5) { ptr = (int *)T.right + c + 1; val = (int)(L0 + r); }
+            if (lane == 6) { ptr = T.feat + c; val = left_leaf ? -1 : kExactTodo; }
+            if (lane == 7) { ptr = T.feat + c + 1; val = right_leaf ? -1 : kExactTodo; }
+            if (lane < 8) *ptr = val;
+            if (lane < 2) (lane == 0 ? T.low : T.high)[id] = lane == 0 ? dlo : dhi;
+        }
+        if (!left_leaf && !right_leaf) {   // right child waits: box = this box with low[cutfeat] = cutval
+            if (sp >= kExactSubStack) { if (lane == 0) *overflow = 1; break; }   // (cannot happen: see above)
+            if (lane < 6) {
+                const int d = lane >> 1, hi = lane & 1;
+                ws->bb[sp][lane] = (d == cutfeat && hi == 0) ? cutval : (hi ? bhi(d) : blo(d));
             }
-            const int lim1 = partition(l, r, cutfeat, cutval, true);
-            const int lim2 = lim1 + partition(l + lim1, r, cutfeat, cutval, false);
-            const int half = count / 2;
-            const int idx = lim1 > half ? lim1 : (lim2 < half ? lim2 : half);
-            const double dlo = idx > lim1 ? cutval : maxa;     // divlow  = left child's high
-            const double dhi = idx < lim2 ? cutval : minc;     // divhigh = right child's low
-            int c = 0;
-            if (lane == 0) {
-                c = atomicAdd(n_nodes_lds, 2);
-                if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
-            }
-            c = __shfl(c, 0);
-            if (c >= 0) {
-                const bool room = sp < kExactSubStack;   // else: the right child goes back to the level loop
-                if (lane == 0) {
-                    T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
-                    T.left[c] = L0 + l; T.right[c] = L0 + l + idx; T.left[c + 1] = L0 + l + idx; T.right[c + 1] = L0 + r;
-                    T.feat[c + 1] = kExactTodo;   // (overwritten when this wave gets to it)
-                }
-                // right child: box = this box with low[cutfeat] = cutval
-                if (room) {
-                    if (lane < 6) {
-                        const int d = lane >> 1, hi = lane & 1;
-                        ws->bb[sp][lane] = (d == cutfeat && hi == 0) ? cutval : (hi ? bhi(d) : blo(d));
-                    }
-                    if (lane == 0) { ws->l[sp] = l + idx; ws->r[sp] = r; ws->id[sp] = c + 1; }
-                    ++sp;
-                } else if (lane < 6) {
-                    const int d = lane >> 1, hi = lane & 1;
-                    T.nbbox[(size_t)(c + 1) * 6 + lane] = (d == cutfeat && hi == 0) ? cutval : (hi ? bhi(d) : blo(d));
-                }
-                // left child next: box = this box with high[cutfeat] = cutval
-                if (cutfeat == 0) b0h = cutval; else if (cutfeat == 1) b1h = cutval; else b2h = cutval;
-                r = l + idx;
-                id = c;
-                descend = true;
-            }
+            if (lane == 0) { ws->l[sp] = l + idx; ws->r[sp] = r; ws->id[sp] = c + 1; }
+            ++sp;
+        }
+        if (!left_leaf) {          // left child next: box = this box with high[cutfeat] = cutval
+            if (cutfeat == 0) b0h = cutval; else if (cutfeat == 1) b1h = cutval; else b2h = cutval;
+            r = l + idx;
+            id = c;
+            continue;
+        }
+        if (!right_leaf) {         // right child next: box = this box with low[cutfeat] = cutval
+            if (cutfeat == 0) b0l = cutval; else if (cutfeat == 1) b1l = cutval; else b2l = cutval;
+            l = l + idx;
+            id = c + 1;
+            continue;
+        }
 #undef blo
 #undef bhi
-        }
-        if (descend) continue;
         if (sp == 0) break;
         --sp;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         l = ws->l[sp]; r = ws->r[sp]; id = ws->id[sp];
         b0l = ws->bb[sp][0]; b0h = ws->bb[sp][1]; b1l = ws->bb[sp][2]; b1h = ws->bb[sp][3]; b2l = ws->bb[sp][4]; b2h = ws->bb[sp][5];
     }
@@ -713,7 +741,11 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
         }
         spins = 0;
         const unsigned cnt = T.right[id] - T.left[id];
+#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 1
+        if (cnt <= (unsigned)kExactSubtree) { if (lane == 0) T.feat[id] = -1; }
+#else
         if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
+#endif
         else {
             exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
             __threadfence_block();   // the children's range / box and the permuted window are in memory before anyone can pop them

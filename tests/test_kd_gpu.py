@@ -319,8 +319,14 @@ def test_nanoflann_tie_order_mode(torch_cuda, oracle):
     dup = np.repeat(rng.uniform(-1, 1, (300, 3)).astype(np.float32), 3, axis=0)
     planar = rng.uniform(-3, 3, (2000, 3)).astype(np.float32); planar[:, 2] = 1.0
     nanx = rng.uniform(-2, 2, (700, 3)).astype(np.float32); nanx[::7, 0] = np.nan
+    # geometric coordinates: every box midpoint cuts off ONE point, the tree is a chain (the register-resident subtrees must
+    # not queue the one-point children: a 40-point chain is 29 levels deep)
+    geo = rng.uniform(-0.1, 0.1, (40, 3)).astype(np.float32); geo[:, 0] = (3.0 ** np.arange(40)).astype(np.float32)
+    geo_neg = geo.copy(); geo_neg[:, 0] = -geo_neg[:, 0]
+    geo_mix = rng.uniform(-5, 5, (3000, 3)).astype(np.float32); geo_mix[:36, 1] = (2.5 ** np.arange(3, 39)).astype(np.float32)
     clouds = dict(grid=g, lattice=lattice, dup=dup, planar=planar, random=rng.uniform(-5, 5, (5000, 3)).astype(np.float32),
-                  tiny=rng.uniform(-1, 1, (7, 3)).astype(np.float32), nanx=nanx, eleven=rng.uniform(-1, 1, (11, 3)).astype(np.float32))
+                  tiny=rng.uniform(-1, 1, (7, 3)).astype(np.float32), nanx=nanx, eleven=rng.uniform(-1, 1, (11, 3)).astype(np.float32),
+                  geo=geo, geo_neg=geo_neg, geo_mix=geo_mix)
     differ_default = 0
     for name, c in clouds.items():
         t = _oracle.kd_oracle(c)
@@ -329,6 +335,8 @@ def test_nanoflann_tie_order_mode(torch_cuda, oracle):
         qs = np.concatenate([pts[rng.integers(0, len(pts), 24)].astype(np.float64),
                              pts[rng.integers(0, len(pts), 24)].astype(np.float64) + 0.5,
                              rng.uniform(-6, 6, (16, 3))])
+        if name.startswith("geo"):   # (the shifted queries above are meaningless at 3^39: query at the points and between them)
+            qs = np.concatenate([pts.astype(np.float64)[:40], 0.5 * (pts[:-1] + pts[1:]).astype(np.float64)[:24]])
         kd = KdBatch(1, len(c))
         assert lib.amk_kd_set_tie_order(kd.h, 1) == 0 and lib.amk_kd_set_tie_order(kd.h, 7) == capi.AMK_ERR_UNSUPPORTED
         kd.build(torch.from_numpy(c[None].copy()).cuda())
