@@ -161,6 +161,7 @@ struct BuildArgs {   // one tree's InitializeNew
     double *gparams;
     const int *keep_if_zero;   // [S] or null: scene s keeps its previous index when keep_if_zero[s] == 0 (FrameKDMap::AddVertex
                                // returns before BOTH InitializeNew calls when the frame's obstacle cloud is empty, FrameKDMap.cpp:39-41)
+    float *soa_x, *soa_y, *soa_z;   // or null: the index-ordered planes of the handle's first scene of this entry, written by the build
 };
 // grid = (scenes, trees): blockIdx.y selects the tree.  FrameKDMap::AddVertex builds TWO trees per depth frame (obstacle +
 // edge cloud, FrameKDMap.cpp:44-47): amk_kd_build_pair issues them as one launch, so the small edge build (24 us alone,
@@ -175,8 +176,10 @@ __global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildAr
     int n = a.counts ? a.counts[s] : a.max_points;
     n = n < 0 ? 0 : (n > a.max_points ? a.max_points : n);
     sample_bbox_scene(s, src, a.point_stride, n, a.bbox_out);
+    const size_t so = (size_t)s * a.cap;
     amk::grid_build_tiles_scene(s, src, a.point_stride, a.cap, n, a.bbox_out, a.GP, a.cell_start, a.ntiles, a.gparams,
-                                a.size_out + s, a.pmax_out + s);
+                                a.size_out + s, a.pmax_out + s, a.soa_x ? a.soa_x + so : nullptr, a.soa_y ? a.soa_y + so : nullptr,
+                                a.soa_z ? a.soa_z + so : nullptr);
 }
 // so: first scene of the handle this entry writes (a gang launch builds frame f into scenes [f * S, (f + 1) * S) of the handle)
 static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, long long scene_stride, const int *d_counts,
@@ -184,7 +187,19 @@ static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, lo
     return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap,
                      kd->size.p + so, kd->pmax.p + so, kd->bbox.p + so * 6, kd->gpt.p + so * kd->cap,
                      kd->cell_start.p + so * kd->ntiles * (amk::kGridMaxCells + 2), kd->ntiles,
-                     kd->gparams.p + so * amk::kGridParamDoubles, nullptr};
+                     kd->gparams.p + so * amk::kGridParamDoubles, nullptr, nullptr, nullptr, nullptr};
+}
+// A handle in nanoflann tie order builds its tree from the index-ordered planes right after the index: the build kernel
+// writes them itself (coalesced) instead of kd_records_to_soa_kernel scattering them from the records afterwards.  Returns
+// whether `a` now asks for them (false: allocation failed or not wanted -- ensure_soa makes them on demand as before).
+static bool build_writes_soa(amk_kd *kd, BuildArgs &a, size_t so = 0) {
+    if (!kd->tie_order || kd->cap <= 0) return false;
+    if (!kd->x.p) {
+        const size_t tot = (size_t)kd->n_scenes * kd->cap;
+        if (kd->x.alloc(tot) != hipSuccess || kd->y.alloc(tot) != hipSuccess || kd->z.alloc(tot) != hipSuccess) return false;
+    }
+    a.soa_x = kd->x.p + so * kd->cap; a.soa_y = kd->y.p + so * kd->cap; a.soa_z = kd->z.p + so * kd->cap;
+    return true;
 }
 
 // index-ordered planes from the bucket records (position -> cloud index), NaN padding behind them
@@ -685,11 +700,12 @@ int amk_kd_build(amk_kd *kd, const float *d_xyz, int point_stride, long long sce
     if (!kd || (!d_xyz && kd->max_points > 0) || point_stride < 3 || scene_stride < 0) return AMK_ERR_INVALID_ARG;
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
-        const BuildArgs a = build_args(kd, d_xyz, point_stride, scene_stride, d_counts);
+        BuildArgs a = build_args(kd, d_xyz, point_stride, scene_stride, d_counts);
+        const bool soa = build_writes_soa(kd, a);
         BuildArgs2 args{};
         args.t[0] = a;
         hipLaunchKernelGGL(kd_build_kernel, dim3(kd->n_scenes, 1), dim3(kCompactThreads), 0, (hipStream_t)stream, args);
-        kd->soa_valid = 0;
+        kd->soa_valid = soa ? 1 : 0;
         kd->ex_valid = 0;   // the exact tree (if any) describes the previous cloud until exact_build has run
         kd->async_pending = 1;
     }
@@ -705,13 +721,14 @@ int amk_kd_build_pair(amk_kd *obstacle, const float *d_xyz, const int *d_counts,
         return AMK_ERR_INVALID_ARG;
     {
         amk::TimedLaunch tg(amk::KC_GRID, (hipStream_t)stream);
-        const BuildArgs a = build_args(obstacle, d_xyz, point_stride, (long long)obstacle->max_points * point_stride, d_counts);
-        const BuildArgs b = build_args(edge, d_edge_xyz, point_stride, (long long)edge->max_points * point_stride, d_edge_counts);
+        BuildArgs a = build_args(obstacle, d_xyz, point_stride, (long long)obstacle->max_points * point_stride, d_counts);
+        BuildArgs b = build_args(edge, d_edge_xyz, point_stride, (long long)edge->max_points * point_stride, d_edge_counts);
+        const bool soa_a = build_writes_soa(obstacle, a), soa_b = build_writes_soa(edge, b);
         BuildArgs2 args{};
         args.t[0] = a; args.t[1] = b;
         hipLaunchKernelGGL(kd_build_kernel, dim3(obstacle->n_scenes, 2), dim3(kCompactThreads), 0, (hipStream_t)stream, args);
+        obstacle->soa_valid = soa_a ? 1 : 0; edge->soa_valid = soa_b ? 1 : 0;
         for (amk_kd *kd : {obstacle, edge}) {
-            kd->soa_valid = 0;
             kd->ex_valid = 0;
             kd->async_pending = 1;
         }
@@ -744,9 +761,17 @@ int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes
             args.t[2 * f + 1] = build_args(edge, d_edge_xyz[f], point_stride, (long long)edge->max_points * point_stride, d_edge_counts[f], so);
             if (d_keep_if_zero) args.t[2 * f].keep_if_zero = args.t[2 * f + 1].keep_if_zero = d_keep_if_zero[f];
         }
+        // (a scene that keeps its previous index keeps planes that may predate the tie-order mode: ensure_soa remakes them all)
+        bool soa_o = !d_keep_if_zero, soa_e = !d_keep_if_zero;
+        for (int f = 0; f < n_frames; ++f) {
+            soa_o = soa_o && build_writes_soa(obstacle, args.t[2 * f], (size_t)f * frame_scenes);
+            soa_e = soa_e && build_writes_soa(edge, args.t[2 * f + 1], (size_t)f * frame_scenes);
+        }
+        if (!soa_o) for (int f = 0; f < n_frames; ++f) args.t[2 * f].soa_x = args.t[2 * f].soa_y = args.t[2 * f].soa_z = nullptr;
+        if (!soa_e) for (int f = 0; f < n_frames; ++f) args.t[2 * f + 1].soa_x = args.t[2 * f + 1].soa_y = args.t[2 * f + 1].soa_z = nullptr;
         hipLaunchKernelGGL(kd_build_kernel, dim3(frame_scenes, 2 * n_frames), dim3(kCompactThreads), 0, stream, args);
+        obstacle->soa_valid = soa_o ? 1 : 0; edge->soa_valid = soa_e ? 1 : 0;
         for (amk_kd *kd : {obstacle, edge}) {
-            kd->soa_valid = 0;
             kd->ex_valid = 0;
             kd->async_pending = 1;
         }
