@@ -33,12 +33,21 @@ constexpr int kExactLeaf = 10;      // kd_tree_two.h:68
 #define AMK_EXACT_THREADS 1024
 #endif
 constexpr int kExactThreads = AMK_EXACT_THREADS; // 16 wavefronts per scene (exact_build_rest)
-constexpr int kExactTopThreads = 512; // exact_build_top: 8 wavefronts with a 256-register budget (at 1024 threads / 128 registers the
+#ifndef AMK_EXACT_TOP_THREADS
+#define AMK_EXACT_TOP_THREADS 512
+#endif
+constexpr int kExactTopThreads = AMK_EXACT_TOP_THREADS; // exact_build_top: 8 wavefronts with a 256-register budget (at 1024 threads / 128 registers the
                                       // block-wide split spilled ~500 B per lane to scratch)
 constexpr int kExactBigNode = 4096; // more points than this: the node is split by the whole workgroup
 constexpr int kExactTodo = -2;      // feat of a node divideTree has not visited yet (a leaf is -1)
 constexpr int kExactSubtree = 64;   // a node of at most this many points: its whole subtree is built by one wavefront, in registers
-constexpr int kExactSubStack = 12;  // pending right children of that wavefront (deeper: handed back to the level loop)
+constexpr int kExactSubStack = 8;   // pending right children of that wavefront: only children of more than kExactLeaf points whose sibling
+                                    // is one too are ever pending, <= 64 / 11 of them
+#ifndef AMK_EXACT_WINDOW
+#define AMK_EXACT_WINDOW 416
+#endif
+constexpr int kExactWindow = AMK_EXACT_WINDOW;   // a node of at most this many points: its whole subtree by one wavefront on a copy in LDS
+constexpr int kExactWinStack = 16;  // pending nodes of more than kExactSubtree points inside a window (<= kExactWindow / 65 + the current one)
 constexpr int kExactMaxDepth = 48;  // traversal stack (one frame per level); deeper trees fall back to the bucketed index
 
 struct ExactTree {  // one scene
@@ -59,6 +68,7 @@ struct ExactTree {  // one scene
     size_t pstride;
     int *n_nodes;            // [1] number of nodes; -1: the tree is not available (capacity / depth exceeded)
     int max_nodes;
+    int lists_local;         // sa / sb are a wavefront's own short buffers, indexed from 0 (a window in LDS); else [lo + j]
     __device__ __forceinline__ float *plane(int dim) const { return pc + (size_t)dim * pstride; }
     __device__ __forceinline__ double val(unsigned i, int dim) const { return (double)pc[(size_t)dim * pstride + i]; }
 };
@@ -83,6 +93,7 @@ struct ExactPtrs {  // the batch
         t.root_bbox = root_bbox + (size_t)s * 6;
         t.n_nodes = n_nodes + s;
         t.max_nodes = max_nodes;
+        t.lists_local = 0;
         return t;
     }
 };
@@ -139,46 +150,48 @@ struct WaveCoop {
 // One Hoare partition of planeSplit on the node positions [lo, hi) (absolute positions in vind): elements with
 // pred = true end up in front.  STRICT selects the predicate of the first loop (val < cutval), else the second
 // (val <= cutval).  Returns the number of pred elements (lim - lo).
+// set bits of a wave mask below this lane (v_mbcnt_lo / _hi)
+__device__ __forceinline__ int mask_rank_below(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+}
 template <bool STRICT, class G>
 __device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree &T, unsigned lo, unsigned hi, int dim,
-                                                    double cutval, int known_cnt = -1) {
+                                                    double cutval, int known_cnt) {
     const unsigned tid = (unsigned)g.tid();
-    auto pred = [&](unsigned i) {
-        const double v = T.val(i, dim);
-        return STRICT ? v < cutval : v <= cutval;
-    };
-    unsigned cnt = (unsigned)known_cnt;
-    if (known_cnt < 0) {   // (the caller's statistics pass already counted)
-        unsigned mine = 0;
-#pragma unroll 4
-        for (unsigned i = lo + tid; i < hi; i += G::kN) mine += pred(i) ? 1u : 0u;
-        cnt = g.sum(mine);
-    }
+    const unsigned cnt = (unsigned)known_cnt;   // (the caller's statistics pass counted)
     const unsigned lim = lo + cnt;
-    // misplaced on the left: positions in [lo, lim) with !pred, ascending  -> sa[lo + j]
-    unsigned ml = 0;
-    for (unsigned base = lo; base < lim; base += G::kN) {
-        const unsigned i = base + tid;
-        const bool f = i < lim && !pred(i);
-        unsigned tot;
-        const unsigned at = g.scan(f, tot);
-        if (f) T.sa[lo + ml + at] = i;
-        ml += tot;
-    }
-    // misplaced on the right: positions in [lim, hi) with pred, DESCENDING  -> sb[lo + j]
-    unsigned mr = 0;
-    for (unsigned top = hi; top > lim; top = top > lim + G::kN ? top - G::kN : lim) {
-        const bool in = top >= lim + 1 + tid;  // position top - 1 - tid >= lim
-        const unsigned i = top - 1 - tid;
-        const bool f = in && pred(i);
-        unsigned tot;
-        const unsigned at = g.scan(f, tot);
-        if (f) T.sb[lo + mr + at] = i;
-        mr += tot;
+    const unsigned lb = T.lists_local ? 0u : lo;   // where this partition's lists start in sa / sb
+    // ONE forward pass, four chunks of 64 in flight: misplaced on the left (positions in [lo, lim) with !pred) -> sa[lo + j],
+    // misplaced on the right (positions in [lim, hi) with pred) -> sb[lo + j], both ASCENDING
+    const float *pl = T.plane(dim);
+    unsigned ml = 0, mr = 0;
+    for (unsigned base = lo; base < hi; base += 4 * G::kN) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + G::kN * u + tid;
+            v[u] = i < hi ? pl[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + G::kN * u + tid;
+            const bool in = i < hi;
+            const bool pr = in && (STRICT ? (double)v[u] < cutval : (double)v[u] <= cutval);
+            const bool fl = in && i < lim && !pr, fr = in && i >= lim && pr;
+            const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+            if (fl) T.sa[lb + ml + mask_rank_below(bl)] = i;
+            if (fr) T.sb[lb + mr + mask_rank_below(br)] = i;
+            ml += __popcll(bl); mr += __popcll(br);
+        }
     }
     g.sync();  // the lists were written by other threads of the group
-    for (unsigned j = tid; j < ml; j += G::kN) {  // ml == mr: the j-th from the left swaps with the j-th from the right
-        const unsigned a = T.sa[lo + j], b = T.sb[lo + j];
+    // planeSplit's swap loop pairs the j-th misplaced from the left (ascending) with the j-th from the right (DESCENDING); ml == mr
+#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 4
+    ml = 0;
+#endif
+#pragma unroll 2
+    for (unsigned j = tid; j < ml; j += G::kN) {
+        const unsigned a = T.sa[lb + j], b = T.sb[lb + (ml - 1 - j)];
         const unsigned ta = T.vind[a], tb = T.vind[b];
         T.vind[a] = tb; T.vind[b] = ta;
         float *p0 = T.plane(0), *p1 = T.plane(1), *p2 = T.plane(2);
@@ -194,13 +207,14 @@ __device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree 
 // the dimensions whose box span qualifies, :1201-1225 -- the others are simply not used), ONE statistics pass on the cut
 // dimension -- #{v < cut}, #{v == cut}, max{v < cut}, min{v > cut} -- that gives both partition sizes and divlow / divhigh
 // (see exact_process_big_node), then the two Hoare partitions (two list passes and a swap each).
+// Returns child1 of the split (child2 = child1 + 1), -1 for a leaf or when the node capacity is exhausted.
 template <class G>
-__device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &T, int id, int *n_nodes_lds, int *overflow) {
+__device__ __forceinline__ int exact_process_node(const G &g, const ExactTree &T, int id, int *n_nodes_lds, int *overflow) {
     const int tid = g.tid();
     const unsigned l = T.left[id], r = T.right[id], count = r - l;
     if (count <= (unsigned)kExactLeaf) {
         if (tid == 0) T.feat[id] = -1;
-        return;
+        return -1;
     }
     // the node's box in six scalars: a private array indexed by the cut dimension would live in scratch (or be promoted
     // to 48 B of LDS per thread)
@@ -252,7 +266,11 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
     }
     na = g.sum(na); nb = g.sum(nb); maxa = g.max(maxa); minc = g.min(minc);
     // planeSplit (:1256-1294)
+#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 2
+    const unsigned lim1 = na;
+#else
     const unsigned lim1 = na > 0 ? hoare_partition<true>(g, T, l, r, cutfeat, cutval, (int)na) : 0u;
+#endif
     // (no element equal to the cut -- the rule on continuous coordinates, where the cut is a box midpoint: the second loop of
     // planeSplit finds everything in place)
     const unsigned lim2 = lim1 + (nb > 0 ? hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval, (int)nb) : 0u);
@@ -267,7 +285,7 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
         if (c + 2 > T.max_nodes) { *overflow = 1; c = -1; }
     }
     c = g.bcast(c);
-    if (c < 0) return;
+    if (c < 0) return -1;
     if (tid == 0) {
         T.feat[id] = cutfeat; T.child[id] = c; T.low[id] = dlo; T.high[id] = dhi;
         T.left[c] = l; T.right[c] = l + idx; T.left[c + 1] = l + idx; T.right[c + 1] = r;
@@ -281,6 +299,7 @@ __device__ __forceinline__ void exact_process_node(const G &g, const ExactTree &
         T.nbbox[(size_t)c * 6 + tid] = vl;
         T.nbbox[(size_t)(c + 1) * 6 + tid] = vr;
     }
+    return c;
 #undef blo
 #undef bhi
 }
@@ -313,10 +332,6 @@ __device__ __forceinline__ float wave_minmax_f32(float v) {
     const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16)),
                 r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
     return op(op(r0, r1), op(r2, r3));
-}
-// set bits of a wave mask below this lane (v_mbcnt_lo / _hi)
-__device__ __forceinline__ int mask_rank_below(unsigned long long m) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
 }
 __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root, int *n_nodes_lds, int *overflow, ExactSubLds *ws) {
     const int lane = threadIdx.x & 63;
@@ -454,6 +469,62 @@ __device__ __forceinline__ void exact_subtree_wave(const ExactTree &T, int root,
 }
 
 
+// divideTree for node `root` of 65 .. kExactWindow points AND everything below it, by one wavefront on a COPY of the node's
+// window of vAcc_ and of the coordinate planes in LDS.  Measured before this existed (round 4): a wavefront-level split in
+// global memory is a chain of ~10 dependent round trips (range and box of the node, min / max, statistics, the two lists,
+// the swap, the children's records) = 13 us per node whatever its size, and 56 of the 63 nodes a wavefront splits hold fewer
+// than 512 points.  On the copy the same code runs (exact_process_node / exact_subtree_wave on a view of the tree whose
+// data pointers address the window: flat loads that land in LDS), the node records still go to global memory (stores only),
+// and the window is written back once.
+struct ExactWinLds {   // per wavefront
+    float x[kExactWindow], y[kExactWindow], z[kExactWindow];
+    unsigned vind[kExactWindow];
+    unsigned sa[kExactWindow / 2], sb[kExactWindow / 2];   // as many misplaced on the left as on the right: <= half the node each
+    int stack[kExactWinStack];
+};
+__device__ __forceinline__ void exact_window_wave(const ExactTree &T, int root, int *n_nodes_lds, int *overflow, ExactSubLds *ws,
+                                                  ExactWinLds *win) {
+    const int lane = threadIdx.x & 63;
+    const unsigned L0 = T.left[root];
+    const int W = (int)(T.right[root] - L0);
+    for (int i = lane; i < W; i += 64) {
+        win->x[i] = T.plane(0)[L0 + i]; win->y[i] = T.plane(1)[L0 + i]; win->z[i] = T.plane(2)[L0 + i];
+        win->vind[i] = T.vind[L0 + i];
+    }
+    ExactTree TL = T;   // same node arrays; the data of positions [L0, L0 + W) live in the window
+    TL.pc = (float *)((uintptr_t)(float *)win->x - (uintptr_t)L0 * sizeof(float));
+    TL.pstride = kExactWindow;
+    TL.vind = (unsigned *)((uintptr_t)(unsigned *)win->vind - (uintptr_t)L0 * sizeof(unsigned));
+    TL.sa = win->sa; TL.sb = win->sb;
+    TL.lists_local = 1;
+    const WaveCoop gw{};
+    int sp = 0;
+    if (lane == 0) win->stack[0] = root;
+    sp = 1;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    while (sp > 0) {
+        --sp;
+        const int id = __builtin_amdgcn_readfirstlane(win->stack[sp]);
+        const unsigned cnt = T.right[id] - T.left[id];
+        if (cnt <= (unsigned)kExactSubtree) {
+            exact_subtree_wave(TL, id, n_nodes_lds, overflow, ws);
+        } else {
+            const int c = exact_process_node(gw, TL, id, n_nodes_lds, overflow);
+            __threadfence_block();   // the children's ranges and boxes are read back from memory by this wavefront
+            if (c >= 0) {
+                if (sp + 2 > kExactWinStack) { if (lane == 0) *overflow = 1; break; }   // (cannot happen: each pending node holds > 64 points)
+                if (lane == 0) { win->stack[sp] = c + 1; win->stack[sp + 1] = c; }
+                sp += 2;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    for (int i = lane; i < W; i += 64) {   // the permuted window back into vAcc_ and the coordinate planes
+        T.vind[L0 + i] = win->vind[i];
+        T.plane(0)[L0 + i] = win->x[i]; T.plane(1)[L0 + i] = win->y[i]; T.plane(2)[L0 + i] = win->z[i];
+    }
+}
+
 // ---- round 4: the two ends of the tree that cost the build its 5 ms at 50k points ------------------------------------------
 // (1) Nodes of more than kExactBigNode points (the top 4 levels of a 50k-point tree) are split by the whole workgroup.  Rounds
 // 2-3 ran planeSplit's compactions CHUNK by chunk (1024 elements, two barriers per chunk and direction: ~200 barrier pairs per
@@ -476,22 +547,26 @@ __device__ __forceinline__ void block_partition(const ExactTree &T, unsigned lo,
     const unsigned n = hi - lo, lim = lo + cnt;
     const unsigned seg = ((n + NW - 1) / NW + 63) & ~63u;   // whole chunks of 64 per wavefront
     const unsigned s_lo = min(hi, lo + w * seg), s_hi = min(hi, s_lo + seg);
-    auto pred = [&](unsigned i) {
-        const double v = T.val(i, dim);
-        return STRICT ? v < cutval : v <= cutval;
-    };
     // misplaced positions of this wavefront's segment, both ASCENDING, at the start of its own part of sa / sb
     unsigned ml = 0, mr = 0;
-    for (unsigned base = s_lo; base < s_hi; base += 64) {
-        const unsigned i = base + lane;
-        const bool in = i < s_hi;
-        const bool pr = in && pred(i);
-        const bool fl = in && i < lim && !pr, fr = in && i >= lim && pr;
-        const unsigned long long bl = __ballot(fl), br = __ballot(fr);
-        const unsigned long long below = (1ull << lane) - 1ull;
-        if (fl) T.sa[s_lo + ml + __popcll(bl & below)] = i;
-        if (fr) T.sb[s_lo + mr + __popcll(br & below)] = i;
-        ml += __popcll(bl); mr += __popcll(br);
+    for (unsigned base = s_lo; base < s_hi; base += 256) {   // four chunks per round: their loads are in flight together
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + 64 * u + lane;
+            v[u] = i < s_hi ? T.plane(dim)[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = base + 64 * u + lane;
+            const bool in = i < s_hi;
+            const bool pr = in && (STRICT ? (double)v[u] < cutval : (double)v[u] <= cutval);
+            const bool fl = in && i < lim && !pr, fr = in && i >= lim && pr;
+            const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+            if (fl) T.sa[s_lo + ml + mask_rank_below(bl)] = i;
+            if (fr) T.sb[s_lo + mr + mask_rank_below(br)] = i;
+            ml += __popcll(bl); mr += __popcll(br);
+        }
     }
     if (lane == 0) { B->cnt[w][0] = ml; B->cnt[w][1] = mr; }
     __threadfence_block();
@@ -504,13 +579,14 @@ __device__ __forceinline__ void block_partition(const ExactTree &T, unsigned lo,
     __syncthreads();
     const unsigned total = B->pre[0][NW];   // == B->pre[1][NW]: as many misplaced on the left as on the right
     // planeSplit's swap loop pairs the j-th misplaced from the left (ascending) with the j-th from the right (DESCENDING)
+#pragma unroll 2
     for (unsigned j = tid; j < total; j += kExactTopThreads) {
         int wl = 0, wr = 0;
         const unsigned jr = total - 1 - j;
 #pragma unroll
-        for (int st = NW / 2; st > 0; st >>= 1) {   // the last wavefront whose prefix is <= j (prefixes ascend): 4 probes
-            wl += B->pre[0][wl + st] <= j ? st : 0;
-            wr += B->pre[1][wr + st] <= jr ? st : 0;
+        for (int st = 8; st > 0; st >>= 1) {   // the last wavefront whose prefix is <= j (prefixes ascend): 4 probes (NW <= 16)
+            if (wl + st < NW && B->pre[0][wl + st] <= j) wl += st;
+            if (wr + st < NW && B->pre[1][wr + st] <= jr) wr += st;
         }
         const unsigned a = T.sa[min(hi, lo + wl * seg) + (j - B->pre[0][wl])];
         const unsigned b = T.sb[min(hi, lo + wr * seg) + (jr - B->pre[1][wr])];
@@ -532,12 +608,21 @@ __device__ __forceinline__ void exact_process_big_node(const ExactTree &T, int i
                  b1h = T.nbbox[(size_t)id * 6 + 3], b2l = T.nbbox[(size_t)id * 6 + 4], b2h = T.nbbox[(size_t)id * 6 + 5];
 #define blo(d) ((d) == 0 ? b0l : ((d) == 1 ? b1l : b2l))
 #define bhi(d) ((d) == 0 ? b0h : ((d) == 1 ? b1h : b2h))
-    // pass 1: computeMinMax of the three dimensions at once (:1037-1052; the reference computes only those it needs)
+    // pass 1: computeMinMax (:1037-1052) of the dimensions whose box span qualifies (:1201-1225; usually one), in one pass
+    const double EPS = 0.00001;
+    double max_span = b0h - b0l;
+#pragma unroll
+    for (int d = 1; d < 3; ++d) {
+        const double span = bhi(d) - blo(d);
+        if (span > max_span) max_span = span;
+    }
+    const bool q0 = (b0h - b0l) > (1 - EPS) * max_span, q1 = (b1h - b1l) > (1 - EPS) * max_span, q2 = (b2h - b2l) > (1 - EPS) * max_span;
     double mn0 = DBL_MAX, mn1 = DBL_MAX, mn2 = DBL_MAX, mx0 = -DBL_MAX, mx1 = -DBL_MAX, mx2 = -DBL_MAX;
-#pragma unroll 4
+#pragma unroll 8
     for (unsigned i = l + tid; i < r; i += kExactTopThreads) {
-        const double x = T.val(i, 0), y = T.val(i, 1), z = T.val(i, 2);
-        mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z);
+        if (q0) { const double x = T.val(i, 0); mn0 = fmin(mn0, x); mx0 = fmax(mx0, x); }
+        if (q1) { const double y = T.val(i, 1); mn1 = fmin(mn1, y); mx1 = fmax(mx1, y); }
+        if (q2) { const double z = T.val(i, 2); mn2 = fmin(mn2, z); mx2 = fmax(mx2, z); }
     }
     mn0 = wave_min_f64(mn0); mn1 = wave_min_f64(mn1); mn2 = wave_min_f64(mn2);
     mx0 = wave_max_f64(mx0); mx1 = wave_max_f64(mx1); mx2 = wave_max_f64(mx2);
@@ -551,13 +636,6 @@ __device__ __forceinline__ void exact_process_big_node(const ExactTree &T, int i
     }
     __syncthreads();   // red is reused below
     // middleSplit_ (:1197-1245)
-    const double EPS = 0.00001;
-    double max_span = b0h - b0l;
-#pragma unroll
-    for (int d = 1; d < 3; ++d) {
-        const double span = bhi(d) - blo(d);
-        if (span > max_span) max_span = span;
-    }
     double max_spread = -1.0, min_elem = 0.0, max_elem = 0.0;
     int cutfeat = 0;
 #pragma unroll
@@ -574,7 +652,7 @@ __device__ __forceinline__ void exact_process_big_node(const ExactTree &T, int i
     // pass 2: the statistics of the cut
     unsigned na = 0, nb = 0;
     double maxa = -DBL_MAX, minc = DBL_MAX;
-#pragma unroll 4
+#pragma unroll 8
     for (unsigned i = l + tid; i < r; i += kExactTopThreads) {
         const double v = T.val(i, cutfeat);
         na += v < cutval ? 1u : 0u; nb += v == cutval ? 1u : 0u;
@@ -636,14 +714,14 @@ __device__ __forceinline__ void exact_build_top(const ExactTree T, int n) {
     __shared__ int n_nodes_lds, overflow, head, tail, any_big;
     __shared__ double red[kExactTopThreads / 64][6];
     __shared__ ExactBigLds big;
-    for (int i = tid; i < n; i += kExactTopThreads) {  // init_vind + the coordinate planes in the same (identity) order
-        T.vind[i] = i;
-        T.plane(0)[i] = T.x[i]; T.plane(1)[i] = T.y[i]; T.plane(2)[i] = T.z[i];
-    }
-    // computeBoundingBox (:1694-1720)
+    // init_vind + the coordinate planes in the same (identity) order, and computeBoundingBox (:1694-1720) on the way
     double lo[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, hi[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+#pragma unroll 4
     for (int i = tid; i < n; i += kExactTopThreads) {
-        const double v[3] = {(double)T.x[i], (double)T.y[i], (double)T.z[i]};
+        const float xf = T.x[i], yf = T.y[i], zf = T.z[i];
+        T.vind[i] = i;
+        T.plane(0)[i] = xf; T.plane(1)[i] = yf; T.plane(2)[i] = zf;
+        const double v[3] = {(double)xf, (double)yf, (double)zf};
 #pragma unroll
         for (int d = 0; d < 3; ++d) { lo[d] = fmin(lo[d], v[d]); hi[d] = fmax(hi[d], v[d]); }
     }
@@ -680,12 +758,13 @@ __device__ __forceinline__ void exact_build_top(const ExactTree T, int n) {
 }
 
 constexpr int kExactMaxIdleSpins = 200000;
-constexpr int kExactQueue = 4096;   // ring of open nodes of more than kExactSubtree points (the frontier of a 200 k-point tree holds ~3 k)
+constexpr int kExactQueue = 2048;   // ring of open nodes (only nodes of more than kExactWindow points put their children here: the frontier of a 200 k-point tree holds < 1 k)
 __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ int n_nodes_lds, overflow, q_head, q_tail, pending;
     __shared__ int queue[kExactQueue];
     __shared__ ExactSubLds sub[kExactThreads / 64];
+    __shared__ ExactWinLds win[kExactThreads / 64];
     const WaveCoop gw{};
     if (tid == 0) {
         const int nn = *T.n_nodes;
@@ -693,7 +772,10 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
     }
     for (int i = tid; i < kExactQueue; i += kExactThreads) queue[i] = -1;
     __syncthreads();
-    (void)n;
+    // A window keeps one wavefront busy for ~100 us: small clouds (the reference's own 3072-point frames) take smaller windows,
+    // or most of the sixteen wavefronts would have nothing to do (3072 points, 256 scenes: 0.28 ms with 416-point windows,
+    // 0.19 with 96; 50 k points: 2.55 against 2.70)
+    const unsigned win_thr = (unsigned)max(96, min(kExactWindow, n / 64));
     // The nodes the top kernel left.  No level loop below them (rounds 2-3 and the first half of round 4 had one: the barrier
     // per level cost 29 % of this kernel in waiting for the level's slowest wavefront, and every wavefront re-read feat[] of
     // the nodes other wavefronts had already built, 6 %): a ring of open nodes in LDS.  A wavefront pops a node, splits it (or
@@ -713,6 +795,11 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
         return;
     }
     int spins = 0;
+#ifdef AMK_EXACT_TRACE
+    unsigned long long t_sub = 0, t_win = 0, t_mid = 0, n_sub = 0, n_win = 0, n_mid = 0;
+    const unsigned long long t_begin = wall_clock64();
+    unsigned long long t_last_work = t_begin;
+#endif
     for (;;) {
         int id = -1, idle = 0;
         if (++spins > kExactMaxIdleSpins) {   // bounded waiting: ~0.1 s of idle polling means something is wrong (it never
@@ -741,16 +828,19 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
         }
         spins = 0;
         const unsigned cnt = T.right[id] - T.left[id];
+#ifdef AMK_EXACT_TRACE
+        const unsigned long long t0 = wall_clock64();
+#endif
 #if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 1
         if (cnt <= (unsigned)kExactSubtree) { if (lane == 0) T.feat[id] = -1; }
 #else
         if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
 #endif
+        else if (cnt <= win_thr) exact_window_wave(T, id, &n_nodes_lds, &overflow, &sub[w], &win[w]);
         else {
-            exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
+            const int c = exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
             __threadfence_block();   // the children's range / box and the permuted window are in memory before anyone can pop them
-            if (lane == 0 && T.feat[id] >= 0) {   // split: the two children are open nodes
-                const int c = T.child[id];
+            if (lane == 0 && c >= 0) {   // split: the two children are open nodes
                 const int pos = atomicAdd(&q_tail, 2);
                 if (pos + 2 - __atomic_load_n(&q_head, __ATOMIC_RELAXED) <= kExactQueue) {
                     atomicAdd(&pending, 2);
@@ -765,7 +855,28 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
             }
         }
         if (lane == 0) atomicSub(&pending, 1);
+#ifdef AMK_EXACT_TRACE
+        {
+            const unsigned long long t1 = wall_clock64();
+            if (cnt <= (unsigned)kExactSubtree) { t_sub += t1 - t0; ++n_sub; }
+            else if (cnt <= win_thr) { t_win += t1 - t0; ++n_win; }
+            else { t_mid += t1 - t0; ++n_mid; }
+            t_last_work = t1;
+        }
+#endif
     }
+#ifdef AMK_EXACT_TRACE
+    {
+        const unsigned long long t_end = wall_clock64();
+        __syncthreads();
+        const unsigned long long t_all = wall_clock64();
+        if (blockIdx.x == 0 && lane == 0) {   // 100 MHz ticks
+            unsigned *o = T.sa + w * 16;
+            o[0] = (unsigned)t_sub; o[1] = (unsigned)n_sub; o[2] = (unsigned)t_win; o[3] = (unsigned)n_win; o[4] = (unsigned)t_mid; o[5] = (unsigned)n_mid;
+            o[6] = (unsigned)(t_end - t_begin); o[7] = (unsigned)(t_last_work - t_begin); o[8] = (unsigned)(t_all - t_begin);
+        }
+    }
+#endif
     __syncthreads();
     if (tid == 0) *T.n_nodes = overflow ? -1 : n_nodes_lds;
 }

@@ -795,6 +795,17 @@ int amk__kd_exact_nodes(amk_kd *kd, int *h_nodes) {
     return AMK_OK;
 }
 
+#ifdef AMK_EXACT_TRACE
+// diagnostics build only (tools/experiments/exact_phase_clocks.py): the first n words of the scene-0 list buffer, where the
+// lower-level build kernel leaves its per-wavefront phase clocks
+int amk__kd_exact_trace(amk_kd *kd, unsigned *h, int n) {
+    if (!kd || !h || !kd->ex_sa.p) return AMK_ERR_INVALID_ARG;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h, kd->ex_sa.p, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    return AMK_OK;
+}
+#endif
+
 int amk_kd_set_tie_order(amk_kd *kd, int mode) {
     if (!kd) return AMK_ERR_INVALID_ARG;
     if (mode != AMK_TIES_LOWEST_INDEX && mode != AMK_TIES_NANOFLANN) return AMK_ERR_UNSUPPORTED;
