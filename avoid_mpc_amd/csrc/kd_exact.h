@@ -11,17 +11,20 @@
 //                       (AM/include/kd_tree_two.h:68)
 //   exact_knn_thread    findNeighbors -> computeInitialDistances -> searchLevel + KNNResultSet
 //                       (nanoflann_two.hpp:1563-1586, 1296-1315, 1729-1793, 179-255)
-// The build is level-synchronous, one workgroup (8 wavefronts) per scene.  A node with more than kExactBigNode points is
-// processed by the WHOLE workgroup (the top ~5 levels of a 50k-point tree: one wavefront per node left 7 of 8 waves idle
-// there and the first three levels alone took most of the build), smaller nodes by one WAVEFRONT each.  The data passes of a
-// node (min/max per dimension, the two Hoare partitions of planeSplit) read the coordinates from planes kept IN vAcc_ ORDER
-// (px/py/pz are permuted together with vAcc_), so they are coalesced streams instead of gathers through the permutation.
-// planeSplit's sequential swap loop pairs the j-th misplaced element from the left with the j-th misplaced element from the
-// right; the same permutation is produced here from two order-preserving compactions (ballot + popcount, across the
-// workgroup through an LDS prefix for big nodes) and a parallel swap, so vAcc_ ends up identical.  divlow / divhigh are the
-// refined child boxes' bounds on the cut dimension = max of the left / min of the right subtree's coordinates, taken when
-// the node is split.  Round 2 (wave per node, gathers): 23 ms per 256 x 50k-point build, now 7 ms (0.4 ms at the reference's 3072 points):
-// DESIGN.md section 4.
+// The build of a scene runs in two kernels, one workgroup each.  exact_build_top (8 wavefronts): every node of more than
+// kExactBigNode points -- the top four levels of a 50k-point tree -- is split by the WHOLE workgroup, level by level.
+// exact_build_rest (16 wavefronts): a ring of open nodes in LDS; a wavefront pops a node and
+//   * > kExactWindow points: splits it in global memory (exact_process_node) and pushes the two children,
+//   * 65 .. kExactWindow points: builds everything below it on a copy of its window in LDS (exact_window_wave),
+//   * <= 64 points: builds everything below it with the points in registers (exact_subtree_wave).
+// The data passes of a node (min / max per dimension, the statistics of the cut, the two Hoare partitions of planeSplit) read
+// the coordinates from planes kept IN vAcc_ ORDER (permuted together with vAcc_): coalesced streams instead of gathers
+// through the permutation.  planeSplit's sequential swap loop pairs the j-th misplaced element from the left with the j-th
+// misplaced element from the right; the same permutation is produced here from two order-preserving compactions (ballot +
+// popcount; across the workgroup through an LDS prefix for big nodes) and a parallel swap, so vAcc_ ends up identical.
+// divlow / divhigh are the refined child boxes' bounds on the cut dimension = max of the left / min of the right subtree's
+// coordinates, taken from the statistics of the cut when the node is split.  Round 2 (wave per node, gathers): 23 ms per
+// 256 x 50k-point build, round 3: 5.1 ms, round 4: 2.5 ms (0.2 ms at the reference's 3072 points): DESIGN.md section 4.
 #pragma once
 #include <cstring>
 #include "kd_grid.h"
@@ -186,9 +189,6 @@ __device__ __forceinline__ unsigned hoare_partition(const G &g, const ExactTree 
     }
     g.sync();  // the lists were written by other threads of the group
     // planeSplit's swap loop pairs the j-th misplaced from the left (ascending) with the j-th from the right (DESCENDING); ml == mr
-#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 4
-    ml = 0;
-#endif
 #pragma unroll 2
     for (unsigned j = tid; j < ml; j += G::kN) {
         const unsigned a = T.sa[lb + j], b = T.sb[lb + (ml - 1 - j)];
@@ -266,11 +266,7 @@ __device__ __forceinline__ int exact_process_node(const G &g, const ExactTree &T
     }
     na = g.sum(na); nb = g.sum(nb); maxa = g.max(maxa); minc = g.min(minc);
     // planeSplit (:1256-1294)
-#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 2
-    const unsigned lim1 = na;
-#else
     const unsigned lim1 = na > 0 ? hoare_partition<true>(g, T, l, r, cutfeat, cutval, (int)na) : 0u;
-#endif
     // (no element equal to the cut -- the rule on continuous coordinates, where the cut is a box midpoint: the second loop of
     // planeSplit finds everything in place)
     const unsigned lim2 = lim1 + (nb > 0 ? hoare_partition<false>(g, T, l + lim1, r, cutfeat, cutval, (int)nb) : 0u);
@@ -831,11 +827,7 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
 #ifdef AMK_EXACT_TRACE
         const unsigned long long t0 = wall_clock64();
 #endif
-#if defined(AMK_EXACT_DIAG) && AMK_EXACT_DIAG == 1
-        if (cnt <= (unsigned)kExactSubtree) { if (lane == 0) T.feat[id] = -1; }
-#else
         if (cnt <= (unsigned)kExactSubtree) exact_subtree_wave(T, id, &n_nodes_lds, &overflow, &sub[w]);
-#endif
         else if (cnt <= win_thr) exact_window_wave(T, id, &n_nodes_lds, &overflow, &sub[w], &win[w]);
         else {
             const int c = exact_process_node(gw, T, id, &n_nodes_lds, &overflow);

@@ -363,6 +363,43 @@ def test_nanoflann_tie_order_mode(torch_cuda, oracle):
     assert differ_default > 50     # the default (lowest-index) policy does differ on these clouds: the mode matters
 
 
+def test_nanoflann_tie_order_large_and_quantised(torch_cuda, oracle):
+    """The device-built reference tree at BASELINE sizes -- every path of the build (block-wide top levels, the work queue, LDS
+    windows, register-resident subtrees): 200 k continuous points, 50 k points on a 5 cm lattice (exact ties and duplicates), a
+    20 k-point line; three orders of the same cloud per batch.  Node counts and traversal results equal the oracle's."""
+    import ctypes as C
+    torch = torch_cuda
+    from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import KdBatch
+    lib = capi.load()
+    lib_o = _oracle.load_oracle(); lib_o.kdo_num_nodes.restype = C.c_int; lib_o.kdo_num_nodes.argtypes = [C.c_void_p]
+    rng = np.random.default_rng(3)
+    for n, kind in ((200000, "continuous"), (50000, "lattice"), (20000, "line")):
+        c = synth.make_cloud(n, 11)[0]
+        if kind == "lattice":
+            c = (np.round(c * 20) / 20).astype(np.float32)
+        if kind == "line":
+            c[:, 1] = 0.5; c[:, 2] = 1.0
+        cl = np.stack([c, c[::-1].copy(), c[rng.permutation(n)]])
+        S = len(cl)
+        kd = KdBatch(S, n); kd.set_tie_order(1)
+        kd.build(torch.from_numpy(cl).cuda())
+        nn = np.zeros(S, np.int32)
+        assert lib.amk__kd_exact_nodes(kd.h, nn.ctypes.data_as(C.c_void_p)) == 0
+        qs = np.concatenate([c[rng.integers(0, n, 24)].astype(np.float64), rng.uniform(-5, 25, (24, 3))])
+        r = kd.search(torch.from_numpy(np.stack([qs] * S)).cuda(), 8)
+        torch.cuda.synchronize()
+        idx, d2 = r["indices"].cpu().numpy(), r["sqdist"].cpu().numpy()
+        for s in range(S):
+            t = _oracle.kd_oracle(cl[s])
+            assert nn[s] == lib_o.kdo_num_nodes(t.h), (n, kind, s, nn[s])
+            for i, q in enumerate(qs):
+                ia, da, _ = t.search(q, 8)
+                assert np.array_equal(idx[s, i][:len(ia)], ia), (n, kind, s, i)
+                assert np.array_equal(d2[s, i][:len(ia)].view(np.int64), da.view(np.int64))
+        kd.close()
+
+
 def test_pair_build_equals_two_builds(torch_cuda, oracle):
     """amk_kd_build_pair (FrameKDMap::AddVertex's two InitializeNew calls as one launch, grid.y = tree): the obstacle and
     the edge index answer exactly like two separately built ones -- ragged counts, NaN-x points, 16-byte stride."""
