@@ -265,7 +265,9 @@ def flight_main(args):
     B = nslots * gang                                        # batches of flights = (slot, gang position) pairs
     P = args.periods if args.periods > 0 else max(2, -(-args.steps // B))
     W = min(B, 4)                                            # distinct world sets (frames of W x P x 169 MB stay resident)
-    worlds = [flight.FlightWorldsTorch(S, n, prm, 9000 + w, dev) for w in range(W)]
+    # the corridor outlasts the flights (80 m holds the default 52 periods; beyond its last cylinder a frame degenerates)
+    world_len = max(80.0, 8.0 + prm.speed * prm.dt * P + 30.0 + 10.0)
+    worlds = [flight.FlightWorldsTorch(S, n, prm, 9000 + w, dev, length=world_len) for w in range(W)]
     t_gen = time.perf_counter()
     frames = [[worlds[w].frame(t) for t in range(P)] for w in range(W)]
     torch.cuda.synchronize()
@@ -366,7 +368,7 @@ def flight_main(args):
                                    "SECONDARY to the cold-start headline (default workload)",
                        "scenes_per_gpu": S, "points": n, "horizon": N, "K": prm.K, "batches": B, "periods": P, "streams_in_flight": nslots,
                        "steps_per_launch": gang, "queue_depth_per_slot": args.queue_depth if args.queue_depth > 0 else 2,
-                       "distinct_world_sets": W, "distinct_frames_bytes": int(W * P * S * 12 * (n + ne)),
+                       "distinct_world_sets": W, "world_length_m": world_len, "distinct_frames_bytes": int(W * P * S * 12 * (n + ne)),
                        "frame_generation_s_untimed": round(t_gen, 2), "host_submit_ms_per_step": round(1e3 * t_sub / steps, 4),
                        "orchestration": "amk_pipeline TASK mode (prologue / epilogue kernels); the vehicle's kernels are queued on the "
                                         "slot's own stream behind the step: no host synchronisation inside the loop"},
