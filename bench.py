@@ -413,6 +413,9 @@ def main():
                     help="cold (the headline: fresh frame + zero warm start every step) or flight (closed loop: every step is one "
                          "control period of a batch of flights -- fresh frame, GetInitPath, warm start, command, vehicle)")
     ap.add_argument("--periods", type=int, default=0, help="flight workload: control periods per flight (0: from --steps)")
+    ap.add_argument("--inputs", default="device", choices=("device", "host"),
+                    help="host: every step's clouds, edge clouds and odometry start in pinned host memory and cross PCIe inside the "
+                         "timed region (the PCIe-inclusive rate DESIGN.md quotes; never the headline)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only (CPU, gloo): ranks rendezvous, partition the scenes, exchange a gather-shaped buffer and "
                          "rank 0 prints a JSON line without a value -- what tests/test_bench_launch.py runs without a GPU")
@@ -477,6 +480,9 @@ def main():
             self.sq = torch.from_numpy(sq).to(dev); self.ref0 = torch.from_numpy(ref0).to(dev)
             self.posx = torch.from_numpy(posx).to(dev)
             self.last_row = 0
+            self.ticket = None
+            if args.inputs == "host":   # the step's inputs as a host application holds them: pinned, copied every step
+                self.host = [t.cpu().pin_memory() for t in (self.clouds, self.edges, self.sq, self.posx, self.ref0)]
 
     # the C ABI's pipeline (include/avoid_mpc_amd.h: amk_pipeline_*): what a C++ host would call; bench.py only feeds it.
     # Steps queued per slot before submit() blocks: 1 (+1-2 % against deeper queues).  Rounds 2-3 used 8 whenever a process
@@ -504,6 +510,7 @@ def main():
         sh.gather(warm[rank].clone(), warm)   # RCCL sets a communicator's channels up at its first collective: not in the clock
         torch.cuda.synchronize()
     step_no = [0]
+    copy_stream = torch.cuda.Stream(device=dev) if args.inputs == "host" else None
     # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
     # value is then NOT the metric (the JSON line says so)
     DIAG_SKIP = os.environ.get("AMK_BENCH_SKIP", "")
@@ -520,6 +527,14 @@ def main():
         fr = slots[i if frames is None else frames]
         step_no[0] += 1
         fr.last_row = row
+        if diag_streams is None and args.inputs == "host":
+            if fr.ticket is not None:
+                pl.wait(fr.ticket)   # the launch that last read this frame set's device buffers
+            with torch.cuda.stream(copy_stream):
+                for dst, src in zip((fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0), fr.host):
+                    dst.copy_(src, non_blocking=True)
+                fr.ticket = pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row], order_after_current_stream=True)
+            return fr.ticket
         if diag_streams is None:
             return pl.submit(fr.clouds, fr.edges, fr.sq, fr.posx, fr.ref0, u_out=u_sweep[row], order_after_current_stream=False)
         st = diag_streams[i]
@@ -707,6 +722,9 @@ def main():
             "value": round(value, 1), "unit": "MPC steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
             **({"INVALID_diagnostic_run": "AMK_BENCH_SKIP=" + DIAG_SKIP} if DIAG_SKIP else {}),
+            **({"NOT_THE_HEADLINE_pcie_inclusive": f"--inputs host: {12 * (n + ne) * S + 8 * S * (10 * prm.max_iter + 1 + 10 * N)} bytes per "
+                                                   "step cross PCIe from pinned host memory inside the timed region"}
+               if args.inputs == "host" else {}),
             "scaling": "weak", "vs_baseline": None, "dtype": "f64" if args.precision == 64 else "f32", "data": "synthetic",
             "value_steady_state": round(steady, 1) if steady else None,
             "value_steady_state_steps": args.steady_steps if steady else None,
