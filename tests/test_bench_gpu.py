@@ -13,7 +13,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("extra", [["--steps", "20", "--warmup", "5"],
-                                   ["--steps", "9", "--warmup", "2", "--streams", "3", "--gang", "3", "--scenes", "64", "--steady-steps", "0"]])
+                                   ["--steps", "9", "--warmup", "2", "--streams", "3", "--gang", "3", "--scenes", "64", "--steady-steps", "0"],
+                                   # inputs in pinned host memory, copied every step (the PCIe-inclusive rate): same controls
+                                   ["--steps", "12", "--warmup", "2", "--streams", "2", "--gang", "2", "--scenes", "32", "--steady-steps", "0",
+                                    "--inputs", "host"]])
 def test_bench_line(extra):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + extra, capture_output=True, text=True,
                        timeout=900, cwd=ROOT)
@@ -27,6 +30,7 @@ def test_bench_line(extra):
     assert d["n_gpus"] == 1 and d["steps"] == int(extra[1]) and d["value"] > 0 and d["dtype"] == "f64"
     assert d["roofline"]["bound"] and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
     assert d["parity"]["fixtures"]["ok"], d["parity"]["fixtures"]
+    assert ("NOT_THE_HEADLINE_pcie_inclusive" in d) == ("host" in extra)
     chk = d["parity"]["timed_workload_vs_cpu_oracle"]
     assert chk["ok"] and chk["scenes"] == d["config"]["scenes_per_gpu"], chk
 
