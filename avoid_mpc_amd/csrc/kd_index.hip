@@ -194,9 +194,11 @@ static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, lo
 // whether `a` now asks for them (false: allocation failed or not wanted -- ensure_soa makes them on demand as before).
 static bool build_writes_soa(amk_kd *kd, BuildArgs &a, size_t so = 0) {
     if (!kd->tie_order || kd->cap <= 0) return false;
-    if (!kd->x.p) {
+    if (!kd->x.p || !kd->y.p || !kd->z.p) {   // (a failed allocation leaves what it got: ensure_soa retries the rest)
         const size_t tot = (size_t)kd->n_scenes * kd->cap;
-        if (kd->x.alloc(tot) != hipSuccess || kd->y.alloc(tot) != hipSuccess || kd->z.alloc(tot) != hipSuccess) return false;
+        if ((!kd->x.p && kd->x.alloc(tot) != hipSuccess) || (!kd->y.p && kd->y.alloc(tot) != hipSuccess) ||
+            (!kd->z.p && kd->z.alloc(tot) != hipSuccess))
+            return false;
     }
     a.soa_x = kd->x.p + so * kd->cap; a.soa_y = kd->y.p + so * kd->cap; a.soa_z = kd->z.p + so * kd->cap;
     return true;
@@ -222,11 +224,11 @@ __global__ __launch_bounds__(256) void kd_records_to_soa_kernel(const float4 *__
 // makes the SoA planes of `kd` valid on `stream` (no-op when they already are)
 static int ensure_soa(amk_kd *kd, hipStream_t stream) {
     if (kd->soa_valid) return AMK_OK;
-    if (!kd->x.p) {
+    if (!kd->x.p || !kd->y.p || !kd->z.p) {
         const size_t tot = (size_t)kd->n_scenes * kd->cap;
-        AMK_HIP(kd->x.alloc(tot));
-        AMK_HIP(kd->y.alloc(tot));
-        AMK_HIP(kd->z.alloc(tot));
+        if (!kd->x.p) AMK_HIP(kd->x.alloc(tot));
+        if (!kd->y.p) AMK_HIP(kd->y.alloc(tot));
+        if (!kd->z.p) AMK_HIP(kd->z.alloc(tot));
     }
     if (kd->cap > 0)
         hipLaunchKernelGGL(kd_records_to_soa_kernel, dim3((kd->cap + 255) / 256, kd->n_scenes), dim3(256), 0, stream,
