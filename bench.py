@@ -261,9 +261,11 @@ def flight_main(args):
     torch.cuda.set_device(0)
     prm = synth.MpcParams(T=args.T, K=args.K)
     S, n, ne, N = args.scenes, args.points, args.points // 10, prm.N
-    nslots, gang = max(1, args.streams), max(1, args.gang)
+    nslots, gang = max(1, args.streams), args.gang if args.gang > 0 else 8
     B = nslots * gang                                        # batches of flights = (slot, gang position) pairs
-    P = args.periods if args.periods > 0 else max(2, -(-args.steps // B))
+    # periods per flight: 52 unless asked otherwise (17 m at 10 m/s: the corridor's first 8 m are free of obstacles, shorter flights
+    # would measure mostly those); an explicit --steps gives ceil(steps / batches)
+    P = args.periods if args.periods > 0 else (52 if args.steps == 2048 else max(2, -(-args.steps // B)))
     W = min(B, 4)                                            # distinct world sets (frames of W x P x 169 MB stay resident)
     # the corridor outlasts the flights (80 m holds the default 52 periods; beyond its last cylinder a frame degenerates)
     world_len = max(80.0, 8.0 + prm.speed * prm.dt * P + 30.0 + 10.0)
@@ -394,10 +396,12 @@ def main():
     ap.add_argument("--K", type=int, default=8)
     ap.add_argument("--streams", type=int, default=10,
                     help="pipeline slots = independent launches in flight (each on its own HIP stream with its own handles)")
-    ap.add_argument("--gang", type=int, default=4,
+    ap.add_argument("--gang", type=int, default=0,
                     help="steps (frames) that share one set of launches on a slot (amk_pipeline_config.gang): streams x gang steps "
-                         "are in flight or staged.  10 x 4 against the 20 x 1 of rounds 2-3a, same box: 519 k vs 466 k scene-steps/s "
-                         "steady, 410-422 k vs 378 k over the driver's 20 steps")
+                         "are in flight or staged; 0 = 4, flight workload 8.  10 x 4 against the 20 x 1 of rounds 2-3a, same box: 519 k "
+                         "vs 466 k scene-steps/s steady, 410-422 k vs 378 k over the driver's 20 steps; the warm-started flights, whose "
+                         "launches are shorter and end with longer tails, want more frames in flight: 10 x 8 1.24 M against 1.12 M (10 x 4), "
+                         "same box, 52 periods")
     ap.add_argument("--queue-depth", type=int, default=0, help="steps queued per pipeline slot (0: 1; flight workload: 2)")
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
@@ -460,7 +464,7 @@ def main():
     prm = synth.MpcParams(T=args.T, K=args.K)
     S, n, ne, N = args.scenes, args.points, args.points // 10, prm.N
     nslots = max(1, args.streams)
-    gang = max(1, args.gang)
+    gang = args.gang if args.gang > 0 else 4
     nframes = nslots * gang   # distinct frame sets: every step in flight (or staged) owns its inputs
 
     class Frames:
