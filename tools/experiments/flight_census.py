@@ -1,6 +1,6 @@
 """Closed-loop parity census beyond tests/test_flight_gpu.py: more flights, longer, and all three BASELINE sizes.  GPU
 (amk_pipeline, keep_warm_start) against the CPU oracle on the same worlds and frames (tests/_flight.py); writes a JSON report.
-usage: python tools/experiments/flight_census.py [out.json]"""
+usage: python tools/experiments/flight_census.py [out.json [cfg:flights:periods:batch ...]]"""
 import json
 import os
 import sys
@@ -13,7 +13,10 @@ if __name__ == "__main__":
     import numpy as np
     from tests import _flight
     out = {}
-    for cfg, F, P, batch in (("C2", 256, 150, 64), ("C5", 16, 60, 16), ("C1", 128, 150, 128)):
+    runs = [("C2", 256, 150, 64), ("C5", 16, 60, 16), ("C1", 128, 150, 128)]
+    if len(sys.argv) > 2:   # e.g. C2:1024:150:64
+        runs = [(a.split(":")[0],) + tuple(int(v) for v in a.split(":")[1:]) for a in sys.argv[2:]]
+    for cfg, F, P, batch in runs:
         seeds = list(range(20000, 20000 + F))
         kw = dict(cyl_per_m=1.5, length=100.0)
         t0 = time.time()
