@@ -755,7 +755,8 @@ __device__ __forceinline__ void exact_build_top(const ExactTree T, int n) {
 
 constexpr int kExactMaxIdleSpins = 200000;
 constexpr int kExactQueue = 2048;   // ring of open nodes (only nodes of more than kExactWindow points put their children here: the frontier of a 200 k-point tree holds < 1 k)
-__device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
+// qcap: capacity of the ring actually used (a power of two <= kExactQueue; smaller only in tests: amk__exact_set_queue_cap)
+__device__ __forceinline__ void exact_build_rest(const ExactTree T, int n, int qcap = kExactQueue) {
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     __shared__ int n_nodes_lds, overflow, q_head, q_tail, pending;
     __shared__ int queue[kExactQueue];
@@ -782,7 +783,7 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
     for (int id = tid; id < nn0; id += kExactThreads)
         if (T.feat[id] == kExactTodo) {
             const int pos = atomicAdd(&q_tail, 1);
-            if (pos < kExactQueue) { queue[pos] = id; atomicAdd(&pending, 1); }
+            if (pos < qcap) { queue[pos] = id; atomicAdd(&pending, 1); }
             else overflow = 1;
         }
     __syncthreads();
@@ -807,9 +808,11 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
                 const int hd = __atomic_load_n(&q_head, __ATOMIC_RELAXED);
                 if (hd >= __atomic_load_n(&q_tail, __ATOMIC_RELAXED)) break;
                 if (atomicCAS(&q_head, hd, hd + 1) == hd) {
-                    const int slot = hd & (kExactQueue - 1);
-                    do { id = __atomic_load_n(&queue[slot], __ATOMIC_RELAXED); } while (id < 0);   // (reserved, being written)
-                    __atomic_store_n(&queue[slot], -1, __ATOMIC_RELAXED);
+                    const int slot = hd & (qcap - 1);
+                    // (reserved, being written: the producer advanced q_tail before it stored the id.  It stores it unless the
+                    // scene was given up meanwhile -- then nobody will, and this wave leaves with the others)
+                    do { id = __atomic_load_n(&queue[slot], __ATOMIC_RELAXED); } while (id < 0 && !__atomic_load_n(&overflow, __ATOMIC_RELAXED));
+                    if (id >= 0) __atomic_store_n(&queue[slot], -1, __ATOMIC_RELAXED);
                     break;
                 }
             }
@@ -833,16 +836,28 @@ __device__ __forceinline__ void exact_build_rest(const ExactTree T, int n) {
             const int c = exact_process_node(gw, T, id, &n_nodes_lds, &overflow);
             __threadfence_block();   // the children's range / box and the permuted window are in memory before anyone can pop them
             if (lane == 0 && c >= 0) {   // split: the two children are open nodes
-                const int pos = atomicAdd(&q_tail, 2);
-                if (pos + 2 - __atomic_load_n(&q_head, __ATOMIC_RELAXED) <= kExactQueue) {
+                // Reserve two slots -- capacity is checked BEFORE q_tail moves (advancing first and then giving up left
+                // two positions inside [q_head, q_tail) that nobody would ever write, and the consumer that claimed one spun on it
+                // for good; reachable beyond ~430 k points per scene).  q_head only grows, so a stale read errs on the safe side.
+                int pos = __atomic_load_n(&q_tail, __ATOMIC_RELAXED);
+                bool room;
+                for (;;) {
+                    room = pos + 2 - __atomic_load_n(&q_head, __ATOMIC_RELAXED) <= qcap;
+                    if (!room) break;
+                    const int seen = atomicCAS(&q_tail, pos, pos + 2);
+                    if (seen == pos) break;
+                    pos = seen;
+                }
+                if (room) {
                     atomicAdd(&pending, 2);
                     for (int e = 0; e < 2; ++e) {
-                        int *slot = &queue[(pos + e) & (kExactQueue - 1)];
-                        while (__atomic_load_n(slot, __ATOMIC_RELAXED) != -1) {}   // (a lapped slot whose consumer has claimed it but not read it yet)
+                        int *slot = &queue[(pos + e) & (qcap - 1)];
+                        // (a lapped slot whose consumer has claimed it but not read it yet)
+                        while (__atomic_load_n(slot, __ATOMIC_RELAXED) != -1 && !__atomic_load_n(&overflow, __ATOMIC_RELAXED)) {}
                         __atomic_store_n(slot, c + e, __ATOMIC_RELAXED);
                     }
                 } else {
-                    __atomic_store_n(&overflow, 1, __ATOMIC_RELAXED);
+                    __atomic_store_n(&overflow, 1, __ATOMIC_RELAXED);   // the scene keeps the bucketed index's answer
                 }
             }
         }

@@ -372,9 +372,18 @@ __global__ __launch_bounds__(amk::kExactTopThreads) void kd_exact_build_top_kern
     const int s = blockIdx.x;
     amk::exact_build_top(ep.scene(s), sizes[s]);
 }
-__global__ __launch_bounds__(amk::kExactThreads) void kd_exact_build_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes) {
+__global__ __launch_bounds__(amk::kExactThreads) void kd_exact_build_kernel(amk::ExactPtrs ep, const int *__restrict__ sizes, int qcap) {
     const int s = blockIdx.x;
-    amk::exact_build_rest(ep.scene(s), sizes[s]);
+    amk::exact_build_rest(ep.scene(s), sizes[s], qcap);
+}
+// tests only (tests/test_kd_gpu.py): a smaller ring of open nodes, so that the give-up path of exact_build_rest is reachable
+// with a cloud that fits a test (0 = the compiled capacity)
+static int g_exact_queue_cap = amk::kExactQueue;
+extern "C" int amk__exact_set_queue_cap(int cap) {
+    if (cap == 0) cap = amk::kExactQueue;
+    if (cap < 2 || cap > amk::kExactQueue || (cap & (cap - 1))) return AMK_ERR_INVALID_ARG;
+    g_exact_queue_cap = cap;
+    return AMK_OK;
 }
 
 // one WAVEFRONT per (scene, query): nanoflann's own traversal (kd_exact.h: exact_knn_wave).  Overwrites the outputs of the
@@ -431,7 +440,7 @@ static int exact_build(amk_kd *kd, hipStream_t stream) {
     if (st != AMK_OK) return st;
     hipLaunchKernelGGL(kd_exact_build_top_kernel, dim3(kd->n_scenes), dim3(amk::kExactTopThreads), 0, stream, exact_ptrs(kd), kd->size.p);
     hipLaunchKernelGGL(kd_exact_build_kernel, dim3(kd->n_scenes), dim3(amk::kExactThreads), 0, stream, exact_ptrs(kd),
-                       kd->size.p);
+                       kd->size.p, g_exact_queue_cap);
     AMK_HIP(hipGetLastError());
     kd->ex_valid = 1;
     return AMK_OK;

@@ -44,6 +44,25 @@ PROFILE_TAG = "r04"
 N_CU, N_SIMD, CLOCK_GHZ = 256, 4, 2.4   # MI355X: /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_hbm_peak(torch, lib, gib=1.0, reps=10):
+    """SURVEY.md 8(d) / BASELINE.md 3: the ACHIEVABLE HBM rate beside the vendor peak -- a float4 device copy of `gib` GiB
+    (amk__hbm_copy_probe, csrc/probe.hip; far beyond the 256 MiB Infinity Cache), bytes read + bytes written over the time of
+    the copy.  Runs before the pipeline's buffers exist; returns GB/s."""
+    import ctypes as C
+    nb = int(gib * (1 << 30)) // 16 * 16
+    src = torch.empty(nb, dtype=torch.uint8, device="cuda"); dst = torch.empty_like(src)
+    src.fill_(1)
+    torch.cuda.synchronize()
+    ms = C.c_double()
+    lib.amk__hbm_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+    lib.amk__hbm_copy_probe.restype = C.c_int
+    rc = lib.amk__hbm_copy_probe(src.data_ptr(), dst.data_ptr(), nb, reps, None, C.byref(ms))
+    assert rc == 0, rc
+    del src, dst
+    torch.cuda.empty_cache()
+    return 2.0 * nb / (ms.value * 1e-3) / 1e9
+
+
 def alg_bytes_per_step(n, ne, N, K):
     """every input read once, every output written once, per scene-step."""
     nx = 10 + 14 * N
@@ -281,6 +300,8 @@ def flight_main(args):
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
         pl.mpc(i).set_precision(args.precision)
+        if args.ipm_max_iter is not None:
+            pl.mpc(i).set_solver_options(1e-4, args.ipm_max_iter)
     x0 = np.zeros((B, S, 10)); ref0 = np.zeros((B, S, N, 10))
     for b in range(B):
         for s_ in range(S):

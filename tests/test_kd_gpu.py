@@ -459,3 +459,47 @@ def test_exact_tree_is_never_used_stale(torch_cuda, oracle):
     for i in range(3):
         ia, da, _ = t2.search(q[0, i], 4)
         assert np.array_equal(r["indices"][0, i].cpu().numpy(), ia) and np.array_equal(r["sqdist"][0, i].cpu().numpy(), da)
+
+
+def test_exact_build_gives_up_cleanly_when_the_ring_of_open_nodes_is_full(torch_cuda, oracle):
+    """the ring of open nodes of exact_build_rest used to advance q_tail BEFORE it checked the capacity; on overflow two
+    positions stayed unwritten and the consumer that claimed one spun for ever (reachable beyond ~430 k points per scene).  With
+    the ring shrunk to 2 / 4 / 16 entries (amk__exact_set_queue_cap, tests only) a 50 k-point build must END: every scene either
+    has the reference's tree (same node count, nanoflann's order) or reports it unavailable (-1) and is answered by the bucketed
+    index (lowest-index order, same distances)."""
+    import ctypes as C
+    torch = torch_cuda
+    from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import KdBatch
+    lib = capi.load()
+    lib_o = _oracle.load_oracle(); lib_o.kdo_num_nodes.restype = C.c_int; lib_o.kdo_num_nodes.argtypes = [C.c_void_p]
+    n = 50000
+    cl = np.stack([synth.make_cloud(n, 31 + s)[0] for s in range(4)])
+    rng = np.random.default_rng(5)
+    qs = np.concatenate([cl[0][rng.integers(0, n, 8)].astype(np.float64), rng.uniform(-5, 25, (8, 3))])
+    assert lib.amk__exact_set_queue_cap(3) == capi.AMK_ERR_INVALID_ARG and lib.amk__exact_set_queue_cap(4096) == capi.AMK_ERR_INVALID_ARG
+    gave_up = 0
+    try:
+        for cap in (2, 4, 16, 0):
+            assert lib.amk__exact_set_queue_cap(cap) == 0
+            kd = KdBatch(len(cl), n); kd.set_tie_order(1)
+            kd.build(torch.from_numpy(cl).cuda())
+            nn = np.zeros(len(cl), np.int32)
+            assert lib.amk__kd_exact_nodes(kd.h, nn.ctypes.data_as(C.c_void_p)) == 0     # synchronises: the build ended
+            r = kd.search(torch.from_numpy(np.stack([qs] * len(cl))).cuda(), 8)
+            torch.cuda.synchronize()
+            idx, d2 = r["indices"].cpu().numpy(), r["sqdist"].cpu().numpy()
+            for s in range(len(cl)):
+                t = _oracle.kd_oracle(cl[s])
+                assert nn[s] == -1 or nn[s] == lib_o.kdo_num_nodes(t.h), (cap, s, nn[s])
+                gave_up += int(nn[s] == -1)
+                for i, q in enumerate(qs):
+                    ia, da, _ = t.search(q, 8) if nn[s] >= 0 else (*t.bruteforce(q, 8), None)
+                    assert np.array_equal(d2[s, i].view(np.int64), da.view(np.int64)), (cap, s, i)
+                    assert np.array_equal(idx[s, i], ia), (cap, s, i)
+            if cap == 0:
+                assert (nn >= 0).all()                                                    # the shipped capacity holds a 50 k-point tree
+            kd.close()
+    finally:
+        lib.amk__exact_set_queue_cap(0)
+    assert gave_up > 0, "a 2-entry ring must overflow on 50 k points: the give-up path was not exercised"
