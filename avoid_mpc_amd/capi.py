@@ -167,6 +167,7 @@ def load():
         "amk_pipeline_create": (i, [C.POINTER(PipelineConfig), C.POINTER(vp)]),
         "amk_pipeline_destroy": (i, [vp]),
         "amk_pipeline_slots": (i, [vp]),
+        "amk_mpc_set_solve_budget": (i, [vp, i, i]),
         "amk_pipeline_gang": (i, [vp]),
         "amk_pipeline_mpc": (vp, [vp, i]),
         "amk_pipeline_kd": (vp, [vp, i, i]),

@@ -158,6 +158,16 @@ struct LaneRole {
     int pad;
 };
 
+// Per-launch scheduling of the solve inside the control step (mpc_solve.hip: solve_kernel_body; step.hip: amk_step_batch).
+// budget > 0: interior-point iterations a scene may make in THIS launch before it pauses (state to rec, done_rw[s] = 2) and is
+// picked up by a later launch; max_passes: the step's mpc_max_iter (a scene that has made them all gets done_rw[s] = 1).
+// All zero / null: the plain solve (amk_mpc_solve, amk_step_batch_frames).
+struct SolveSched {
+    int budget, max_passes;
+    double *rec;     // [S][8 N + 8]: zl, zu, {mu, delta_last, it, n_reg, ls_fail}
+    int *done_rw;
+};
+
 struct SceneIO {
     const double *ref;   // [N][10] reference states            (P[10 : 10+10N])
     const double *obs;   // [N][K][3] obstacle points           (P[10+10N : ...])

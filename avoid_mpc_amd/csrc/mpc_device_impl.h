@@ -739,10 +739,21 @@ __device__ __forceinline__ real next_mu(real mu, real mu_min, real kappa_mu) {
 // memory (warm start in, solution out; may alias).  info[4] as in the C ABI.  ybuf: [N][K][YB] doubles of scratch.
 // Statement by statement the algorithm of DESIGN.md section 5, as the CPU restatement of the tests (one difference in bookkeeping only: an accepted first
 // line-search trial is evaluated WITH derivatives, so the next iteration finds q, r, H6 of its iterate in LDS).
+//
+// Resumable (round 5): with budget > 0 the call makes at most `budget` interior-point iterations and, if the solve has not
+// ended by then, PAUSES: the iterate goes to w_out as usual (X and U: X is carried by the updates X += a dX, not re-rolled, so it is
+// state), the bound multipliers and five scalars (mu, delta_last, it, n_reg, ls_fail) to `rec` ([8 N + 8] doubles), the term
+// multipliers are in ybuf already; sm[L.red + 2] = 1 tells the caller.  A later call with resume = true picks the solve up at
+// the top of the iteration it stopped before: the derivatives, the reduced gradient and the optimality errors of the iterate
+// are recomputed by the same eval_iterate(false, ...) the uninterrupted solve runs whenever its line search did not hand them
+// over, and find the same bits (the speculative evaluation of an accepted first trial ran the same code on the same values:
+// Xt = X + a dX is the expression of the update).  A paused-and-resumed solve therefore returns the bits of the uninterrupted
+// one (tests/test_mpc_resume_gpu.py); what it costs is one derivative evaluation per pause.
 __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
                             const double *x_init, const double *target, const SceneIO &io, const double *w0,
                             double *w_out, int *info, const double *plan_coef, const int *plan_meta, double *ybuf,
-                            double *gains, double *trace = nullptr) {
+                            double *gains, double *trace = nullptr, bool resume = false, int budget = 0,
+                            double *rec = nullptr) {
     const int lane = threadIdx.x;
     const real o_tol = (real)opt.tol, o_mu_init = (real)opt.mu_init, o_bound_push = (real)opt.bound_push, o_bound_frac = (real)opt.bound_frac, o_kappa_mu = (real)opt.kappa_mu, o_tau_min = (real)opt.tau_min, o_eta_phi = (real)opt.eta_phi, o_s_max = (real)opt.s_max, o_kappa_sigma = (real)opt.kappa_sigma;
     const real o_kappa_eps = (real)opt.kappa_eps, o_maj = (real)opt.maj;
@@ -770,6 +781,15 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         }
     }
     const int nvar = UD * N;
+    if (resume) {  // the paused iterate, its bound multipliers (the term multipliers never left ybuf)
+        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] = (real)w0[14 * (e / SD) + (e % SD)];
+        for (int e = lane; e < nvar; e += 64) {
+            sm[L.U + e] = (real)w0[14 * (e / UD) + 10 + (e % UD)];
+            sm[L.zl + e] = (real)rec[e];
+            sm[L.zu + e] = (real)rec[nvar + e];
+        }
+        __syncthreads();
+    } else {
     // warm start pushed into the interior
     for (int e = lane; e < nvar; e += 64) {
         const int k = e / UD, i = e % UD;
@@ -782,7 +802,8 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     for (int e = lane; e < (N - 1) * K; e += 64)  // no collision term has multipliers yet
         *reinterpret_cast<double2 *>(ybuf + (size_t)e * YB) = make_double2(-1.0, -1.0);
     __syncthreads();
-    {  // rollout X_{k+1} = A X_k + B U_k + c
+    }
+    if (!resume) {  // rollout X_{k+1} = A X_k + B U_k + c
         const real *c = prm + PRM_C;
         const int row = lane < SD ? lane : 0;
         real arow[SD], brow[UD];  // row `lane` of A and B
@@ -803,7 +824,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         }
     }
     const real mu_min = o_tol * (real)opt.mu_min_fac;
-    real mu = o_mu_init, phi0 = RL(0.0);
+    real mu = resume ? (real)rec[2 * nvar + 0] : o_mu_init, phi0 = RL(0.0);
     real err[2] = {RL(0.0), RL(0.0)}, acc[2] = {RL(0.0), RL(0.0)};
     // derivatives, reduced gradient and optimality errors of the iterate under mu (oracle eval_iterate)
     auto eval_iterate = [&](bool derivs_in_lds, real J_known, long long *tclk) -> real {
@@ -823,27 +844,32 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     // update below would leave it (a warm start from a previous solution begins several levels down)
 #pragma unroll 1
     for (;;) {
-        for (int e = lane; e < nvar; e += 64) {
-            const int i = e % UD;
-            const real u = sm[L.U + e];
-            sm[L.zl + e] = mu / (u - prm[PRM_LB + i]);
-            sm[L.zu + e] = mu / (prm[PRM_UB + i] - u);
+        if (!resume) {
+            for (int e = lane; e < nvar; e += 64) {
+                const int i = e % UD;
+                const real u = sm[L.U + e];
+                sm[L.zl + e] = mu / (u - prm[PRM_LB + i]);
+                sm[L.zu + e] = mu / (prm[PRM_UB + i] - u);
+            }
+            __syncthreads();
         }
-        __syncthreads();
         phi0 = eval_iterate(false, RL(0.0), nullptr);
-        if (!(err[0] <= o_kappa_eps * mu) || mu <= mu_min) break;
+        if (resume || !(err[0] <= o_kappa_eps * mu) || mu <= mu_min) break;   // (a resumed solve only needs the evaluation)
         mu = next_mu(mu, mu_min, o_kappa_mu);
     }
-    real delta_last = RL(0.0);
-    int status = 1, n_reg = 0, ls_fail = 0, it = 0;
+    real delta_last = resume ? (real)rec[2 * nvar + 1] : RL(0.0);
+    const int it_begin = resume ? (int)rec[2 * nvar + 2] : 0;
+    int status = 1, n_reg = resume ? (int)rec[2 * nvar + 3] : 0, ls_fail = resume ? (int)rec[2 * nvar + 4] : 0, it = 0;
+    bool paused = false;
 #pragma unroll 1
-    for (it = 0; it < opt.max_iter; ++it) {
+    for (it = it_begin; it < opt.max_iter; ++it) {
         const long long t0 = AMK_CLK();
         long long tclk[3] = {0, 0, 0};
         if (kTrace && trace && lane == 0) {
             trace[16 * it + 0] = phi0; trace[16 * it + 1] = err[1]; trace[16 * it + 2] = mu; trace[16 * it + 3] = err[0];
         }
         if (mu <= mu_min && err[0] <= o_tol) { status = 0; break; }  // the last barrier problem is solved to tol
+        if (budget > 0 && it - it_begin >= budget) { paused = true; break; }  // this launch's share is used up: continue later
         if (it > 0 && err[0] <= o_kappa_eps * mu && mu > mu_min) {   // barrier update (one level per iteration)
             mu = next_mu(mu, mu_min, o_kappa_mu);
             __syncthreads();
@@ -959,9 +985,20 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     __syncthreads();
     for (int e = lane; e < (N + 1) * SD; e += 64) w_out[14 * (e / SD) + (e % SD)] = sm[L.X + e];
     for (int e = lane; e < nvar; e += 64) w_out[14 * (e / UD) + 10 + (e % UD)] = sm[L.U + e];
+    if (paused) {
+        for (int e = lane; e < nvar; e += 64) {
+            rec[e] = (double)sm[L.zl + e];
+            rec[nvar + e] = (double)sm[L.zu + e];
+        }
+        if (lane == 0) {
+            rec[2 * nvar + 0] = (double)mu; rec[2 * nvar + 1] = (double)delta_last; rec[2 * nvar + 2] = (double)it;
+            rec[2 * nvar + 3] = (double)n_reg; rec[2 * nvar + 4] = (double)ls_fail;
+        }
+    }
     if (lane == 0) {  // kept for the control-step bookkeeping of the calling kernel
         sm[L.red + 0] = (real)status;
         sm[L.red + 1] = (real)it;
+        sm[L.red + 2] = paused ? RL(1.0) : RL(0.0);
     }
     if (info && lane == 0) {
         info[0] = status;
@@ -973,6 +1010,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
 
 __device__ __forceinline__ int sm_status(const real *sm, const LdsMap &L) { return (int)sm[L.red + 0]; }
 __device__ __forceinline__ int sm_iters(const real *sm, const LdsMap &L) { return (int)sm[L.red + 1]; }
+__device__ __forceinline__ bool sm_paused(const real *sm, const LdsMap &L) { return sm[L.red + 2] != RL(0.0); }
 
 
 #undef RL

@@ -34,7 +34,10 @@ struct amk_mpc {
     amk::DevBuf<float> edge_pt;     // [S][3]       nearest edge point of reference point 0
     amk::DevBuf<double> edge_d2;    // [S]
     amk::DevBuf<double> ref_states; // [S][nref]    vecRefStates handed to Solve
-    amk::DevBuf<int> done;          // [S]          scene left the re-plan loop (:333-335)
+    amk::DevBuf<int> done;          // [S]          1: scene left the re-plan loop (:333-335); 2: its solve is paused (iteration budget)
+    amk::DevBuf<double> resume_rec; // [S][8 N + 8] what a paused solve needs beside w0 and ybuf (mpc_device.h: SolveSched)
+    int solve_budget = 0;           // amk_mpc_set_solve_budget: iterations per launch in the first budget_rounds rounds of a step (0: off)
+    int budget_rounds = 0;
     // per-frame raw query results of amk_step_batch_frames (allocated by its first call)
     int mf_frames = 0;
     amk::DevBuf<float> mf_knn_pts, mf_edge_pt;    // [F][S][N][K][3], [F][S][3]
@@ -49,6 +52,7 @@ struct amk_mpc {
 namespace amk {
 // Launches the solve for every scene of `m` (skipping scenes with d_done[s] != 0 when given).
 // d_ref_path / d_step_flags: control-step mode (refill mRefPath, count solves / iterations).
+// budget / max_passes (control step only, amk_step_batch): see mpc_device.h SolveSched; both 0 = the plain solve.
 int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
-                 double *d_ref_path, int *d_step_flags, hipStream_t stream);
+                 double *d_ref_path, int *d_step_flags, hipStream_t stream, int budget = 0, int max_passes = 0);
 }  // namespace amk

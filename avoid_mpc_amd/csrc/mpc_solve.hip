@@ -249,12 +249,16 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
                                                   const int *__restrict__ done, double *__restrict__ ref_path,
                                                   int *__restrict__ step_flags, const double *__restrict__ plan_coef,
                                                   const int *__restrict__ plan_meta, double *__restrict__ ybuf,
-                                                  double *__restrict__ gains) {
+                                                  double *__restrict__ gains, const SolveSched sched) {
     using namespace amk32;  // solve_scene / sm_status / sm_iters overload on the scratchpad type
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     R *sm = reinterpret_cast<R *>(sm_raw);
     const int s = blockIdx.x;
-    if (done && done[s]) return;  // control step: this scene left the re-plan loop already
+    // control step: done[s] = 1: this scene left the re-plan loop already; 2: its solve was paused by an earlier launch's
+    // iteration budget (it skipped this round's queries and packing: P still holds the problem it is solving)
+    const int dstate = sched.done_rw ? sched.done_rw[s] : (done ? done[s] : 0);
+    if (dstate == 1) return;
+    const bool resume = dstate == 2;
     const int N = NT > 0 ? NT : Nrt;
     const LdsMap L(N);
     const double *P = ref_states + (size_t)s * nref;
@@ -264,9 +268,14 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     const double *target = P + SD + SD * N + 3 * K * N;
     double *w = w0 + (size_t)s * nx;
     solve_scene(sm, L, N, K, prm, opt, P, target, io, w, w, info ? info + 4 * s : nullptr, plan_coef, plan_meta,
-                ybuf + (size_t)s * N * (K > 0 ? K : 1) * kTermRecord, gains + (size_t)s * N * GAIN_STAGE, s == 0 ? trace : nullptr);
+                ybuf + (size_t)s * N * (K > 0 ? K : 1) * kTermRecord, gains + (size_t)s * N * GAIN_STAGE, s == 0 ? trace : nullptr,
+                resume, sched.budget, sched.rec ? sched.rec + (size_t)s * (8 * N + 8) : nullptr);
     __syncthreads();
     const int lane = threadIdx.x;
+    if (sm_paused(sm, L)) {  // out of budget: the scene keeps its place in the re-plan loop and continues in a later launch
+        if (lane == 0) sched.done_rw[s] = 2;
+        return;
+    }
     if (lane < UD) u_out[4 * s + lane] = sm[L.U + lane];  // sol[10..13]  HighLvlMpc.cpp:124-128
     if (x0array)                                           // rows [X_k,U_k], k < N  :130-136
         for (int e = lane; e < 14 * N; e += 64) {
@@ -276,9 +285,12 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     if (ref_path)  // mRefPath[i] = x0Array[i][0:10], AvoidanceStateMachine.cpp:338-342
         for (int e = lane; e < SD * N; e += 64) ref_path[(size_t)s * SD * N + e] = sm[L.X + e];
     if (step_flags && lane == 0) {
-        step_flags[4 * s + 1] += 1;
+        const int passes = step_flags[4 * s + 1] + 1;
+        step_flags[4 * s + 1] = passes;
         step_flags[4 * s + 2] = max(step_flags[4 * s + 2], sm_status(sm, L));  // worst status over the step's solves
         step_flags[4 * s + 3] += sm_iters(sm, L);
+        // per-scene scheduling (amk_step_batch with an iteration budget): the scene is free for its next pass, or has made them all
+        if (sched.done_rw) sched.done_rw[s] = passes >= sched.max_passes ? 1 : 0;
     }
 }
 
@@ -287,8 +299,8 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
         const double *__restrict__ ref_states, double *__restrict__ w0, double *__restrict__ u_out,                      \
         double *__restrict__ x0array, int *__restrict__ info, double *trace, const int *__restrict__ done,               \
         double *__restrict__ ref_path, int *__restrict__ step_flags, const double *__restrict__ plan_coef,               \
-        const int *__restrict__ plan_meta, double *__restrict__ ybuf, double *__restrict__ gains
-#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta, ybuf, gains
+        const int *__restrict__ plan_meta, double *__restrict__ ybuf, double *__restrict__ gains, const SolveSched sched
+#define AMK_SOLVE_PASS Nrt, K, nref, nx, prm, opt, ref_states, w0, u_out, x0array, info, trace, done, ref_path, step_flags, plan_coef, plan_meta, ybuf, gains, sched
 
 template <int NT>
 __global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel(AMK_SOLVE_ARGS) {
@@ -301,12 +313,18 @@ __global__ __launch_bounds__(64, AMK_SOLVE_WAVES) void mpc_solve_kernel_f32(AMK_
 
 namespace amk {
 int launch_solve(amk_mpc *m, const double *d_ref_states, double *d_u, double *d_x0array, int *d_info, const int *d_done,
-                 double *d_ref_path, int *d_step_flags, hipStream_t stream) {
+                 double *d_ref_path, int *d_step_flags, hipStream_t stream, int budget, int max_passes) {
+    SolveSched sched{0, 0, nullptr, nullptr};
+    if (max_passes > 0) {   // per-scene scheduling of amk_step_batch: done[] is read AND written (0 free / 1 left the loop / 2 paused)
+        if (!d_done || !d_step_flags) return AMK_ERR_INVALID_ARG;
+        if (!m->resume_rec.p) AMK_HIP(m->resume_rec.alloc((size_t)m->S * (8 * m->N + 8)));
+        sched = SolveSched{budget > 0 ? budget : 0, max_passes, m->resume_rec.p, const_cast<int *>(d_done)};
+    }
     TimedLaunch tl(KC_SOLVE, stream);
 #define AMK_LAUNCH_SOLVE(KERNEL, NT, LDS)                                                                            \
     hipLaunchKernelGGL(KERNEL<NT>, dim3(m->launch_scenes()), dim3(64), LDS, stream, m->N, m->K, m->nref, m->nx, m->prm.p, m->opt,      \
                        d_ref_states, m->w0.p, d_u, d_x0array, d_info, g_trace, d_done, d_ref_path, d_step_flags,         \
-                       m->plan_coef.p, m->plan_meta.p, m->ybuf.p, m->gains.p)
+                       m->plan_coef.p, m->plan_meta.p, m->ybuf.p, m->gains.p, sched)
     if (m->precision == 32) {  // fp32 arithmetic, half the scratchpad
         const size_t lds = m->lds_bytes / 2;
         switch (m->N) {
@@ -455,6 +473,13 @@ int amk_mpc_set_solver_options(amk_mpc *m, double tol, int max_iter) {
     if (!m || !(tol > 0) || max_iter < 0) return AMK_ERR_INVALID_ARG;
     m->opt.tol = tol;
     m->opt.max_iter = max_iter;
+    return AMK_OK;
+}
+
+int amk_mpc_set_solve_budget(amk_mpc *m, int budget, int budget_rounds) {
+    if (!m || budget < 0 || budget_rounds < 0 || budget_rounds > AMK_MAX_BUDGET_ROUNDS) return AMK_ERR_INVALID_ARG;
+    m->solve_budget = budget;
+    m->budget_rounds = budget_rounds;
     return AMK_OK;
 }
 

@@ -8,11 +8,12 @@
 
 namespace {
 constexpr int kCopyThreads = 256, kCopyUnroll = 8;
-__global__ __launch_bounds__(kCopyThreads) void hbm_copy_kernel(const float4 *__restrict__ src, float4 *__restrict__ dst, size_t n16) {
+typedef float v4f __attribute__((ext_vector_type(4)));   // (the non-temporal builtins take native vectors, not HIP's float4 struct)
+__global__ __launch_bounds__(kCopyThreads) void hbm_copy_kernel(const v4f *__restrict__ src, v4f *__restrict__ dst, size_t n16) {
     const size_t stride = (size_t)gridDim.x * kCopyThreads;
     size_t i = (size_t)blockIdx.x * kCopyThreads + threadIdx.x;
     for (; i + (kCopyUnroll - 1) * stride < n16; i += kCopyUnroll * stride) {
-        float4 v[kCopyUnroll];
+        v4f v[kCopyUnroll];
 #pragma unroll
         for (int u = 0; u < kCopyUnroll; ++u) v[u] = __builtin_nontemporal_load(src + i + u * stride);
 #pragma unroll
@@ -35,10 +36,10 @@ extern "C" int amk__hbm_copy_probe(const void *d_src, void *d_dst, size_t n_byte
     hipEvent_t e0, e1;
     AMK_HIP(hipEventCreate(&e0));
     AMK_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(kCopyThreads), 0, stream, (const float4 *)d_src, (float4 *)d_dst, n16);  // warm-up
+    hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(kCopyThreads), 0, stream, (const v4f *)d_src, (v4f *)d_dst, n16);  // warm-up
     AMK_HIP(hipEventRecord(e0, stream));
     for (int r = 0; r < reps; ++r)
-        hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(kCopyThreads), 0, stream, (const float4 *)d_src, (float4 *)d_dst, n16);
+        hipLaunchKernelGGL(hbm_copy_kernel, dim3(blocks), dim3(kCopyThreads), 0, stream, (const v4f *)d_src, (v4f *)d_dst, n16);
     AMK_HIP(hipEventRecord(e1, stream));
     AMK_HIP(hipEventSynchronize(e1));
     float ms = 0.f;

@@ -271,6 +271,9 @@ __device__ __forceinline__ void pack_scene(int s, const int *__restrict__ sizes_
                                                           double *__restrict__ ref_states, int *__restrict__ done,
                                                           const int *__restrict__ flags) {
     const int lane = threadIdx.x;
+    // iter < 0: the scene's own pass counter (the solves it has finished this step, flags[1]) -- with an iteration budget on the
+    // solve (amk_mpc_set_solve_budget) the scenes of a launch are no longer in the same pass
+    if (iter < 0) iter = flags[4 * s + 1];
     // QueryNearest through either path returns K points iff the cloud holds more than K, else none
     // (FrameKDMap.cpp:298,339-345 + kd_tree_two.h:119-124)
     const int cnt = sizes_obs[s] > K ? K : 0;
@@ -370,7 +373,20 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
     // handles in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build)
     const int ex_obs = use_grid && obstacle->tie_order && obstacle->ex_valid, ex_edge = use_grid && edge->tie_order && edge->ex_valid;
     const ExactPtrs eobs = ex_obs ? amk_exact_ptrs(obstacle) : ExactPtrs{}, eedge = ex_edge ? amk_exact_ptrs(edge) : ExactPtrs{};
-    for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
+    // Rounds.  Plain schedule (no budget): round r IS pass r of every scene still in the loop, mpc_max_iter rounds.  With an
+    // iteration budget B (amk_mpc_set_solve_budget) a solve launch of the first `budget_rounds` rounds ends after B iterations per
+    // scene; a scene that is not finished by then pauses (done[s] = 2), sits out the next round's queries and packing, and is
+    // resumed INSIDE that round's solve launch beside the fresh solves of the scenes that moved on.  Every scene still makes its
+    // passes in order with the reference's data flow (queries at ITS refilled path, its own pass counter for GetCurStateQuad and
+    // the early exit), so the results are the plain schedule's bit for bit; what changes is that a launch no longer lasts as
+    // long as its slowest scene.  The rounds behind the budgeted ones run without a budget: a scene that enters them in pass p
+    // needs mpc_max_iter - p of them, hence mpc_max_iter catch-up rounds (a round nobody needs is three empty launches).
+    const int mi = prm->mpc_max_iter;
+    const int budget = (g_diag_skip & 4) ? 0 : mpc->solve_budget;
+    const int brounds = budget > 0 ? (mpc->budget_rounds > 0 ? mpc->budget_rounds : mi - 1) : 0;
+    const int rounds = budget > 0 && brounds > 0 ? brounds + mi : mi;
+    const bool per_scene = rounds != mi;
+    for (int iter = 0; iter < rounds; ++iter) {
         if (g_diag_skip & 1) {
         } else if (use_grid) {
             TimedLaunch tl(KC_SCAN_OBS, stream);
@@ -397,12 +413,13 @@ extern "C" int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, cons
         else if (ex_obs) plan_kernel = step_plan_pack_kernel<true, true>;
         hipLaunchKernelGGL(plan_kernel, dim3(S), dim3(kWave), 0, stream, gobs, eobs, obstacle->x.p,
                            obstacle->y.p, obstacle->z.p, obstacle->cap, obstacle->size.p, obstacle->pmax.p, edge->size.p, N,
-                           K, mpc->nref, iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
+                           K, mpc->nref, per_scene ? -1 : iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad,
                            d_pos_x, d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->edge_pt.p, mpc->edge_d2.p,
                            mpc->ref_states.p, mpc->done.p, d_flags); }
         AMK_HIP(hipGetLastError());
         if (g_diag_skip & 4) continue;
-        int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream);
+        int st = launch_solve(mpc, mpc->ref_states.p, d_u, d_x0array, nullptr, mpc->done.p, d_ref_path, d_flags, stream,
+                              per_scene && iter < brounds ? budget : 0, per_scene ? mi : 0);
         if (st != AMK_OK) return st;
     }
     return AMK_OK;

@@ -175,6 +175,11 @@ class MpcBatch:
     def set_solver_options(self, tol=1e-4, max_iter=capi.AMK_MPC_DEFAULT_MAX_ITER):
         capi.check(self.lib.amk_mpc_set_solver_options(self.h, float(tol), int(max_iter)), "set_solver_options")
 
+    def set_solve_budget(self, budget, budget_rounds=0):
+        """amk_mpc_set_solve_budget: interior-point iterations per solve LAUNCH inside amk_step_batch (0: off); unfinished solves
+        pause and are resumed inside the next round's launch.  A scheduling knob: results are unchanged bit for bit."""
+        capi.check(self.lib.amk_mpc_set_solve_budget(self.h, int(budget), int(budget_rounds)), "set_solve_budget")
+
     def set_precision(self, bits):
         """64 (default) or 32: arithmetic of the solve (BASELINE config C5's fp32 tolerance check)."""
         capi.check(self.lib.amk_mpc_set_precision(self.h, int(bits)), "set_precision")

@@ -302,6 +302,8 @@ def flight_main(args):
         pl.mpc(i).set_precision(args.precision)
         if args.ipm_max_iter is not None:
             pl.mpc(i).set_solver_options(1e-4, args.ipm_max_iter)
+        if args.solve_budget is not None:
+            pl.mpc(i).set_solve_budget(args.solve_budget, args.budget_rounds)
     x0 = np.zeros((B, S, 10)); ref0 = np.zeros((B, S, N, 10))
     for b in range(B):
         for s_ in range(S):
@@ -427,6 +429,10 @@ def main():
     ap.add_argument("--precision", type=int, default=64, choices=(32, 64),
                     help="arithmetic of the MPC solve (64 = the reference's; 32 = BASELINE configs[4] variant, not the headline)")
     ap.add_argument("--ipm-max-iter", type=int, default=None, help="iteration cap of the solve (default: the library's)")
+    ap.add_argument("--solve-budget", type=int, default=None,
+                    help="interior-point iterations per solve launch of a step's budgeted rounds (amk_mpc_set_solve_budget; 0: plain "
+                         "schedule; default: the shipped setting)")
+    ap.add_argument("--budget-rounds", type=int, default=0, help="budgeted rounds of a step (0: mpc_max_iter - 1)")
     ap.add_argument("--tie-order", type=int, default=0, choices=(0, 1),
                     help="1: amk_kd_set_tie_order(AMK_TIES_NANOFLANN) on both indices (not the headline configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -523,6 +529,8 @@ def main():
         pl.mpc(i).set_precision(args.precision)
         if args.ipm_max_iter is not None:
             pl.mpc(i).set_solver_options(1e-4, args.ipm_max_iter)
+        if args.solve_budget is not None:
+            pl.mpc(i).set_solve_budget(args.solve_budget, args.budget_rounds)
     slots = [Frames(i) for i in range(nframes)]
     max_rows = max(args.steps, args.steady_steps if args.steps < args.steady_steps else 0, nframes, args.warmup, 64)
     u_sweep = torch.zeros((max_rows, S, 4), dtype=torch.float64, device=dev)   # the sweep's controls, one row per step

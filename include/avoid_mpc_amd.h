@@ -40,6 +40,7 @@ typedef enum amk_status {
 #define AMK_S_DIM 10        /* [px,py,pz,yaw,vx,vy,vz,ax,ay,az]  mpc_obstacle_casadi.py:41-46    */
 #define AMK_U_DIM 4         /* [ax_cmd,ay_cmd,az_cmd,yaw_dot]    mpc_obstacle_casadi.py:75       */
 #define AMK_MPC_DEFAULT_MAX_ITER 100 /* iteration cap of this library's interior-point method (see amk_mpc_create) */
+#define AMK_MAX_BUDGET_ROUNDS 16    /* amk_mpc_set_solve_budget: budgeted rounds of a control step */
 
 int amk_version(void);
 const char *amk_status_string(int status);
@@ -164,6 +165,15 @@ int amk_mpc_set_drone_accel_limits(amk_mpc *mpc, double aMinZ, double aMaxZ, dou
                                    double aMaxYawDot);              /* .cpp:70-92                */
 /* ipopt.tol of HighLvlMpc.cpp:19 and the iteration cap of this library's method (see amk_mpc_create) */
 int amk_mpc_set_solver_options(amk_mpc *mpc, double tol, int max_iter);
+/* Scheduling of the solves inside amk_step_batch -- results are unchanged, bit for bit.  budget > 0: a solve launch of the
+ * step's first `budget_rounds` rounds (0: mpc_max_iter - 1) ends after `budget` interior-point iterations per scene; a scene
+ * whose solve has not converged by then is paused (iterate + multipliers kept on the device) and resumed inside the NEXT
+ * round's launch, while the scenes that did converge make their next re-plan pass there -- a launch no longer lasts as long
+ * as its slowest scene.  Every scene still runs PlanWapionts -> ProcessWaypoints -> GetRefStates -> Solve to convergence ->
+ * refill per pass, in order (AvoidanceStateMachine.cpp:322-344; one Solve per pass, warm start in / out, HighLvlMpc.cpp:93-137);
+ * mpc_max_iter catch-up rounds without a budget follow the budgeted ones.  budget = 0 (default): one round per pass, every
+ * launch runs its scenes to convergence.  No effect on amk_mpc_solve / amk_step_batch_frames.                              */
+int amk_mpc_set_solve_budget(amk_mpc *mpc, int budget, int budget_rounds);
 /* Arithmetic of the NLP evaluation and the interior-point method: 64 (default; the reference's CasADi/IPOPT
  * path is fp64 throughout) or 32 (BASELINE.json configs[4], "fp32 tolerance check vs CPU trajectory").  The
  * interface stays double and the KD queries stay fp64 (neighbour indices remain bit-exact); only the solve
