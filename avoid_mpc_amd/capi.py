@@ -66,7 +66,7 @@ class TaskParams(C.Structure):
     """amk_task_params"""
     _fields_ = [("decay", C.c_double), ("iter_time", C.c_double), ("farest_point", C.c_double), ("height", C.c_double),
                 ("slow_down_kp", C.c_double), ("slow_down_kd", C.c_double), ("a_max_xy", C.c_double), ("a_max_z", C.c_double),
-                ("use_odom_est", C.c_int), ("reserved", C.c_int)]
+                ("use_odom_est", C.c_int), ("task", C.c_int)]
 
 
 class PipelineConfig(C.Structure):
@@ -83,7 +83,8 @@ class PipelineFrame(C.Structure):
                 ("d_ref_path_init", C.c_void_p), ("d_u_out", C.c_void_p), ("d_odom", C.c_void_p), ("odom_age", C.c_double),
                 ("d_cmd_out", C.c_void_p), ("d_depth", C.c_void_p), ("depth_type", C.c_int), ("depth_rows", C.c_int), ("depth_cols", C.c_int),
                 ("reserved", C.c_int), ("d_Twb", C.c_void_p), ("kf_obstacle", C.c_void_p), ("kf_edge", C.c_void_p), ("n_keyframes", C.c_int),
-                ("reserved2", C.c_int), ("d_Twc_cur", C.c_void_p), ("camera", C.c_void_p), ("input_ready", C.c_void_p)]
+                ("reserved2", C.c_int), ("d_Twc_cur", C.c_void_p), ("camera", C.c_void_p), ("input_ready", C.c_void_p),
+                ("d_global_goal", C.c_void_p)]
 
 
 class FrameCamera(C.Structure):

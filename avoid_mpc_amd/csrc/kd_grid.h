@@ -247,6 +247,9 @@ __device__ __forceinline__ void grid_build_tiles_scene(int s, const float *__res
         // the cloud clamps its index, rounds behind it load nothing (NaN x = not kept)
         // (one wave-uniform base per round + a 32-bit lane offset would save the address pairs, but the rounds then sit in
         // uniform branches and their loads no longer overlap: 172 us against 115 for the build alone)
+        // (round 5: the NEXT tile's loads issued before this tile's stores, so that they fly while the records leave -- same
+        // registers, 126 VGPRs -- measured SLOWER, 362-387 us against 351-363 per 1024-scene launch, same box; with non-temporal
+        // loads 370; profiles/r05_ab_build_prefetch.txt.  The two blocks of a CU already overlap each other's phases.)
 #pragma unroll
         for (int j = 0; j < kTileP; ++j) {
             const int i = i0 + j * kGridBuildThreads + tid;

@@ -168,7 +168,7 @@ struct BuildArgs {   // one tree's InitializeNew
 // mostly latency) runs in the shadow of the obstacle build instead of behind it.
 constexpr int kBuildMaxEntries = 2 * AMK_PIPELINE_MAX_GANG;   // (tree, frame) pairs of one launch
 struct BuildArgs2 { BuildArgs t[kBuildMaxEntries]; };
-__global__ __launch_bounds__(kCompactThreads) void kd_build_kernel(const BuildArgs2 args) {
+__global__ __launch_bounds__(kCompactThreads, 4) void kd_build_kernel(const BuildArgs2 args) {   // 4 waves per SIMD = two blocks per CU: <= 128 VGPRs
     const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
     const int s = blockIdx.x;
     if (a.keep_if_zero && a.keep_if_zero[s] == 0) return;   // (block-uniform)

@@ -233,6 +233,9 @@ extern "C" int amk__fast_math_probe(const double *d_x, double *d_out, int n, voi
 static double *g_trace = nullptr;
 extern "C" void amk__debug_trace(double *d_buf) { g_trace = d_buf; }
 
+#ifndef AMK_SOLVE_PRIO
+#define AMK_SOLVE_PRIO 3
+#endif
 #ifndef AMK_SOLVE_WAVES
 #define AMK_SOLVE_WAVES 2  // waves per SIMD the register budget is set for (256 VGPRs each)
 #endif
@@ -254,6 +257,10 @@ __device__ __forceinline__ void solve_kernel_body(int Nrt, int K, int nref, int 
     extern __shared__ __attribute__((aligned(16))) unsigned char sm_raw[];
     R *sm = reinterpret_cast<R *>(sm_raw);
     const int s = blockIdx.x;
+    // the solves go first where a SIMD has to choose: the search / plan waves that share the CUs are fillers for the issue
+    // slots these latency-bound waves leave empty (same-box A/B, 3 x alternating: lone solve launch 2070-2076 us against
+    // 2092-2100, steady state 554.9-555.9 k against 549.5-554.5 k steps/s; profiles/r05_ab_build_prefetch.txt, variant D)
+    __builtin_amdgcn_s_setprio(AMK_SOLVE_PRIO);
     // control step: done[s] = 1: this scene left the re-plan loop already; 2: its solve was paused by an earlier launch's
     // iteration budget (it skipped this round's queries and packing: P still holds the problem it is solving)
     const int dstate = sched.done_rw ? sched.done_rw[s] : (done ? done[s] : 0);

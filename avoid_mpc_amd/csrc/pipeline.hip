@@ -42,6 +42,7 @@ struct amk_pipeline {
         const double *Twc_cur;
         bool has_camera;
         amk_frame_camera camera;
+        const double *global_goal;          // TASK mode, task global_goal: mStateGlobalGoal per scene (or null: {0, 0, height})
     };
     struct Slot {
         hipStream_t stream = nullptr;
@@ -147,10 +148,11 @@ struct PrologueArgs {
     const double *odom[AMK_PIPELINE_MAX_GANG];       // NULL: not a TASK-mode frame
     const double *ref_init[AMK_PIPELINE_MAX_GANG];   // NULL: the slot's own path
     double age[AMK_PIPELINE_MAX_GANG];
+    const double *goal[AMK_PIPELINE_MAX_GANG];       // [S][3] or NULL: mStateGlobalGoal (task global_goal)
     double *sq_dst, *px_dst, *ref_dst;               // [G][S][mi][10], [G][S], [G][S][N][10]
     int S, N, mi;
-    double decay, iter_time, farest, height, speed, T;
-    int use_odom_est;
+    double decay, iter_time, farest, height, speed, T, dt;
+    int use_odom_est, task;
 };
 __global__ __launch_bounds__(256) void pipeline_task_prologue_kernel(const PrologueArgs a) {
 #pragma clang fp contract(off)   // bit-identical to the host twins (avoid_mpc_amd/fsm.py, include/avoid_mpc_amd/avoidance_step.hpp)
@@ -169,20 +171,38 @@ __global__ __launch_bounds__(256) void pipeline_task_prologue_kernel(const Prolo
         const int e = k * 64 + lane;
         v[k] = (live && e < n_shift) ? src[e + 10] : 0.0;
     }
+    // the goal (:26-45), from the path as it is BEFORE the shift.  forward: speed * T ahead of the odometry position, capped;
+    // global_goal: from the path's last point towards mStateGlobalGoal by at most speed * dt (dPos.normalized() * min(|dPos|, .):
+    // Eigen's normalized() divides by the norm when it is positive and returns the vector unchanged otherwise)
+    double goalx = 0.0, goaly = 0.0, goalz = a.height;
+    if (live) {
+        if (a.task == AMK_TASK_GLOBAL_GOAL) {
+            const double *gg = a.goal[g] ? a.goal[g] + (size_t)s * 3 : nullptr;
+            const double g0 = gg ? gg[0] : 0.0, g1 = gg ? gg[1] : 0.0, g2 = gg ? gg[2] : a.height;
+            const double *last = src + n_shift;
+            const double d0 = g0 - last[0], d1 = g1 - last[1], d2 = g2 - last[2];
+            const double z = (d0 * d0 + d1 * d1) + d2 * d2, nrm = sqrt(z);
+            const double step = fmin(nrm, a.speed * a.dt);
+            const double e0 = z > 0.0 ? d0 / nrm : d0, e1 = z > 0.0 ? d1 / nrm : d1, e2 = z > 0.0 ? d2 / nrm : d2;
+            goalx = last[0] + e0 * step; goaly = last[1] + e1 * step; goalz = last[2] + e2 * step;
+        } else {
+            goalx = fmin(a.speed * a.T + o[0], a.farest);
+        }
+    }
     __syncthreads();
     if (live) {
         for (int k = 0; k < 5; ++k) {
             const int e = k * 64 + lane;
-            if (e < n_shift) ref[e] = (e % 10 == 2) ? a.height : v[k];
+            if (e < n_shift) ref[e] = (e % 10 == 2) ? goalz : v[k];
         }
-        if (lane < 10) {
-            const double goalx = fmin(a.speed * a.T + o[0], a.farest);
-            ref[n_shift + lane] = lane == 0 ? goalx : (lane == 2 ? a.height : (lane == 4 ? a.speed : 0.0));
-        }
-        // GetCurStateQuad(start + decay): pass i starts odom_age + decay + i * iter_time after the odometry stamp
+        if (lane < 10) ref[n_shift + lane] = lane == 0 ? goalx : (lane == 1 ? goaly : (lane == 2 ? goalz : (lane == 4 ? a.speed : 0.0)));
+        // GetCurStateQuad(start_i + decay_i) (:329-330,343): pass 0 extrapolates by odom_age + decay; pass i >= 1 starts i passes
+        // later and extrapolates by the MEASURED duration of pass i - 1 -- with the clock model "every pass takes iter_time":
+        // odom_age + (i + 1) * iter_time (written iter_time + i * iter_time so that the default iter_time = decay
+        // keeps the bits of rounds 3-4)
         for (int e = lane; e < a.mi * 10; e += 64) {
             const int i = e / 10, j = e - 10 * i;
-            const double dt = a.age[g] + a.decay + i * a.iter_time;
+            const double dt = a.age[g] + (i == 0 ? a.decay : a.iter_time) + i * a.iter_time;
             double r;
             if (j < 3) r = a.use_odom_est ? o[j] + o[4 + j] * dt + 0.5 * o[7 + j] * dt * dt : o[j];
             else if (j == 3) r = o[3];
@@ -231,7 +251,7 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         const bool task = f.odom != nullptr;
         any_task = any_task || task;
         ga.sq[g] = task ? nullptr : f.state_quad; ga.px[g] = task ? nullptr : f.pos_x; ga.ref[g] = task ? nullptr : f.ref_path_init;
-        pa.odom[g] = f.odom; pa.ref_init[g] = f.ref_path_init; pa.age[g] = f.odom_age;
+        pa.odom[g] = f.odom; pa.ref_init[g] = f.ref_path_init; pa.age[g] = f.odom_age; pa.goal[g] = f.global_goal;
         // fresh frame: mRefPath after GetInitPath, zero warm start unless the caller carries it over (HighLvlMpc.cpp:26-27,35,129)
         ga.keep_warm_start[g] = f.keep_warm_start;
     }
@@ -251,7 +271,7 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         pa.sq_dst = s.state_quad.p; pa.px_dst = s.pos_x.p; pa.ref_dst = s.ref_path.p;
         pa.S = S; pa.N = N; pa.mi = mi;
         pa.decay = t.decay; pa.iter_time = t.iter_time > 0 ? t.iter_time : t.decay; pa.farest = t.farest_point; pa.height = t.height;
-        pa.speed = c.step.speed; pa.T = c.T; pa.use_odom_est = t.use_odom_est;
+        pa.speed = c.step.speed; pa.T = c.T; pa.dt = c.dt; pa.use_odom_est = t.use_odom_est; pa.task = t.task;
         hipLaunchKernelGGL(pipeline_task_prologue_kernel, dim3((S + 3) / 4, filled), dim3(256), 0, st, pa);
         AMK_HIP(hipGetLastError());
     }
@@ -351,7 +371,8 @@ extern "C" {
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
     if (!cfg || !out || cfg->n_slots <= 0 || cfg->n_slots > AMK_PIPELINE_MAX_SLOTS || cfg->n_scenes <= 0 ||
         cfg->max_points <= 0 || cfg->max_edge_points <= 0 || cfg->gang < 0 || cfg->gang > AMK_PIPELINE_MAX_GANG ||
-        cfg->step.mpc_max_iter < 1 || cfg->step.mpc_max_iter > AMK_MAX_OUTER_ITER)
+        cfg->step.mpc_max_iter < 1 || cfg->step.mpc_max_iter > AMK_MAX_OUTER_ITER ||
+        (cfg->task.task != AMK_TASK_FORWARD && cfg->task.task != AMK_TASK_GLOBAL_GOAL))
         return AMK_ERR_INVALID_ARG;
     *out = nullptr;
     if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
@@ -466,7 +487,7 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     s.open.push_back(amk_pipeline::Staged{f->d_cloud, f->d_edge, f->d_cloud_counts, f->d_edge_counts, f->d_state_quad, f->d_pos_x,
                                            f->d_ref_path_init, f->d_u_out, f->keep_warm_start, (hipEvent_t)f->input_ready,
                                            f->d_odom, f->odom_age, f->d_cmd_out, f->d_depth, f->depth_type, f->depth_rows, f->depth_cols, f->d_Twb,
-                                           {}, {}, f->d_Twc_cur, f->camera != nullptr, f->camera ? *f->camera : amk_frame_camera{}});
+                                           {}, {}, f->d_Twc_cur, f->camera != nullptr, f->camera ? *f->camera : amk_frame_camera{}, f->d_global_goal});
     if (f->n_keyframes > 0) {
         s.open.back().kf_obstacle.assign(f->kf_obstacle, f->kf_obstacle + f->n_keyframes);
         s.open.back().kf_edge.assign(f->kf_edge, f->kf_edge + f->n_keyframes);

@@ -3,7 +3,7 @@ the reference-path bookkeeping around amk_step_batch.  (The C++ twin for a ROS n
 include/avoid_mpc_amd/avoidance_step.hpp.)
 
   cur_state_quad  <- AvoidanceStateMachine::GetCurStateQuad   AM/src/AvoidanceStateMachine.cpp:183-203
-  get_init_path   <- AvoidanceStateMachine::GetInitPath       AM/src/AvoidanceStateMachine.cpp:24-54 ("forward")
+  get_init_path   <- AvoidanceStateMachine::GetInitPath       AM/src/AvoidanceStateMachine.cpp:24-54 ("forward", "global_goal")
   state_quads     the per-outer-iteration initial states handed to amk_step_batch
 """
 import numpy as np
@@ -29,18 +29,34 @@ def state_quads(pos, vel, acc, yaw, decay, max_iter, iter_time=None):
     (:329-330,343): iteration 0 extrapolates by `decay`, iteration i by the measured duration of
     iteration i-1 on top of the time already spent.  The device loop has no host round trip, so the
     caller supplies a clock model: every outer iteration is assumed to take `iter_time` seconds
-    (default: decay, the reference's own compute-latency assumption, mpc_parameters.yaml:77)."""
+    (default: decay, the reference's own compute-latency assumption, mpc_parameters.yaml:77): pass 0 extrapolates by decay,
+    pass i >= 1 by (i + 1) * iter_time = i passes spent + the duration of pass i - 1 (written iter_time + i * iter_time: the
+    bits of the default iter_time = decay are those of decay + i * decay)."""
     it = decay if iter_time is None else iter_time
-    return np.stack([cur_state_quad(pos, vel, acc, yaw, decay + i * it) for i in range(max_iter)])
+    return np.stack([cur_state_quad(pos, vel, acc, yaw, (decay if i == 0 else it) + i * it) for i in range(max_iter)])
 
 
-def get_init_path(ref_path, speed, T, pos_x, farest_point, height):
-    """GetInitPath for task "forward": shift by one, append the goal (:29-33,46-53).  In place."""
+def get_init_path(ref_path, speed, T, pos_x, farest_point, height, task="forward", global_goal=None, dt=None):
+    """GetInitPath: shift by one, append the goal (:24-54).  In place.  task "forward" (:29-33): the goal is speed * T ahead of
+    the odometry position, capped at farest_point; task "global_goal" (:34-45): the path's last point walks towards
+    global_goal (mStateGlobalGoal; default the constructor's {0, 0, height}, :22) by at most speed * dt, and its z is written
+    into every shifted point (goalz, :46-52)."""
     N = ref_path.shape[0]
-    goalx = min(speed * T + pos_x, farest_point)
+    goalx, goaly, goalz = min(speed * T + pos_x, farest_point), 0.0, height
+    if task == "global_goal":
+        g = np.array([0.0, 0.0, height]) if global_goal is None else np.asarray(global_goal, np.float64)
+        last = ref_path[N - 1, 0:3]
+        d = g - last
+        z = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+        nrm = np.sqrt(z)
+        e = d / nrm if z > 0.0 else d                       # Eigen's normalized()
+        step = min(nrm, speed * dt)
+        goalx, goaly, goalz = (float(last[i] + e[i] * step) for i in range(3))
+    else:
+        assert task == "forward", task
     for i in range(N - 1):
         nxt = ref_path[i + 1].copy()
         ref_path[i] = nxt
-        ref_path[i, 2] = height
-    ref_path[N - 1] = [goalx, 0.0, height, 0.0, speed, 0.0, 0.0, 0.0, 0.0, 0.0]
+        ref_path[i, 2] = goalz
+    ref_path[N - 1] = [goalx, goaly, goalz, 0.0, speed, 0.0, 0.0, 0.0, 0.0, 0.0]
     return ref_path

@@ -240,10 +240,11 @@ class Pipeline:
     gang = frames (of n_scenes scenes) that share one set of launches -- the slot's handles then hold gang * n_scenes scenes."""
 
     def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0, farest_point=500.0,
-                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None):
+                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None, task="forward"):
         self.lib = capi.load()
         task = capi.TaskParams(float(prm.decay), float(iter_time), float(farest_point), float(prm.height), float(slow_down_kp),
-                               float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)), 0)
+                               float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)),
+                               {"forward": 0, "global_goal": 1}[task])
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
                                   int(prm.K), int(queue_depth), int(gang),
                                   capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task,
@@ -276,7 +277,7 @@ class Pipeline:
 
     def submit(self, clouds, edges, state_quad=None, pos_x=None, ref_path_init=None, cloud_counts=None, edge_counts=None, u_out=None,
                keep_warm_start=False, order_after_current_stream=True, odom=None, odom_age=0.0, cmd_out=None, depth=None, Twb=None,
-               keyframes=None, Twc_cur=None, cam=None):
+               keyframes=None, Twc_cur=None, cam=None, global_goal=None):
         """One fresh frame + control step on the next slot; returns its ticket at once (blocks only when that slot's queue
         is full).  ticket % n_slots = slot; with a gang the frame is staged until the gang is full (or wait / drain).
         All tensors are device tensors that must stay alive until the frame finished.  A slot runs on its own stream: by default
@@ -311,7 +312,8 @@ class Pipeline:
                 del self._events[:len(self._events) // 2]
         fr = capi.PipelineFrame(opt(clouds), opt(cloud_counts), opt(edges), opt(edge_counts),
                                 int(clouds.shape[2]) if clouds is not None else 3, int(bool(keep_warm_start)), opt(state_quad), opt(pos_x),
-                                opt(ref_path_init), opt(u_out), opt(odom), float(odom_age), opt(cmd_out), *dinfo, *kinfo, ev_ptr)
+                                opt(ref_path_init), opt(u_out), opt(odom), float(odom_age), opt(cmd_out), *dinfo, *kinfo, ev_ptr,
+                                opt(global_goal))
         slot = C.c_int(-1)
         capi.check(self.lib.amk_pipeline_submit(self.h, C.byref(fr), C.byref(slot)), "amk_pipeline_submit")
         return slot.value

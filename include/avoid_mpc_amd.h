@@ -333,8 +333,12 @@ typedef struct amk_task_params {
     double slow_down_kp, slow_down_kd;   /* :79-80  (PubSlowDownCmd :379-397)                                               */
     double a_max_xy, a_max_z;            /* clamp of the slow-down command (:383-388; z clamped to +-aMaxZ as there)        */
     int use_odom_est;       /* mParamIsUseOdomEstimate, :78                                                                 */
-    int reserved;
+    int task;               /* mStrTask of GetInitPath (:29-45): AMK_TASK_FORWARD (0, the launch file's default,             */
+                            /* mpc_obstacle_avoidance_sim.launch:9) or AMK_TASK_GLOBAL_GOAL (1): the path's last point walks  */
+                            /* towards amk_pipeline_frame.d_global_goal by at most speed * dt per period (:34-45)            */
 } amk_task_params;
+#define AMK_TASK_FORWARD 0
+#define AMK_TASK_GLOBAL_GOAL 1
 #define AMK_PIPELINE_MAX_SLOTS 64
 #define AMK_PIPELINE_DEFAULT_DEPTH 3
 #define AMK_PIPELINE_MAX_DEPTH 64
@@ -377,7 +381,8 @@ typedef struct amk_pipeline_frame {
     /* per control period what the reference's callbacks supply: the frame and the odometry.  With d_odom != NULL the slot   */
     /* runs, on the device, GetInitPath (:24-54, task "forward") on ITS OWN mRefPath (position g of slot s keeps the path of */
     /* the frame submitted there last: submit the same robots in the same order every period), GetCurStateQuad (:183-203)    */
-    /* for every re-plan pass at odom_age + decay + i * iter_time, the step, and PubCmd / PubSlowDownCmd (:345-350,369-397). */
+    /* for every re-plan pass (odom_age + decay for pass 0, odom_age + (i + 1) * iter_time for pass i >= 1), the step, PubCmd /  */
+    /* PubSlowDownCmd (:345-350,369-397).                                                                                   */
     /* d_state_quad / d_pos_x are then ignored (may be NULL); d_ref_path_init != NULL first (re)sets mRefPath               */
     /* (InitCircleState :14-23 or any re-initialisation) BEFORE GetInitPath, NULL keeps the slot's.                          */
     const double *d_odom;          /* [S][10] or NULL: [mPos(3), yaw, mVel(3), mAcc(3)] as the callbacks left them       */
@@ -409,6 +414,9 @@ typedef struct amk_pipeline_frame {
     void *input_ready;             /* hipEvent_t or NULL: recorded by the caller on the stream that produces this       */
                                    /* frame's inputs; the slot's stream waits for it before it reads them.  The event   */
                                    /* must stay alive (and must not be re-recorded) until the frame has been launched   */
+    const double *d_global_goal;   /* [S][3] or NULL: mStateGlobalGoal of every scene (GlobalGoalCallback, :166-172), read by   */
+                                   /* GetInitPath when amk_task_params.task == AMK_TASK_GLOBAL_GOAL; NULL = the constructor's   */
+                                   /* {0, 0, height} (:22)                                                                   */
 } amk_pipeline_frame;
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out);
 int amk_pipeline_destroy(amk_pipeline *p);

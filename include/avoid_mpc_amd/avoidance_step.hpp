@@ -45,16 +45,26 @@ public:
         }
         sq[3] = o.yaw;
     }
-    // GetInitPath, task "forward" (:24-54)
-    void GetInitPath(const OdomState &o, double farestPoint) {
-        const double goalx = std::fmin(mSpeed * mMpcT + o.pos[0], farestPoint);
+    // GetInitPath (:24-54).  globalGoal == nullptr: task "forward" (:29-33); else task "global_goal" (:34-45): the last point
+    // of the path walks towards mStateGlobalGoal by at most mSpeed * mMpcDt (Eigen's normalized(): divide by the norm when it is
+    // positive), and its z goes into every shifted point.
+    void GetInitPath(const OdomState &o, double farestPoint, const double *globalGoal = nullptr) {
+        double goalx = std::fmin(mSpeed * mMpcT + o.pos[0], farestPoint), goaly = 0.0, goalz = mHeight;
+        if (globalGoal) {
+            const double *last = &mRefPath[10 * (mMpcN - 1)];
+            const double d0 = globalGoal[0] - last[0], d1 = globalGoal[1] - last[1], d2 = globalGoal[2] - last[2];
+            const double z = (d0 * d0 + d1 * d1) + d2 * d2, nrm = std::sqrt(z);
+            const double step = std::fmin(nrm, mSpeed * mMpcDt);
+            const double e0 = z > 0.0 ? d0 / nrm : d0, e1 = z > 0.0 ? d1 / nrm : d1, e2 = z > 0.0 ? d2 / nrm : d2;
+            goalx = last[0] + e0 * step; goaly = last[1] + e1 * step; goalz = last[2] + e2 * step;
+        }
         for (int i = 0; i < mMpcN - 1; ++i) {
             for (int j = 0; j < 10; ++j) mRefPath[10 * i + j] = mRefPath[10 * (i + 1) + j];
-            mRefPath[10 * i + 2] = mHeight;
+            mRefPath[10 * i + 2] = goalz;
         }
         double *l = &mRefPath[10 * (mMpcN - 1)];
         for (int j = 0; j < 10; ++j) l[j] = 0.0;
-        l[0] = goalx; l[2] = mHeight; l[4] = mSpeed;
+        l[0] = goalx; l[1] = goaly; l[2] = goalz; l[4] = mSpeed;
     }
 
     // One TASK step against the current frame of `map`.  now: ros::Time::now() at the start of the step -- the state is
@@ -70,7 +80,7 @@ public:
         if (iterTime < 0) iterTime = mDecay;
         std::vector<double> sq((size_t)mMaxIter * 10);
         const double age = now >= 0 ? now - o.stamp : 0.0;
-        for (int i = 0; i < mMaxIter; ++i) CurStateQuad(o, age + mDecay + i * iterTime, &sq[10 * i]);
+        for (int i = 0; i < mMaxIter; ++i) CurStateQuad(o, age + (i == 0 ? mDecay : iterTime) + i * iterTime, &sq[10 * i]);   // pass i >= 1: (i + 1) * iterTime (:329-330,343)
         amk_step_params p;
         p.speed = mSpeed; p.safety_distance = mSafety; p.mpc_max_iter = mMaxIter; p.reserved = 0;
         u.assign(4, 0.0);
