@@ -31,7 +31,7 @@ SYMBOLS = [
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
-    "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_precision", "amk_mpc_solve",
+    "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_solve_budget", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
     "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_mpc_np", "amk_mpc_eval_gamma",

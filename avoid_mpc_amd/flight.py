@@ -130,7 +130,7 @@ def initial_state(seed, prm):
     return x, synth.make_ref_path(pos, prm)
 
 
-def period_inputs(x, ref_path, prm, farest=500.0, shift=True):
+def period_inputs(x, ref_path, prm, farest=500.0, shift=True, task="forward", global_goal=None):
     """Host side of one period BEFORE the step, for a batch: x [S, 10] plant states (= odometry: perfect sensing),
     ref_path [S, N, 10] in/out.  GetInitPath (:24-54; task "forward", goal_x = 500 of mpc_parameters.yaml:55), then the
     per-pass initial states of the clock model (fsm.state_quads).  -> (state_quad [S, max_iter, 10], pos_x [S])"""
@@ -138,7 +138,8 @@ def period_inputs(x, ref_path, prm, farest=500.0, shift=True):
     sq = np.empty((S, prm.max_iter, 10))
     for s in range(S):
         if shift:
-            fsm.get_init_path(ref_path[s], prm.speed, prm.T, x[s, 0], farest, prm.height)
+            fsm.get_init_path(ref_path[s], prm.speed, prm.T, x[s, 0], farest, prm.height, task=task,
+                              global_goal=None if global_goal is None else global_goal[s], dt=prm.dt)
         sq[s] = fsm.state_quads(x[s, 0:3], x[s, 4:7], x[s, 7:10], x[s, 3], prm.decay, prm.max_iter)
     return sq, x[:, 0].copy()
 

@@ -50,7 +50,8 @@ class _GivenFrames:
 
 
 def _oracle_flight(job):
-    seed, cfg, periods, n_points, world_kw = job
+    seed, cfg, periods, n_points, world_kw = job[:5]
+    task_kw = job[5] if len(job) > 5 else {}      # dict(task="global_goal", global_goal=[3]): GetInitPath's other task (:34-45)
     from tests import _oracle
     prm, n = make_prm(cfg) if isinstance(cfg, str) else (synth.MpcParams(T=cfg[0], K=cfg[1]), n_points)
     n = n_points or n
@@ -66,7 +67,8 @@ def _oracle_flight(job):
     for t in range(periods):
         cloud, edge = world.frame(t)
         kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
-        sq, px = flight.period_inputs(x[None], ref[None], prm)
+        sq, px = flight.period_inputs(x[None], ref[None], prm, task=task_kw.get("task", "forward"),
+                                      global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[None])
         r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
         kd.close(); ke.close()
         a = flight.command(r["u"][None], r["flags"][None], x[None], prm)
@@ -115,11 +117,13 @@ def usable_cores():
     return cores
 
 
-def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None):
-    """-> dict of arrays [F, ...]: x [F, periods + 1, 10], u, flags, cmd, clearance [F, periods + 1]"""
+def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None, task_kw=None):
+    """-> dict of arrays [F, ...]: x [F, periods + 1, 10], u, flags, cmd, clearance [F, periods + 1].
+    task_kw: dict(task="global_goal", global_goal=[F, 3]) flies GetInitPath's other task."""
     from tests import _oracle
     _oracle.build_oracle()
-    jobs = [(int(s), cfg, periods, n_points, world_kw or {}) for s in seeds]
+    tk = lambda i: {} if not task_kw else dict(task=task_kw["task"], global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[i])
+    jobs = [(int(s), cfg, periods, n_points, world_kw or {}, tk(i)) for i, s in enumerate(seeds)]
     return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
 
 
@@ -135,7 +139,7 @@ def oracle_flights_on_frames(clouds, edges, x0, ref0, T, K, cyl=None, workers=No
 
 
 def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batch=None, tie_order=0, precision=64, mode="host",
-                gang=1):
+                gang=1, task_kw=None):
     """The same flights through amk_pipeline_*: one (slot, gang position) per batch of flights, one submit(keep_warm_start) per
     period.  mode "host": GetInitPath / clock model / command on the host (avoid_mpc_amd/flight.py), the pipeline gets
     state_quad, pos_x and the shifted path; mode "task": the pipeline's TASK mode -- the slot keeps mRefPath, the caller hands
@@ -153,16 +157,19 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
     worlds = [flight.FlightWorld(int(s), prm, n, **(world_kw or {})) for s in seeds]
     st = [flight.initial_state(int(s), prm) for s in seeds]
     x = np.stack([a for a, _ in st]); ref = np.stack([b for _, b in st])
-    pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang)
+    task = (task_kw or {}).get("task", "forward")
+    goal = None if not task_kw or task_kw.get("global_goal") is None else np.ascontiguousarray(task_kw["global_goal"], np.float64)
+    pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang, task=task)
     for i in range(nb // gang):
         pl.kd(i, 0).set_tie_order(tie_order); pl.kd(i, 1).set_tie_order(tie_order); pl.mpc(i).set_precision(precision)
+    goal_d = None if goal is None else torch.from_numpy(goal).to(dev)
     logs = dict(x=np.zeros((F, periods + 1, 10)), u=np.zeros((F, periods, 4)), flags=np.zeros((F, periods, 4), np.int32),
                 cmd=np.zeros((F, periods, 3)))
     logs["x"][:, 0] = x
     for t in range(periods):
         keep, tickets = [], []
         if mode == "host":
-            sq, px = flight.period_inputs(x, ref, prm)
+            sq, px = flight.period_inputs(x, ref, prm, task=task, global_goal=goal)
         for b in range(nb):   # every batch of the period in flight, then collect
             sl = slice(b * B, (b + 1) * B)
             fr = [worlds[i].frame(t) for i in range(sl.start, sl.stop)]
@@ -175,7 +182,8 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
                 odom = torch.from_numpy(x[sl]).to(dev); cmd = torch.empty((B, 3), dtype=torch.float64, device=dev)
                 ref0 = torch.from_numpy(ref[sl]).to(dev) if t == 0 else None     # InitCircleState's role; afterwards the slot's own
                 keep.append((clouds, edges, odom, cmd, ref0))
-                tickets.append(pl.submit(clouds, edges, ref_path_init=ref0, odom=odom, cmd_out=cmd, keep_warm_start=t > 0))
+                tickets.append(pl.submit(clouds, edges, ref_path_init=ref0, odom=odom, cmd_out=cmd, keep_warm_start=t > 0,
+                                         global_goal=None if goal_d is None else goal_d[sl]))
         for b, tk in enumerate(tickets):
             sl = slice(b * B, (b + 1) * B)
             pl.wait(tk)

@@ -79,6 +79,35 @@ def test_task_mode_equals_host_mode():
         assert np.array_equal(h["x"], t["x"]) and np.array_equal(h["flags"], t["flags"]) and np.array_equal(h["cmd"], t["cmd"])
 
 
+def test_global_goal_task_of_get_init_path():
+    """GetInitPath's other task (AvoidanceStateMachine.cpp:34-45, mStrTask == "global_goal"): the last point of the path walks
+    towards mStateGlobalGoal by at most speed * dt per period, its z goes into every shifted point.  The device prologue
+    (csrc/pipeline.hip) against the host twin (avoid_mpc_amd/fsm.py), bit for bit over whole flights, gang 1 and 2, goals 20 m
+    ahead / off-axis / the constructor's default {0, 0, height} (d_global_goal = NULL: the goal is BEHIND the start, the path
+    folds back); and against the CPU oracle flown with the same task."""
+    seeds = list(range(760, 768))
+    kw = dict(cyl_per_m=1.0, x_first=3.0)
+    prm, _ = _flight.make_prm("C1")
+    rng = np.random.default_rng(4)
+    goals = np.stack([[20.0, 0.0, prm.height]] * 4 + [[18.0 + rng.uniform(-2, 2), rng.uniform(-1.5, 1.5), prm.height + rng.uniform(-0.3, 0.3)]
+                                                      for _ in range(4)])
+    for tk in (dict(task="global_goal", global_goal=goals), dict(task="global_goal", global_goal=None)):
+        h = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4, task_kw=tk)
+        assert np.abs(h["x"][:, -1, 0:3] - h["x"][:, 0, 0:3]).max() > 0.5
+        for gang in (1, 2):
+            t = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4, mode="task", gang=gang, task_kw=tk)
+            assert np.array_equal(h["x"], t["x"]) and np.array_equal(h["flags"], t["flags"]) and np.array_equal(h["cmd"], t["cmd"])
+        o = _flight.oracle_flights(seeds, "C1", 40, world_kw=kw, task_kw=tk)
+        cmp = _flight.compare(h, o)
+        print("\nglobal_goal flights:", {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")},
+              "x final", h["x"][:, -1, 0].round(2))
+        assert cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= 1
+    fwd = _flight.gpu_flights(seeds, "C1", 40, world_kw=kw, batch=4)
+    assert not np.array_equal(fwd["x"], h["x"])                 # the task does change the flight
+    # (the vehicle does NOT stop at the goal in this harness: the path's last point carries vx = mSpeed (:53) and GetRefStates
+    # pushes the target on by up to speed * T (:251-254) -- the reference's behaviour, flown identically by all three drivers)
+
+
 def test_flights_from_the_raw_depth_image():
     """Pipeline frames that start where FrameKDMap::AddVertex starts (FrameKDMap.cpp:34-52): rendered 16UC1 depth images ->
     ProcessDepth + BuildEdgeCloud (through the slot's own stale Twc, :209) -> both index builds -> TASK step, against the oracle
