@@ -9,7 +9,7 @@ import os
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libavoid_mpc_amd.so")
 
-AMK_OK, AMK_ERR_INVALID_ARG, AMK_ERR_HIP, AMK_ERR_NO_DEVICE, AMK_ERR_UNSUPPORTED = 0, 1, 2, 3, 4   # include/avoid_mpc_amd.h
+AMK_OK, AMK_ERR_INVALID_ARG, AMK_ERR_HIP, AMK_ERR_NO_DEVICE, AMK_ERR_UNSUPPORTED, AMK_ERR_TIMEOUT = 0, 1, 2, 3, 4, 5   # include/avoid_mpc_amd.h
 AMK_MAX_K = 64
 AMK_MAX_QUERIES = 64
 AMK_MAX_HORIZON = 32
@@ -31,16 +31,20 @@ SYMBOLS = [
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
+    "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
+    "amk_kfmap_update", "amk_kfmap_step", "amk_kfmap_state_host",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_solve_budget", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
     "amk_mpc_solve_host", "amk_mpc_ng", "amk_mpc_jac_nnz", "amk_mpc_hess_nnz", "amk_mpc_jac_sparsity",
     "amk_mpc_hess_sparsity", "amk_mpc_eval", "amk_mpc_eval_host", "amk_mpc_np", "amk_mpc_eval_gamma",
     "amk_mpc_eval_gamma_host", "amk_step_batch", "amk_step_batch_frames", "amk_step_batch_host",
     "amk_pipeline_create", "amk_pipeline_destroy", "amk_pipeline_slots", "amk_pipeline_gang", "amk_pipeline_mpc", "amk_pipeline_kd",
+    "amk_pipeline_kfmap",
     "amk_pipeline_stream", "amk_pipeline_submit", "amk_pipeline_wait", "amk_pipeline_query", "amk_pipeline_drain",
     "amk_pipeline_outputs", "amk_pipeline_wait_stream",
     "amk_shard_scene_range", "amk_shard_unique_id", "amk_shard_create", "amk_shard_destroy", "amk_shard_rank",
     "amk_shard_world", "amk_shard_last_rccl_error", "amk_shard_gather", "amk_shard_gather_u", "amk_shard_max", "amk_shard_padded_count",
+    "amk_shard_rccl_info", "amk_shard_wait",
     "amk_depth_out_size", "amk_depth_to_cloud", "amk_depth_to_cloud_host",
     "amk_depth_to_edge_cloud", "amk_depth_to_edge_cloud_host",
 ]
@@ -69,11 +73,17 @@ class TaskParams(C.Structure):
                 ("use_odom_est", C.c_int), ("task", C.c_int)]
 
 
+class KfmapParams(C.Structure):
+    """amk_kfmap_params"""
+    _fields_ = [("max_frame_count", C.c_int), ("keyframe_th_count", C.c_int), ("keyframe_th_dist", C.c_double), ("depth_min", C.c_double),
+                ("Tbc", C.c_double * 16)]
+
+
 class PipelineConfig(C.Structure):
     """amk_pipeline_config"""
     _fields_ = [("n_slots", C.c_int), ("n_scenes", C.c_int), ("max_points", C.c_int), ("max_edge_points", C.c_int),
                 ("T", C.c_double), ("dt", C.c_double), ("nearest_point_num", C.c_int), ("queue_depth", C.c_int),
-                ("gang", C.c_int), ("step", StepParams), ("task", TaskParams), ("depth", DepthParams)]
+                ("gang", C.c_int), ("step", StepParams), ("task", TaskParams), ("depth", DepthParams), ("keyframes", KfmapParams)]
 
 
 class PipelineFrame(C.Structure):
@@ -172,6 +182,7 @@ def load():
         "amk_pipeline_gang": (i, [vp]),
         "amk_pipeline_mpc": (vp, [vp, i]),
         "amk_pipeline_kd": (vp, [vp, i, i]),
+        "amk_pipeline_kfmap": (vp, [vp, i]),
         "amk_pipeline_stream": (vp, [vp, i]),
         "amk_pipeline_submit": (i, [vp, C.POINTER(PipelineFrame), C.POINTER(i)]),
         "amk_pipeline_wait": (i, [vp, i]),
@@ -180,6 +191,15 @@ def load():
         "amk_pipeline_query": (i, [vp, i]),
         "amk_pipeline_drain": (i, [vp]),
         "amk_pipeline_outputs": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "amk_kfmap_create": (i, [i, i, i, C.POINTER(KfmapParams), C.POINTER(vp)]),
+        "amk_kfmap_destroy": (i, [vp]),
+        "amk_kfmap_scenes": (i, [vp]),
+        "amk_kfmap_frames": (i, [vp]),
+        "amk_kfmap_twc": (vp, [vp]),
+        "amk_kfmap_add_vertex": (i, [vp, i, i, vp, vp, vp, vp, i, vp, vp]),
+        "amk_kfmap_update": (i, [vp, vp]),
+        "amk_kfmap_step": (i, [vp, vp, vp, C.POINTER(StepParams), vp, vp, vp, vp, vp, vp, vp]),
+        "amk_kfmap_state_host": (i, [vp, vp, vp, vp, vp]),
         "amk_shard_scene_range": (i, [i, i, i, C.POINTER(i), C.POINTER(i)]),
         "amk_shard_unique_id": (i, [C.c_char_p]),
         "amk_shard_create": (i, [C.c_char_p, i, i, C.POINTER(vp)]),
@@ -191,6 +211,8 @@ def load():
         "amk_shard_gather_u": (i, [vp, vp, i, vp, vp]),
         "amk_shard_max": (i, [vp, vp, i, vp]),
         "amk_shard_padded_count": (i, [i, i]),
+        "amk_shard_rccl_info": (i, [C.c_char_p, i, C.POINTER(i), C.POINTER(i)]),
+        "amk_shard_wait": (i, [vp, vp, d]),
         "amk_depth_out_size": (i, [i, i, d, C.POINTER(i), C.POINTER(i)]),
         "amk_depth_to_cloud": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp, vp]),
         "amk_depth_to_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),

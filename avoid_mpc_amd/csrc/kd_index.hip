@@ -162,6 +162,8 @@ struct BuildArgs {   // one tree's InitializeNew
     const int *keep_if_zero;   // [S] or null: scene s keeps its previous index when keep_if_zero[s] == 0 (FrameKDMap::AddVertex
                                // returns before BOTH InitializeNew calls when the frame's obstacle cloud is empty, FrameKDMap.cpp:39-41)
     float *soa_x, *soa_y, *soa_z;   // or null: the index-ordered planes of the handle's first scene of this entry, written by the build
+    const int *out_scene;      // [S] or null: input scene s is built into scene out_scene[s] of the handle (< 0: not built) -- the
+                               // keyframe map's pool, where every scene's current frame lives in a physical slot of its own (kfmap.hip)
 };
 // grid = (scenes, trees): blockIdx.y selects the tree.  FrameKDMap::AddVertex builds TWO trees per depth frame (obstacle +
 // edge cloud, FrameKDMap.cpp:44-47): amk_kd_build_pair issues them as one launch, so the small edge build (24 us alone,
@@ -170,10 +172,12 @@ constexpr int kBuildMaxEntries = 2 * AMK_PIPELINE_MAX_GANG;   // (tree, frame) p
 struct BuildArgs2 { BuildArgs t[kBuildMaxEntries]; };
 __global__ __launch_bounds__(kCompactThreads, 4) void kd_build_kernel(const BuildArgs2 args) {   // 4 waves per SIMD = two blocks per CU: <= 128 VGPRs
     const BuildArgs &a = args.t[blockIdx.y];   // a scalar load from the kernel-argument segment
-    const int s = blockIdx.x;
-    if (a.keep_if_zero && a.keep_if_zero[s] == 0) return;   // (block-uniform)
-    const float *src = a.xyz + (long long)s * a.scene_stride;
-    int n = a.counts ? a.counts[s] : a.max_points;
+    const int s_in = blockIdx.x;
+    if (a.keep_if_zero && a.keep_if_zero[s_in] == 0) return;   // (block-uniform)
+    const int s = a.out_scene ? a.out_scene[s_in] : s_in;      // where the index goes
+    if (s < 0) return;
+    const float *src = a.xyz + (long long)s_in * a.scene_stride;
+    int n = a.counts ? a.counts[s_in] : a.max_points;
     n = n < 0 ? 0 : (n > a.max_points ? a.max_points : n);
     sample_bbox_scene(s, src, a.point_stride, n, a.bbox_out);
     const size_t so = (size_t)s * a.cap;
@@ -187,7 +191,7 @@ static BuildArgs build_args(amk_kd *kd, const float *d_xyz, int point_stride, lo
     return BuildArgs{d_xyz, point_stride, scene_stride, d_counts, kd->max_points, kd->cap,
                      kd->size.p + so, kd->pmax.p + so, kd->bbox.p + so * 6, kd->gpt.p + so * kd->cap,
                      kd->cell_start.p + so * kd->ntiles * (amk::kGridMaxCells + 2), kd->ntiles,
-                     kd->gparams.p + so * amk::kGridParamDoubles, nullptr, nullptr, nullptr, nullptr};
+                     kd->gparams.p + so * amk::kGridParamDoubles, nullptr, nullptr, nullptr, nullptr, nullptr};
 }
 // A handle in nanoflann tie order builds its tree from the index-ordered planes right after the index: the build kernel
 // writes them itself (coalesced) instead of kd_records_to_soa_kernel scattering them from the records afterwards.  Returns
@@ -454,15 +458,21 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
                                                             const float *__restrict__ KX, const float *__restrict__ KY,
                                                             const float *__restrict__ KZ, int kcap,
                                                             const int *__restrict__ ksizes, double th_dist,
-                                                            unsigned char *__restrict__ flags) {
-    const int s = blockIdx.y;
+                                                            unsigned char *__restrict__ flags,
+                                                            const int *__restrict__ kf_list = nullptr,
+                                                            const int *__restrict__ cur_list = nullptr) {
+    // kf_list / cur_list (the keyframe map's pool, kfmap.hip): row blockIdx.y sweeps scene kf_list[row] of the keyframe arrays
+    // against scene cur_list[row] of the current-frame arrays; kf_list[row] < 0: nothing to sweep.  Null: scene = row in both.
+    const int s = kf_list ? kf_list[blockIdx.y] : blockIdx.y;
+    if (s < 0) return;
+    const int sc = cur_list ? cur_list[blockIdx.y] : s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = ksizes[s];
     if (i >= n) return;
     const size_t o = (size_t)s * kcap + i;
     unsigned char f = 0;
-    if (cur_sizes[s] > 1) {  // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
-        const double d2 = amk::grid_nn1_thread(cur.scene(s), (double)KX[o], (double)KY[o], (double)KZ[o]);
+    if (cur_sizes[sc] > 1) {  // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
+        const double d2 = amk::grid_nn1_thread(cur.scene(sc), (double)KX[o], (double)KY[o], (double)KZ[o]);
         if (d2 < DBL_MAX && sqrt(d2) > th_dist) f = 1;
     }
     flags[o] = f;
@@ -473,8 +483,18 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
 __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
     float *__restrict__ X, float *__restrict__ Y, float *__restrict__ Z, int cap, int *__restrict__ sizes,
     float *__restrict__ pmax_out, float *__restrict__ bbox_out, const unsigned char *__restrict__ flags, int th_count,
-    int *__restrict__ sweep_cnt, int *__restrict__ out_outliers, int *__restrict__ out_rebuilt) {
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    int *__restrict__ sweep_cnt, int *__restrict__ out_outliers, int *__restrict__ out_rebuilt,
+    const int *__restrict__ kf_list = nullptr) {
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int s = kf_list ? kf_list[row] : row;   // (out_outliers / out_rebuilt / sweep_cnt are per ROW)
+    if (s < 0) {
+        if (tid == 0) {
+            if (sweep_cnt) { sweep_cnt[2 * row] = 0; sweep_cnt[2 * row + 1] = 0; }
+            if (out_outliers) out_outliers[row] = 0;
+            if (out_rebuilt) out_rebuilt[row] = 0;
+        }
+        return;
+    }
     float *xs = X + (size_t)s * cap, *ys = Y + (size_t)s * cap, *zs = Z + (size_t)s * cap;
     const unsigned char *fl = flags + (size_t)s * cap;
     const int n = sizes[s];
@@ -497,10 +517,9 @@ __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
     const int total = total_sh;
     const int rebuilt = total >= th_count ? 1 : 0;  // :477-479
     if (tid == 0) {
-        sweep_cnt[2 * s] = total;
-        sweep_cnt[2 * s + 1] = rebuilt;
-        if (out_outliers) out_outliers[s] = total;
-        if (out_rebuilt) out_rebuilt[s] = rebuilt;
+        if (sweep_cnt) { sweep_cnt[2 * row] = total; sweep_cnt[2 * row + 1] = rebuilt; }
+        if (out_outliers) out_outliers[row] = total;
+        if (out_rebuilt) out_rebuilt[row] = rebuilt;
     }
     if (!rebuilt) return;
     float amax = 0.f, bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
@@ -601,6 +620,76 @@ extern "C" int amk_kd_keyframe_sweep(amk_kd *keyframe, amk_kd *current, double t
     return AMK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// the keyframe map's pool (kfmap.hip): one handle holds P physical frames x S scenes, scene index = slot * S + s
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(amk::kGridBuildThreads) void kd_grid_build_list_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap,
+    const int *__restrict__ sizes, const float *__restrict__ bbox, float4 *__restrict__ GP, int *__restrict__ cell_start,
+    int ntiles, double *__restrict__ gparams, const int *__restrict__ list, const int *__restrict__ rebuilt) {
+    const int s = list[blockIdx.x];
+    if (s < 0 || !rebuilt[blockIdx.x]) return;   // (block-uniform)
+    amk::grid_build_scene(s, X + (size_t)s * cap, Y + (size_t)s * cap, Z + (size_t)s * cap, cap, sizes[s], bbox, GP, cell_start,
+                          ntiles, gparams);
+}
+
+namespace amk {
+static int pool_planes(amk_kd *kd) {   // the index-ordered planes of a pool handle: written by every build, compacted by the sweeps
+    const size_t tot = (size_t)kd->n_scenes * kd->cap;
+    if (!kd->x.p) AMK_HIP(kd->x.alloc(tot));
+    if (!kd->y.p) AMK_HIP(kd->y.alloc(tot));
+    if (!kd->z.p) AMK_HIP(kd->z.alloc(tot));
+    return AMK_OK;
+}
+
+// FrameKDMap::AddVertex's two InitializeNew calls (FrameKDMap.cpp:44-47) for n_in scenes, each into the pool scene
+// d_out_scene[s] (< 0: that scene gets no new frame); the obstacle pool's planes are written along.
+int kd_build_mapped(amk_kd *obs_pool, amk_kd *edge_pool, int n_in, const float *d_xyz, const int *d_counts,
+                    const float *d_edge_xyz, const int *d_edge_counts, int point_stride, const int *d_out_scene,
+                    hipStream_t stream) {
+    if (!obs_pool || !edge_pool || n_in < 1 || !d_xyz || !d_edge_xyz || !d_out_scene || point_stride < 3) return AMK_ERR_INVALID_ARG;
+    const int st = pool_planes(obs_pool);
+    if (st != AMK_OK) return st;
+    BuildArgs a = build_args(obs_pool, d_xyz, point_stride, (long long)obs_pool->max_points * point_stride, d_counts);
+    BuildArgs b = build_args(edge_pool, d_edge_xyz, point_stride, (long long)edge_pool->max_points * point_stride, d_edge_counts);
+    a.out_scene = b.out_scene = d_out_scene;
+    a.soa_x = obs_pool->x.p; a.soa_y = obs_pool->y.p; a.soa_z = obs_pool->z.p;
+    BuildArgs2 args{};
+    args.t[0] = a; args.t[1] = b;
+    {
+        amk::TimedLaunch tg(amk::KC_GRID, stream);
+        hipLaunchKernelGGL(kd_build_kernel, dim3(n_in, 2), dim3(kCompactThreads), 0, stream, args);
+    }
+    AMK_HIP(hipGetLastError());
+    for (amk_kd *kd : {obs_pool, edge_pool}) { kd->soa_valid = 0; kd->ex_valid = 0; kd->async_pending = 1; }
+    return AMK_OK;
+}
+
+// KeyframeThreadWorker's sweep (FrameKDMap.cpp:463-485) for n_rows scenes of a map: row r sweeps the points of pool scene
+// d_kf_list[r] (the newest keyframe) against pool scene d_cur_list[r] (the current frame); with >= th_count outliers the
+// keyframe's planes are compacted to them in place and its index is rebuilt.  d_outliers / d_rebuilt: [n_rows].
+int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d_cur_list, double th_dist, int th_count,
+                    int *d_outliers, int *d_rebuilt, hipStream_t stream) {
+    if (!pool || n_rows < 1 || !d_kf_list || !d_cur_list || !d_rebuilt) return AMK_ERR_INVALID_ARG;
+    int st = pool_planes(pool);
+    if (st != AMK_OK) return st;
+    if (!pool->flags.p) AMK_HIP(pool->flags.alloc((size_t)pool->n_scenes * pool->cap));
+    const amk::GridPtrs cur{pool->gpt.p, pool->cell_start.p, pool->gparams.p, pool->cap, pool->ntiles};
+    if (pool->max_points > 0)
+        hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
+                           pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list, d_cur_list);
+    hipLaunchKernelGGL(kd_sweep_compact_kernel, dim3(n_rows), dim3(kCompactThreads), 0, stream, pool->x.p, pool->y.p, pool->z.p,
+                       pool->cap, pool->size.p, pool->pmax.p, pool->bbox.p, pool->flags.p, th_count, (int *)nullptr, d_outliers,
+                       d_rebuilt, d_kf_list);
+    hipLaunchKernelGGL(kd_grid_build_list_kernel, dim3(n_rows), dim3(amk::kGridBuildThreads), 0, stream, pool->x.p, pool->y.p,
+                       pool->z.p, pool->cap, pool->size.p, pool->bbox.p, pool->gpt.p, pool->cell_start.p, pool->ntiles,
+                       pool->gparams.p, d_kf_list, d_rebuilt);
+    AMK_HIP(hipGetLastError());
+    pool->async_pending = 1;
+    return AMK_OK;
+}
+}  // namespace amk
+
 extern "C" int amk_kd_keyframe_sweep_host(amk_kd *keyframe, amk_kd *current, double th_dist, int th_count,
                                           int *h_outliers, int *h_rebuilt) {
     int st = amk_kd_keyframe_sweep(keyframe, current, th_dist, th_count, nullptr, nullptr, nullptr);
@@ -657,6 +746,7 @@ const char *amk_status_string(int status) {
         case AMK_ERR_HIP: return "HIP runtime error";
         case AMK_ERR_NO_DEVICE: return "no HIP device (this library has no CPU fallback)";
         case AMK_ERR_UNSUPPORTED: return "unsupported size";
+        case AMK_ERR_TIMEOUT: return "timed out waiting for a collective (amk_shard_wait)";
         default: return "unknown status";
     }
 }

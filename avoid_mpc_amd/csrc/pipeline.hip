@@ -59,6 +59,9 @@ struct amk_pipeline {
         amk::DevBuf<float> dcloud, dedge;      // [G S][max_points][3], [G S][max_edge_points][3]
         amk::DevBuf<int> dcount, decount;      // [G S]
         amk::DevBuf<double> Twc;               // [G S][16]
+        bool ref_inited[AMK_PIPELINE_MAX_GANG] = {};   // TASK mode: position g holds an mRefPath (a frame with d_ref_path_init ran
+                                        // there, and no launch has failed half-way since)
+        amk_kfmap *map = nullptr;       // amk_pipeline_config.keyframes.max_frame_count > 0: the slot's keyframe map (gang x n_scenes scenes)
         int fail_status = AMK_OK;       // the slot's newest launch failed half-way with this status: its frames were dropped, their
                                         // results are undefined; reported by that submit() and by wait() / drain() until the next launch
     };
@@ -285,11 +288,17 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         keep[g] = nullptr;
         if (!f.depth) continue;
         if (s.point_stride != 3) return AMK_ERR_INVALID_ARG;   // the slot's own clouds are packed xyz
-        if (!s.dcloud.p) {   // first depth frame of this slot
+        if (!s.dcloud.p || !s.dedge.p || !s.dcount.p || !s.decount.p || !s.Twc.p) {   // first depth frame of this slot (or an
+            // earlier attempt ran out of memory half-way: ADVICE r4 -- all five buffers or none)
             const size_t GS = (size_t)G * S;
-            AMK_HIP(s.dcloud.alloc(GS * c.max_points * 3)); AMK_HIP(s.dedge.alloc(GS * c.max_edge_points * 3));
-            AMK_HIP(s.dcount.alloc(GS)); AMK_HIP(s.decount.alloc(GS)); AMK_HIP(s.Twc.alloc(GS * 16));
+            hipError_t e;
+            if ((e = s.dcloud.alloc(GS * c.max_points * 3)) != hipSuccess || (e = s.dedge.alloc(GS * c.max_edge_points * 3)) != hipSuccess ||
+                (e = s.dcount.alloc(GS)) != hipSuccess || (e = s.decount.alloc(GS)) != hipSuccess || (e = s.Twc.alloc(GS * 16)) != hipSuccess) {
+                s.dcloud.release(); s.dedge.release(); s.dcount.release(); s.decount.release(); s.Twc.release();
+                return amk::hip_fail(e);
+            }
             hipLaunchKernelGGL(pipeline_twc_init_kernel, dim3((unsigned)((GS * 16 + 255) / 256)), dim3(256), 0, st, s.Twc.p, (int)GS);
+            AMK_HIP(hipGetLastError());
         }
         any_depth = true;
         const size_t o = (size_t)g * S;
@@ -307,14 +316,38 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         keep[g] = s.dcount.p + o;
     }
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
-    if (G == 1 && !any_depth) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
+    if (s.map) {   // ... into the slot's keyframe map: the scenes' own physical slots, mCurFrame.Twc, then KeyframeThreadWorker's body
+        for (int g = 0; g < filled; ++g) {
+            const amk_pipeline::Staged &f = s.open[g];
+            const double *twc = f.depth ? s.Twc.p + (size_t)g * S * 16 : f.Twc_cur;
+            if (!twc) return AMK_ERR_INVALID_ARG;   // (submit() checked)
+            rc = amk_kfmap_add_vertex(s.map, g * S, S, cl[g], cc[g], ed[g], ec[g], s.point_stride, twc, st);
+            if (rc != AMK_OK) return rc;
+        }
+        rc = amk_kfmap_update(s.map, st);
+    } else if (G == 1 && !any_depth) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
     else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st, any_depth ? keep : nullptr);
     if (rc != AMK_OK) return rc;
     if (p->inject_failure == 2) { p->inject_failure = 0; return AMK_ERR_HIP; }
     double *u = (G == 1 && s.open[0].u_out && !any_task) ? s.open[0].u_out : s.u.p;
     const double *sq = own_inputs ? s.state_quad.p : s.open[0].state_quad, *px = own_inputs ? s.pos_x.p : s.open[0].pos_x;
     s.mpc->run_scenes = filled * S;
-    if (!s.open[0].kf_obstacle.empty()) {   // mVecQueryVector = [this frame, keyframes ...] (gang 1: submit() checked)
+    if (s.map) {   // the step over the slot's own map: mVecQueryVector = [current, keyframes but the newest] of every scene
+        const amk_pipeline::Staged &f = s.open[0];
+        amk_frame_camera cam{};
+        bool has_cam = f.has_camera;
+        if (has_cam) cam = f.camera;
+        if (f.depth) {   // the FrameKDMap constructor's down-scaled intrinsics and ProcessDepth's image size (:21-24,106-107)
+            int w = 0, h = 0;
+            rc = amk_depth_out_size(f.depth_rows, f.depth_cols, c.depth.resize_scale, &w, &h);
+            if (rc != AMK_OK) return rc;
+            cam.fx = c.depth.fx / c.depth.resize_scale; cam.fy = c.depth.fy / c.depth.resize_scale;
+            cam.cx = c.depth.cx / c.depth.resize_scale; cam.cy = c.depth.cy / c.depth.resize_scale;
+            cam.depth_max = c.depth.depth_max; cam.width = w; cam.height = h;
+            has_cam = true;
+        }
+        rc = amk_kfmap_step(s.map, has_cam ? &cam : nullptr, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
+    } else if (!s.open[0].kf_obstacle.empty()) {   // mVecQueryVector = [this frame, keyframes ...] (gang 1: submit() checked)
         const amk_pipeline::Staged &f = s.open[0];
         std::vector<amk_kd *> ob{s.obstacle}, ed2{s.edge};
         ob.insert(ob.end(), f.kf_obstacle.begin(), f.kf_obstacle.end());
@@ -343,6 +376,8 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     }
     AMK_HIP(hipEventRecord(s.done[s.count % p->depth], st));
     ++s.count;
+    for (int g = 0; g < filled; ++g)
+        if (s.open[g].odom && s.open[g].ref_path_init) s.ref_inited[g] = true;
     s.open.clear();
     return AMK_OK;
 }
@@ -355,6 +390,11 @@ int launch_slot(amk_pipeline *p, amk_pipeline::Slot &s) {
     if (s.open.empty()) return AMK_OK;
     const int st = launch_gang(p, s);
     if (st != AMK_OK) {
+        // What had been enqueued before the failure stays enqueued: a TASK frame's GetInitPath may already have shifted the slot's
+        // mRefPath, its warm start may have been reset, a depth frame's Twc may have moved on.  The slot's persistent
+        // TASK state is therefore declared lost: the next TASK frame at any position of this slot must bring d_ref_path_init
+        // (submit() rejects it otherwise) -- re-submitting the failed period as it was would shift the path twice.
+        for (bool &b : s.ref_inited) b = false;
         s.open.clear();
         s.mpc->run_scenes = 0;
         (void)hipEventRecord(s.done[s.count % p->depth], s.stream);
@@ -371,7 +411,7 @@ extern "C" {
 int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
     if (!cfg || !out || cfg->n_slots <= 0 || cfg->n_slots > AMK_PIPELINE_MAX_SLOTS || cfg->n_scenes <= 0 ||
         cfg->max_points <= 0 || cfg->max_edge_points <= 0 || cfg->gang < 0 || cfg->gang > AMK_PIPELINE_MAX_GANG ||
-        cfg->step.mpc_max_iter < 1 || cfg->step.mpc_max_iter > AMK_MAX_OUTER_ITER ||
+        cfg->step.mpc_max_iter < 1 || cfg->step.mpc_max_iter > AMK_MAX_OUTER_ITER || cfg->keyframes.max_frame_count < 0 ||
         (cfg->task.task != AMK_TASK_FORWARD && cfg->task.task != AMK_TASK_GLOBAL_GOAL))
         return AMK_ERR_INVALID_ARG;
     *out = nullptr;
@@ -400,6 +440,14 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
         if ((st = amk_kd_create(GS, cfg->max_points, &s.obstacle)) != AMK_OK) break;
         if ((st = amk_kd_create(GS, cfg->max_edge_points, &s.edge)) != AMK_OK) break;
         if ((st = amk_mpc_create(cfg->T, cfg->dt, cfg->nearest_point_num, GS, &s.mpc)) != AMK_OK) break;
+        if (cfg->keyframes.max_frame_count > 0) {
+            amk_kfmap_params kp = cfg->keyframes;
+            std::memcpy(kp.Tbc, cfg->depth.Tbc, sizeof kp.Tbc);
+            bool zero = true;
+            for (double v : kp.Tbc) zero = zero && v == 0.0;
+            if (zero) kp.Tbc[0] = kp.Tbc[5] = kp.Tbc[10] = kp.Tbc[15] = 1.0;   // (no depth configuration: camera frame = body frame)
+            if ((st = amk_kfmap_create(GS, cfg->max_points, cfg->max_edge_points, &kp, &s.map)) != AMK_OK) break;
+        }
         const size_t S = GS, N = amk_mpc_horizon(s.mpc);
         if ((e = s.ref_path.alloc(S * N * 10)) != hipSuccess || (e = s.u.alloc(S * 4)) != hipSuccess ||
             (e = s.x0array.alloc(S * N * 14)) != hipSuccess || (e = s.flags.alloc(S * 4)) != hipSuccess) {
@@ -426,6 +474,7 @@ int amk_pipeline_destroy(amk_pipeline *p) {
         if (s.obstacle) amk_kd_destroy(s.obstacle);
         if (s.edge) amk_kd_destroy(s.edge);
         if (s.mpc) amk_mpc_destroy(s.mpc);
+        if (s.map) amk_kfmap_destroy(s.map);
         for (auto ev : s.done)
             if (ev) (void)hipEventDestroy(ev);
         if (s.stream) (void)hipStreamDestroy(s.stream);
@@ -439,6 +488,9 @@ int amk_pipeline_gang(const amk_pipeline *p) { return p ? p->gang : -1; }
 
 amk_mpc *amk_pipeline_mpc(amk_pipeline *p, int slot) {
     return (p && slot >= 0 && slot < (int)p->slots.size()) ? p->slots[slot].mpc : nullptr;
+}
+amk_kfmap *amk_pipeline_kfmap(amk_pipeline *p, int slot) {
+    return (p && slot >= 0 && slot < (int)p->slots.size()) ? p->slots[slot].map : nullptr;
 }
 amk_kd *amk_pipeline_kd(amk_pipeline *p, int slot, int which) {
     if (!p || slot < 0 || slot >= (int)p->slots.size()) return nullptr;
@@ -462,12 +514,15 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
     if (f->n_keyframes < 0 || f->n_keyframes > AMK_MAX_FRAMES - 1) return AMK_ERR_INVALID_ARG;
+    if (s.map && (f->n_keyframes > 0 || (!f->d_depth && !f->d_Twc_cur))) return AMK_ERR_INVALID_ARG;   // the slot's own map: no caller keyframes; cloud frames bring mCurFrame.Twc
     if (f->n_keyframes > 0) {
         if (p->gang != 1) return AMK_ERR_UNSUPPORTED;   // keyframe handles hold n_scenes scenes, a gang's handles gang x n_scenes
         if (!f->kf_obstacle || !f->kf_edge) return AMK_ERR_INVALID_ARG;
         for (int i = 0; i < f->n_keyframes; ++i)
             if (!f->kf_obstacle[i] || !f->kf_edge[i]) return AMK_ERR_INVALID_ARG;
     }
+    // a TASK frame shifts the mRefPath the slot keeps for its position: there must be one (InitCircleState's role, :14-23)
+    if (f->d_odom && !f->d_ref_path_init && !s.ref_inited[s.open.size() < AMK_PIPELINE_MAX_GANG ? s.open.size() : 0]) return AMK_ERR_INVALID_ARG;
     const int stride = f->d_depth ? 3 : (f->point_stride ? f->point_stride : 3);
     if (stride != 3 && stride != 4) return AMK_ERR_INVALID_ARG;
     if (!s.open.empty() && stride != s.point_stride) return AMK_ERR_INVALID_ARG;   // one point layout per gang
@@ -528,6 +583,7 @@ int amk_pipeline_query(amk_pipeline *p, int ticket) {  // 1 = finished (or idle)
     if (!p || ticket < 0 || ticket >= (int)p->slots.size() * p->gang) return -1;
     auto &s = p->slots[ticket % (int)p->slots.size()];
     if (!s.open.empty()) return 0;
+    if (s.fail_status != AMK_OK) return -1;   // the slot's newest launch failed half-way: its frames were dropped (wait() tells why)
     if (s.waited >= s.count) return 1;
     const hipError_t e = hipEventQuery(s.done[(s.count - 1) % p->depth]);
     if (e == hipSuccess) { s.waited = s.count; return 1; }

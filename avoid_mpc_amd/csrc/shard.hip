@@ -10,7 +10,10 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <chrono>
 #include <cstring>
+#include <string>
+#include <thread>
 
 namespace {
 
@@ -22,16 +25,28 @@ struct Rccl {
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*GetVersion)(int *) = nullptr;
     bool ok = false;
+    bool was_loaded = false;   // the library was in the process already (RTLD_NOLOAD found it): e.g. PyTorch's bundled copy
+    std::string path;          // where the bound ncclAllGather lives (dladdr)
 };
 
 Rccl &rccl() {
     static Rccl r;
     if (r.h) return r;
-    for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-        if (r.h) break;
+    // ONE RCCL per process: a Python host has already mapped PyTorch's bundled librccl (torch.distributed's "nccl"
+    // backend); a second copy under the same SONAME would give the process two sets of communicator threads, proxy state and
+    // environment parsing -- whatever the first multi-GPU run then does wrong would not be explained by either.  So: take the
+    // copy that is ALREADY loaded if there is one (RTLD_NOLOAD), load one only otherwise, and record which file was bound.
+    for (const char *name : {"librccl.so.1", "librccl.so"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+        if (r.h) { r.was_loaded = true; break; }
     }
+    if (!r.h)
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.h) break;
+        }
     if (!r.h) return r;
     r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(r.h, "ncclGetUniqueId");
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.h, "ncclCommInitRank");
@@ -39,7 +54,10 @@ Rccl &rccl() {
     r.AllGather = (decltype(r.AllGather))dlsym(r.h, "ncclAllGather");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.h, "ncclAllReduce");
     r.GetErrorString = (decltype(r.GetErrorString))dlsym(r.h, "ncclGetErrorString");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
     r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllReduce;
+    Dl_info di;
+    if (r.AllGather && dladdr((void *)r.AllGather, &di) && di.dli_fname) r.path = di.dli_fname;
     return r;
 }
 
@@ -117,6 +135,40 @@ int amk_shard_destroy(amk_shard *s) {
 int amk_shard_rank(const amk_shard *s) { return s ? s->rank : -1; }
 int amk_shard_world(const amk_shard *s) { return s ? s->world : -1; }
 int amk_shard_last_rccl_error(void) { return g_last_nccl; }
+
+// Which RCCL this library bound: the file ncclAllGather was resolved from, its version code (ncclGetVersion: major * 10000 +
+// minor * 100 + patch; 0 when the library has no such entry), and whether it had been loaded by somebody else before (1) or
+// by this library (0).  path: at least path_len bytes, always terminated.  AMK_ERR_UNSUPPORTED when no librccl can be loaded.
+int amk_shard_rccl_info(char *path, int path_len, int *version, int *was_loaded) {
+    if (!path || path_len <= 0) return AMK_ERR_INVALID_ARG;
+    path[0] = 0;
+    Rccl &r = rccl();
+    if (!r.ok) return AMK_ERR_UNSUPPORTED;
+    std::strncpy(path, r.path.c_str(), (size_t)path_len - 1);
+    path[path_len - 1] = 0;
+    int v = 0;
+    if (r.GetVersion && r.GetVersion(&v) != ncclSuccess) v = 0;
+    if (version) *version = v;
+    if (was_loaded) *was_loaded = r.was_loaded ? 1 : 0;
+    return AMK_OK;
+}
+
+// Watchdog for the exchange step: waits until everything queued on `stream` so far (the gathers above included) has finished,
+// polling hipStreamQuery, at most timeout_s seconds.  AMK_ERR_TIMEOUT: a collective is still not done -- a peer that never
+// entered it, a dead link, two RCCL copies in one process ...; the communicator is then unusable and the process should exit
+// (set NCCL_DEBUG=INFO and NCCL_DEBUG_SUBSYS=INIT,COLL for the next run: RCCL prints which rank / channel it waits for).
+int amk_shard_wait(amk_shard *s, void *stream, double timeout_s) {
+    if (!s || !(timeout_s > 0)) return AMK_ERR_INVALID_ARG;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery((hipStream_t)stream);
+        if (e == hipSuccess) return AMK_OK;
+        if (e != hipErrorNotReady) return amk::hip_fail(e);
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > timeout_s) return AMK_ERR_TIMEOUT;
+        if (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.002)
+            std::this_thread::sleep_for(std::chrono::microseconds(200));   // spin for the first 2 ms (a healthy gather), then doze
+    }
+}
 
 int amk_shard_gather(amk_shard *s, const double *d_local, long long n_doubles_per_rank, double *d_all, void *stream) {
     if (!s || !d_local || !d_all || n_doubles_per_rank < 0) return AMK_ERR_INVALID_ARG;

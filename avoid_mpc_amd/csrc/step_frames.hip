@@ -30,6 +30,23 @@ struct FrameSet {  // kernel argument: where every frame's indices live
     GridPtrs obs[AMK_MAX_FRAMES], edge[AMK_MAX_FRAMES];
     const int *size_obs[AMK_MAX_FRAMES], *size_edge[AMK_MAX_FRAMES];
     int n;
+    // Map mode (the keyframe map, kfmap.hip): every frame of every scene lives in ONE pool handle (obs[0] / edge[0] /
+    // size_*[0]); frame f of scene s is pool scene fmap[f * S + s], or absent (< 0: this scene's map is shorter) -- an absent
+    // frame behaves like an empty cloud, which contributes nothing to any query (FrameKDMap.cpp:298,385-387).  n may then
+    // exceed AMK_MAX_FRAMES (the per-frame arrays above are not used beyond [0]).
+    const int *fmap;
+    int S;
+    __device__ __forceinline__ int scene_of(int f, int s) const { return fmap ? fmap[(size_t)f * S + s] : s; }
+    __device__ __forceinline__ GridScene obs_scene(int f, int m) const { return (fmap ? obs[0] : obs[f]).scene(m); }
+    __device__ __forceinline__ GridScene edge_scene(int f, int m) const { return (fmap ? edge[0] : edge[f]).scene(m); }
+    __device__ __forceinline__ int n_obs(int f, int s) const {
+        const int m = scene_of(f, s);
+        return m < 0 ? 0 : (fmap ? size_obs[0] : size_obs[f])[m];
+    }
+    __device__ __forceinline__ int n_edge(int f, int s) const {
+        const int m = scene_of(f, s);
+        return m < 0 ? 0 : (fmap ? size_edge[0] : size_edge[f])[m];
+    }
 };
 
 struct FrameBufs {  // per-frame raw query results, frame-major
@@ -57,11 +74,13 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= nq || done[s]) return;
     const bool is_edge = q == N;
+    const int m = fs.scene_of(f, s);
+    if (m < 0) return;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const int k = is_edge ? 1 : K;
     double ld;
     int li, lpos;
-    const GridScene gs = is_edge ? fs.edge[f].scene(s) : fs.obs[f].scene(s);
+    const GridScene gs = is_edge ? fs.edge_scene(f, m) : fs.obs_scene(f, m);
     grid_knn(gs, qp[0], qp[1], qp[2], k, ld, li, lpos, &wl[w]);
     if (lane < k) {
         const bool ok = li != kNoIndex;
@@ -145,9 +164,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 }
 
 constexpr int kMaxCandPerLane = (AMK_MAX_FRAMES * AMK_MAX_K + 63) / 64;
+constexpr int kMaxCandPerLaneMap = 0;   // the keyframe map beyond 64 kMaxCandPerLane candidates (the reference's max_frame_count = 100:
+                                        // 101 frames x K): the candidates are re-read every round instead of living in registers
 
-// EXACT (some frame in AMK_TIES_NANOFLANN mode): a template parameter so that the default kernel needs no scratch memory
-template <bool EXACT>
+// EXACT (some frame in AMK_TIES_NANOFLANN mode): a template parameter so that the default kernel needs no scratch memory.
+// CPL: merge candidates (frame, neighbour) a lane may hold -- F K <= 64 CPL.
+template <bool EXACT, int CPL = kMaxCandPerLane>
 __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     FrameSet fs, const FrameExact *__restrict__ fe, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
     int max_iter, double speed, double T, double safety_distance, const double *__restrict__ state_quad,
@@ -165,18 +187,20 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     const double p0x = rp[0], p0y = rp[1], p0z = rp[2];
     double d2n = DBL_MAX;  // GetNearestDistance: 1-NN per frame exists iff the frame holds more than one point
     for (int f = 0; f < F; ++f)
-        if (fs.size_obs[f][s] > 1) d2n = fmin(d2n, fb.knn_d2[(((size_t)f * S + s) * N) * K]);
+        if (fs.n_obs(f, s) > 1) d2n = fmin(d2n, fb.knn_d2[(((size_t)f * S + s) * N) * K]);
     int is_safety = 1;
     if (!(sqrt(d2n) > safety_distance)) {
         // QueryNearest(p1, 1, ..., queryEdge = true): fast path iff the current edge cloud holds >= 1 point and p1 is in frame
         double best = DBL_MAX;
         int bf = -1;
-        if (fs.size_edge[0][s] >= 1 && in_frame(p0x, p0y, p0z)) {
-            if (fs.size_edge[0][s] > 1 && fb.edge_d2[s] < DBL_MAX) { best = fb.edge_d2[s]; bf = 0; }
+        if (fs.n_edge(0, s) >= 1 && in_frame(p0x, p0y, p0z)) {
+            if (fs.n_edge(0, s) > 1 && fb.edge_d2[s] < DBL_MAX) { best = fb.edge_d2[s]; bf = 0; }
         } else {
             for (int f = 0; f < F; ++f) {  // k' = min(1, size_f): a result iff size_f > 1; ties keep the earlier frame
-                const double d = fb.edge_d2[(size_t)f * S + s];
-                if (fs.size_edge[f][s] > 1 && d < best) { best = d; bf = f; }
+                if (fs.n_edge(f, s) > 1) {
+                    const double d = fb.edge_d2[(size_t)f * S + s];
+                    if (d < best) { best = d; bf = f; }
+                }
             }
         }
         if (bf < 0) {
@@ -187,7 +211,9 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
             for (int f = 0; f < F; ++f) {  // the snapped point is what ProcessWaypoints queries next (:210-215)
                 double gld;
                 int gli, glpos;
-                const GridScene gs = fs.obs[f].scene(s);
+                const int mf = fs.scene_of(f, s);
+                if (mf < 0) continue;   // (wave-uniform)
+                const GridScene gs = fs.obs_scene(f, mf);
                 grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl);
                 if (lane < K) {
                     const bool ok = gli != kNoIndex;
@@ -225,8 +251,8 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     for (int i = 0; i < N; ++i) {
         const double qx = rp[i * SD], qy = rp[i * SD + 1], qz = rp[i * SD + 2];
         const size_t orow = ((size_t)s * N + i) * K;
-        if (fs.size_obs[0][s] >= K && in_frame(qx, qy, qz)) {  // QueryNearestWithCurFrame (:254-275, 339-345)
-            const int cnt = fs.size_obs[0][s] > K ? K : 0;      // kd_tree_two.h:119-124
+        if (fs.n_obs(0, s) >= K && in_frame(qx, qy, qz)) {  // QueryNearestWithCurFrame (:254-275, 339-345)
+            const int cnt = fs.n_obs(0, s) > K ? K : 0;      // kd_tree_two.h:119-124
             if (lane < K) {
                 const size_t irow = ((size_t)s * N + i) * K + lane;  // frame 0
                 knn_d2[orow + lane] = fb.knn_d2[irow];
@@ -236,30 +262,31 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
             continue;
         }
         // QueryNearestThreadWorker over mVecQueryVector (:276-321) + sort (:371): candidate c = f * K + j
-        unsigned long long key[kMaxCandPerLane];
         const int ncand = F * K;
+        int cnt = 0;
+        if constexpr (CPL > 0) {
+        unsigned long long key[CPL];
 #pragma unroll
-        for (int r = 0; r < kMaxCandPerLane; ++r) {
+        for (int r = 0; r < CPL; ++r) {
             const int c = lane + 64 * r;
             key[r] = ~0ull;
             if (c < ncand) {
                 const int f = c / K, jj = c - f * K;
-                if (fs.size_obs[f][s] > K) {  // k' = min(K, size_f) results exist iff size_f > k'
+                if (fs.n_obs(f, s) > K) {  // k' = min(K, size_f) results exist iff size_f > k'
                     const double d = fb.knn_d2[(((size_t)f * S + s) * N + i) * K + jj];
                     if (d < DBL_MAX) key[r] = (unsigned long long)__double_as_longlong(d);  // d >= 0: order-preserving
                 }
             }
         }
-        int cnt = 0;
         for (int m = 0; m < K; ++m) {  // K rounds of "smallest remaining (distance, candidate id)"
             unsigned long long loc = ~0ull;
 #pragma unroll
-            for (int r = 0; r < kMaxCandPerLane; ++r) loc = key[r] < loc ? key[r] : loc;
+            for (int r = 0; r < CPL; ++r) loc = key[r] < loc ? key[r] : loc;
             const unsigned long long best = wave_min_u64(loc);
             if (best == ~0ull) break;
             int myc = 0x7fffffff;  // lowest candidate id holding `best`
 #pragma unroll
-            for (int r = kMaxCandPerLane - 1; r >= 0; --r)
+            for (int r = CPL - 1; r >= 0; --r)
                 if (key[r] == best) myc = lane + 64 * r;
             int win = myc;
 #pragma unroll
@@ -270,10 +297,45 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
                 knn_d2[orow + m] = __longlong_as_double((long long)best);
                 for (int c = 0; c < 3; ++c) knn_pts[(orow + m) * 3 + c] = fb.knn_pts[irow * 3 + c];
 #pragma unroll
-                for (int r = 0; r < kMaxCandPerLane; ++r)
+                for (int r = 0; r < CPL; ++r)
                     if (lane + 64 * r == win) key[r] = ~0ull;
             }
             ++cnt;
+        }
+        } else {
+        // wide map: the same K rounds, the candidates re-read from the raw rows every round (L2-resident: F K doubles per
+        // reference point), a lane's taken candidates remembered as bits (candidate lane + 64 r = bit r; F K <= 64 x 128)
+        unsigned long long taken0 = 0ull, taken1 = 0ull;
+        for (int m = 0; m < K; ++m) {
+            unsigned long long loc = ~0ull;
+            int myc = 0x7fffffff;
+            for (int r = 0; lane + 64 * r < ncand; ++r) {
+                if ((r < 64 ? taken0 >> r : taken1 >> (r - 64)) & 1ull) continue;
+                const int c = lane + 64 * r;
+                const int f = c / K, jj = c - f * K;
+                if (fs.n_obs(f, s) > K) {
+                    const double d = fb.knn_d2[(((size_t)f * S + s) * N + i) * K + jj];
+                    if (d < DBL_MAX) {
+                        const unsigned long long k64 = (unsigned long long)__double_as_longlong(d);
+                        if (k64 < loc) { loc = k64; myc = c; }   // (ascending r: the lowest candidate id among equal keys of this lane)
+                    }
+                }
+            }
+            const unsigned long long best = wave_min_u64(loc);
+            if (best == ~0ull) break;
+            int win = loc == best ? myc : 0x7fffffff;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) win = min(win, __shfl_xor(win, off));
+            if (loc == best && myc == win) {
+                const int f = win / K, jj = win - f * K;
+                const size_t irow = (((size_t)f * S + s) * N + i) * K + jj;
+                knn_d2[orow + m] = __longlong_as_double((long long)best);
+                for (int c = 0; c < 3; ++c) knn_pts[(orow + m) * 3 + c] = fb.knn_pts[irow * 3 + c];
+                const int r = win >> 6;
+                if (r < 64) taken0 |= 1ull << r; else taken1 |= 1ull << (r - 64);
+            }
+            ++cnt;
+        }
         }
         if (lane == 0) cntq[i] = cnt;
     }
@@ -321,48 +383,45 @@ __global__ void step_frames_begin_kernel(int S, int *__restrict__ done, int *__r
 
 }  // namespace
 
-extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edge, int n_frames, const double *d_Twc,
-                                     const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm,
-                                     const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
-                                     double *d_x0array, int *d_flags, void *stream_) {
-    if (!obstacle || !edge || !mpc || !prm || !d_state_quad || !d_pos_x || !d_ref_path || !d_u || !d_flags || n_frames < 1)
-        return AMK_ERR_INVALID_ARG;
-    if (d_Twc && !cam) return AMK_ERR_INVALID_ARG;
-    if (n_frames > AMK_MAX_FRAMES) return AMK_ERR_UNSUPPORTED;
-    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
-    const int S = mpc->S, N = mpc->N, K = mpc->K, F = n_frames;
-    FrameSet fs;
-    fs.n = F;
-    for (int f = 0; f < F; ++f) {
-        if (!obstacle[f] || !edge[f] || obstacle[f]->n_scenes != S || edge[f]->n_scenes != S) return AMK_ERR_INVALID_ARG;
-        if (obstacle[f]->mode != 0 || edge[f]->mode != 0) return AMK_ERR_UNSUPPORTED;  // bucketed indices only
-        fs.obs[f] = GridPtrs{obstacle[f]->gpt.p, obstacle[f]->cell_start.p, obstacle[f]->gparams.p, obstacle[f]->cap, obstacle[f]->ntiles};
-        fs.edge[f] = GridPtrs{edge[f]->gpt.p, edge[f]->cell_start.p, edge[f]->gparams.p, edge[f]->cap, edge[f]->ntiles};
-        fs.size_obs[f] = obstacle[f]->size.p;
-        fs.size_edge[f] = edge[f]->size.p;
+// tests only (tests/test_kfmap_gpu.py): take the wide-map merge (candidates re-read every round) whatever the map's size
+static int g_force_wide = 0;
+extern "C" void amk__frames_force_wide(int on) { g_force_wide = on; }
+
+// the rounds of the step over a frame set (plain handles or the keyframe map's pool), shared by the two entry points below
+static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const *edge, const double *d_Twc,
+                      const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm, const double *d_state_quad,
+                      const double *d_pos_x, double *d_ref_path, double *d_u, double *d_x0array, int *d_flags, hipStream_t stream) {
+    const int N = mpc->N, K = mpc->K, F = fs.n;
+    {
+        const size_t S = mpc->S;
+        if (!mpc->done.p) {
+            AMK_HIP(mpc->knn_pts.alloc(S * N * K * 3));
+            AMK_HIP(mpc->knn_d2.alloc(S * N * K));
+            AMK_HIP(mpc->edge_pt.alloc(S * 3));
+            AMK_HIP(mpc->edge_d2.alloc(S));
+            AMK_HIP(mpc->ref_states.alloc(S * mpc->nref));
+            AMK_HIP(mpc->done.alloc(S));
+        }
     }
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!mpc->done.p) {
-        AMK_HIP(mpc->knn_pts.alloc((size_t)S * N * K * 3));
-        AMK_HIP(mpc->knn_d2.alloc((size_t)S * N * K));
-        AMK_HIP(mpc->edge_pt.alloc((size_t)S * 3));
-        AMK_HIP(mpc->edge_d2.alloc(S));
-        AMK_HIP(mpc->ref_states.alloc((size_t)S * mpc->nref));
-        AMK_HIP(mpc->done.alloc(S));
+    const int Sall = mpc->S;
+    if (mpc->mf_frames < F) {   // sized ONCE for the largest map of its kind (AMK_MAX_FRAMES handles; a keyframe map: its own
+        // 1 + max_frame_count): a map that gains a keyframe between two calls must not free a buffer an earlier call's kernels
+        // may still be reading
+        const size_t FM = F > AMK_MAX_FRAMES ? F : AMK_MAX_FRAMES;
+        if (mpc->mf_frames > 0) AMK_HIP(hipDeviceSynchronize());   // (growing: an explicit change of the map's capacity)
+        AMK_HIP(mpc->mf_knn_pts.alloc(FM * Sall * N * K * 3));
+        AMK_HIP(mpc->mf_knn_d2.alloc(FM * Sall * N * K));
+        AMK_HIP(mpc->mf_edge_pt.alloc(FM * Sall * 3));
+        AMK_HIP(mpc->mf_edge_d2.alloc(FM * Sall));
+        mpc->mf_frames = (int)FM;
     }
-    if (mpc->mf_frames < F) {   // sized ONCE for the largest map (AMK_MAX_FRAMES): a map that gains a keyframe between two calls
-        const size_t FM = AMK_MAX_FRAMES;   // must not free a buffer an earlier call's kernels may still be reading
-        AMK_HIP(mpc->mf_knn_pts.alloc(FM * S * N * K * 3));
-        AMK_HIP(mpc->mf_knn_d2.alloc(FM * S * N * K));
-        AMK_HIP(mpc->mf_edge_pt.alloc(FM * S * 3));
-        AMK_HIP(mpc->mf_edge_d2.alloc(FM * S));
-        mpc->mf_frames = AMK_MAX_FRAMES;
-    }
+    const int S = mpc->launch_scenes();   // (amk_pipeline: a gang that is not full runs its leading scenes only; the per-frame
+                                          // rows of this call are laid out with this S, the frame map keeps the handle's: fs.S)
     const FrameBufs fb{mpc->mf_knn_pts.p, mpc->mf_knn_d2.p, mpc->mf_edge_pt.p, mpc->mf_edge_d2.p};
     // frames in AMK_TIES_NANOFLANN mode (their reference-shaped trees were built by amk_kd_build / amk_kd_push_keyframe)
     bool any_exact = false;
     FrameExact *fe_dev = nullptr;
-    {
+    if (!fs.fmap) {
         std::vector<char> cur(sizeof(FrameExact), 0);
         FrameExact *h = reinterpret_cast<FrameExact *>(cur.data());
         for (int f = 0; f < F; ++f) {
@@ -390,6 +449,9 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
     }
     amk_frame_camera c{};
     if (cam) c = *cam;
+    const bool wide = F * K > 64 * kMaxCandPerLane || (g_force_wide && !any_exact);   // (only a keyframe map can be: F <= AMK_MAX_MAP_FRAMES)
+    auto merge_kernel = wide ? step_merge_plan_pack_kernel<false, kMaxCandPerLaneMap>
+                             : (any_exact ? step_merge_plan_pack_kernel<true> : step_merge_plan_pack_kernel<false>);
     hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
     const int S8 = (S + 7) / 8 * 8;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
@@ -398,8 +460,7 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
         if (any_exact)
             hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 3) / 4, F), dim3(256), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);
-        hipLaunchKernelGGL(any_exact ? step_merge_plan_pack_kernel<true> : step_merge_plan_pack_kernel<false>, dim3(S),
-                           dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
+        hipLaunchKernelGGL(merge_kernel, dim3(S), dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
                            iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
         AMK_HIP(hipGetLastError());
@@ -408,3 +469,52 @@ extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edg
     }
     return AMK_OK;
 }
+
+extern "C" int amk_step_batch_frames(amk_kd *const *obstacle, amk_kd *const *edge, int n_frames, const double *d_Twc,
+                                     const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm,
+                                     const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u,
+                                     double *d_x0array, int *d_flags, void *stream_) {
+    if (!obstacle || !edge || !mpc || !prm || !d_state_quad || !d_pos_x || !d_ref_path || !d_u || !d_flags || n_frames < 1)
+        return AMK_ERR_INVALID_ARG;
+    if (d_Twc && !cam) return AMK_ERR_INVALID_ARG;
+    if (n_frames > AMK_MAX_FRAMES) return AMK_ERR_UNSUPPORTED;
+    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
+    const int S = mpc->S, F = n_frames;
+    FrameSet fs{};
+    fs.n = F;
+    fs.fmap = nullptr;
+    fs.S = S;
+    for (int f = 0; f < F; ++f) {
+        if (!obstacle[f] || !edge[f] || obstacle[f]->n_scenes != S || edge[f]->n_scenes != S) return AMK_ERR_INVALID_ARG;
+        if (obstacle[f]->mode != 0 || edge[f]->mode != 0) return AMK_ERR_UNSUPPORTED;  // bucketed indices only
+        fs.obs[f] = GridPtrs{obstacle[f]->gpt.p, obstacle[f]->cell_start.p, obstacle[f]->gparams.p, obstacle[f]->cap, obstacle[f]->ntiles};
+        fs.edge[f] = GridPtrs{edge[f]->gpt.p, edge[f]->cell_start.p, edge[f]->gparams.p, edge[f]->cap, edge[f]->ntiles};
+        fs.size_obs[f] = obstacle[f]->size.p;
+        fs.size_edge[f] = edge[f]->size.p;
+    }
+    return run_frames(fs, obstacle, edge, d_Twc, cam, mpc, prm, d_state_quad, d_pos_x, d_ref_path, d_u, d_x0array, d_flags,
+                      (hipStream_t)stream_);
+}
+
+namespace amk {
+// The same step over a keyframe map (kfmap.hip): every frame of every scene in the two pool handles, frame f of scene s = pool
+// scene d_fmap[f * S + s] (< 0: absent); n_frames = 1 + max_frame_count of the map, <= AMK_MAX_MAP_FRAMES.
+int step_batch_map(amk_kd *obs_pool, amk_kd *edge_pool, int n_frames, const int *d_fmap, const double *d_Twc,
+                   const amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm, const double *d_state_quad,
+                   const double *d_pos_x, double *d_ref_path, double *d_u, double *d_x0array, int *d_flags, hipStream_t stream) {
+    if (!obs_pool || !edge_pool || !d_fmap || !mpc || !prm || !d_state_quad || !d_pos_x || !d_ref_path || !d_u || !d_flags || n_frames < 1)
+        return AMK_ERR_INVALID_ARG;
+    if (d_Twc && !cam) return AMK_ERR_INVALID_ARG;
+    if (n_frames > AMK_MAX_MAP_FRAMES || n_frames * mpc->K > 64 * 128) return AMK_ERR_UNSUPPORTED;
+    if (prm->mpc_max_iter < 1 || prm->mpc_max_iter > AMK_MAX_OUTER_ITER || mpc->K < 1) return AMK_ERR_INVALID_ARG;
+    FrameSet fs{};
+    fs.n = n_frames;
+    fs.fmap = d_fmap;
+    fs.S = mpc->S;
+    fs.obs[0] = GridPtrs{obs_pool->gpt.p, obs_pool->cell_start.p, obs_pool->gparams.p, obs_pool->cap, obs_pool->ntiles};
+    fs.edge[0] = GridPtrs{edge_pool->gpt.p, edge_pool->cell_start.p, edge_pool->gparams.p, edge_pool->cap, edge_pool->ntiles};
+    fs.size_obs[0] = obs_pool->size.p;
+    fs.size_edge[0] = edge_pool->size.p;
+    return run_frames(fs, nullptr, nullptr, d_Twc, cam, mpc, prm, d_state_quad, d_pos_x, d_ref_path, d_u, d_x0array, d_flags, stream);
+}
+}  // namespace amk

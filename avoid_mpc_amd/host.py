@@ -235,12 +235,65 @@ class MpcBatch:
         capi.check(self.lib.amk_mpc_reset_warm_start(self.h, capi.stream_ptr(stream)), "reset_warm_start")
 
 
+class KfMap:
+    """amk_kfmap: FrameKDMap's keyframe list for S scenes on the device (FrameKDMap.cpp:29-74,233-252,428-488)."""
+
+    def __init__(self, n_scenes, max_points, max_edge_points, max_frame_count, th_dist, th_count, depth_min, Tbc):
+        self.lib = capi.load()
+        p = capi.KfmapParams(int(max_frame_count), int(th_count), float(th_dist), float(depth_min),
+                             (C.c_double * 16)(*[float(v) for v in np.asarray(Tbc, np.float64).reshape(-1)]))
+        h = C.c_void_p()
+        capi.check(self.lib.amk_kfmap_create(int(n_scenes), int(max_points), int(max_edge_points), C.byref(p), C.byref(h)), "amk_kfmap_create")
+        self.h, self.S, self.F = h, int(n_scenes), int(max_frame_count) + 1
+        self.max_points, self.max_edge_points = int(max_points), int(max_edge_points)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.amk_kfmap_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def add_vertex(self, clouds, edges, Twc, counts=None, edge_counts=None, first_scene=0, stream=None):
+        """clouds [n, max_points, 3|4] f32, edges likewise, Twc [n, 4, 4] f64 = Twb * Tbc of the frame; counts int32 [n] or None."""
+        assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and Twc.dtype == torch.float64
+        assert clouds.shape[1] == self.max_points and edges.shape[1] == self.max_edge_points and clouds.shape[2] == edges.shape[2]
+        capi.check(self.lib.amk_kfmap_add_vertex(self.h, int(first_scene), int(clouds.shape[0]), capi.dptr(clouds), capi.dptr(counts),
+                                                 capi.dptr(edges), capi.dptr(edge_counts), int(clouds.shape[2]), capi.dptr(Twc),
+                                                 capi.stream_ptr(stream)), "amk_kfmap_add_vertex")
+
+    def update(self, stream=None):
+        capi.check(self.lib.amk_kfmap_update(self.h, capi.stream_ptr(stream)), "amk_kfmap_update")
+
+    def step(self, mpc, prm, state_quad, pos_x, ref_path, cam=None, stream=None, out=None):
+        """amk_kfmap_step; ref_path is refilled in place.  -> dict(u, x0array, flags)"""
+        S, N = self.S, mpc.N
+        dev = _dev()
+        if out is None:
+            out = dict(u=torch.empty((S, 4), dtype=torch.float64, device=dev), x0array=torch.empty((S, N, 14), dtype=torch.float64, device=dev),
+                       flags=torch.empty((S, 4), dtype=torch.int32, device=dev))
+        sp = capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0)
+        capi.check(self.lib.amk_kfmap_step(self.h, C.byref(cam) if cam is not None else None, mpc.h, C.byref(sp), capi.dptr(state_quad),
+                                           capi.dptr(pos_x), capi.dptr(ref_path), capi.dptr(out["u"]), capi.dptr(out["x0array"]),
+                                           capi.dptr(out["flags"]), capi.stream_ptr(stream)), "amk_kfmap_step")
+        return out
+
+    def state(self):
+        """-> dict(n_keyframes [S], n_query_frames [S], last_outliers [S], frame_sizes [S, F]) (synchronises)"""
+        nk = np.zeros(self.S, np.int32); nq = np.zeros(self.S, np.int32); out = np.zeros(self.S, np.int32)
+        sz = np.zeros((self.S, self.F), np.int32)
+        capi.check(self.lib.amk_kfmap_state_host(self.h, nk.ctypes.data_as(C.c_void_p), nq.ctypes.data_as(C.c_void_p),
+                                                 out.ctypes.data_as(C.c_void_p), sz.ctypes.data_as(C.c_void_p)), "amk_kfmap_state_host")
+        return dict(n_keyframes=nk, n_query_frames=nq, last_outliers=out, frame_sizes=sz)
+
+
 class Pipeline:
     """amk_pipeline: n_slots launches in flight, each slot = {HIP stream, obstacle + edge index, MPC batch, outputs};
     gang = frames (of n_scenes scenes) that share one set of launches -- the slot's handles then hold gang * n_scenes scenes."""
 
     def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0, farest_point=500.0,
-                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None, task="forward"):
+                 slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None, task="forward", keyframes=None):
+        """keyframes: dict(max_frame_count, th_dist, th_count, depth_min) -> every slot keeps a keyframe map (amk_kfmap)."""
         self.lib = capi.load()
         task = capi.TaskParams(float(prm.decay), float(iter_time), float(farest_point), float(prm.height), float(slow_down_kp),
                                float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)),
@@ -248,7 +301,9 @@ class Pipeline:
         cfg = capi.PipelineConfig(int(n_slots), int(n_scenes), int(max_points), int(max_edge_points), float(prm.T), float(prm.dt),
                                   int(prm.K), int(queue_depth), int(gang),
                                   capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task,
-                                  depth if depth is not None else capi.DepthParams())
+                                  depth if depth is not None else capi.DepthParams(),
+                                  capi.KfmapParams(int(keyframes["max_frame_count"]), int(keyframes["th_count"]), float(keyframes["th_dist"]),
+                                                   float(keyframes["depth_min"])) if keyframes else capi.KfmapParams())
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
@@ -261,6 +316,17 @@ class Pipeline:
                      KdBatch(hs, max_edge_points, handle=self.lib.amk_pipeline_kd(h, i, 1))) for i in range(n_slots)]
         for m in self._mpc:
             m.configure(prm)
+
+    def kfmap_state(self, slot):
+        """State of the slot's keyframe map (amk_kfmap_state_host): dict(n_keyframes, n_query_frames, last_outliers, frame_sizes)."""
+        h = self.lib.amk_pipeline_kfmap(self.h, int(slot))
+        assert h, "the pipeline was created without keyframes"
+        S = self.S * self.gang
+        F = self.lib.amk_kfmap_frames(h)
+        nk = np.zeros(S, np.int32); nq = np.zeros(S, np.int32); out = np.zeros(S, np.int32); sz = np.zeros((S, F), np.int32)
+        capi.check(self.lib.amk_kfmap_state_host(h, nk.ctypes.data_as(C.c_void_p), nq.ctypes.data_as(C.c_void_p),
+                                                 out.ctypes.data_as(C.c_void_p), sz.ctypes.data_as(C.c_void_p)), "amk_kfmap_state_host")
+        return dict(n_keyframes=nk, n_query_frames=nq, last_outliers=out, frame_sizes=sz)
 
     def mpc(self, slot):
         return self._mpc[slot]
@@ -296,12 +362,12 @@ class Pipeline:
             dinfo = (depth.data_ptr(), kind, int(depth.shape[1]), int(depth.shape[2]), 0, Twb.data_ptr())
         else:
             assert clouds.dtype == torch.float32 and edges.dtype == torch.float32 and clouds.shape[2] == edges.shape[2]
-        kinfo = (None, None, 0, 0, None, None)
+        self._kf_keep = (None, None, cam)
+        kinfo = (None, None, 0, 0, opt(Twc_cur), C.cast(C.pointer(cam), C.c_void_p) if cam is not None else None)
         if keyframes:   # [(KdBatch obstacle, KdBatch edge), ...]: the multi-frame map [this frame, keyframes ...] (gang 1 only)
             ko = (C.c_void_p * len(keyframes))(*[k[0].h for k in keyframes]); ke = (C.c_void_p * len(keyframes))(*[k[1].h for k in keyframes])
             self._kf_keep = (ko, ke, cam)
-            kinfo = (C.cast(ko, C.c_void_p), C.cast(ke, C.c_void_p), len(keyframes), 0, opt(Twc_cur),
-                     C.cast(C.pointer(cam), C.c_void_p) if cam is not None else None)
+            kinfo = (C.cast(ko, C.c_void_p), C.cast(ke, C.c_void_p), len(keyframes), 0) + kinfo[4:]
         ev_ptr = None
         if order_after_current_stream:
             ev = torch.cuda.Event()
@@ -378,6 +444,18 @@ class Shard:
     def max(self, values, stream=None):
         capi.check(self.lib.amk_shard_max(self.h, capi.dptr(values), int(values.numel()), capi.stream_ptr(stream)), "amk_shard_max")
         return values
+
+    def wait(self, stream=None, timeout_s=120.0):
+        """amk_shard_wait: the watchdog of the exchange step -- returns capi.AMK_OK or capi.AMK_ERR_TIMEOUT (a hung collective)."""
+        return self.lib.amk_shard_wait(self.h, capi.stream_ptr(stream), float(timeout_s))
+
+    @staticmethod
+    def rccl_info():
+        """-> dict(path, version, was_loaded) of the RCCL the library bound, or None when no librccl can be loaded."""
+        buf = C.create_string_buffer(1024); ver = C.c_int(0); was = C.c_int(0)
+        if capi.load().amk_shard_rccl_info(buf, 1024, C.byref(ver), C.byref(was)) != capi.AMK_OK:
+            return None
+        return dict(path=buf.value.decode(), version=ver.value, loaded_before_amk=bool(was.value))
 
     def close(self):
         if getattr(self, "h", None):

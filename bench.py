@@ -228,6 +228,37 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def rccl_report(torch):
+    """Which RCCL the process carries (make the first multi-GPU run debuggable): the file amk_shard bound its
+    collectives from (dladdr of ncclAllGather; the copy already in the process when there is one), its version, PyTorch's RCCL
+    version, and every librccl the process has mapped -- more than one distinct file means two RCCL instances in one process."""
+    from avoid_mpc_amd.host import Shard
+    info = Shard.rccl_info()
+    try:
+        mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+    except OSError:
+        mapped = None
+    try:
+        tv = torch.cuda.nccl.version()
+        tv = ".".join(str(v) for v in tv) if isinstance(tv, tuple) else str(tv)
+    except Exception as e:   # (a CPU-only dry run)
+        tv = f"unavailable ({type(e).__name__})"
+    return {"amk_shard_bound": info, "torch_nccl_version": tv, "librccl_files_mapped": mapped,
+            "single_rccl_instance": None if mapped is None else len(mapped) <= 1}
+
+
+def write_rank_file(rank, payload):
+    """One small JSON file per rank, written BEFORE the exchange step: if a collective hangs, what every rank measured and which
+    RCCL it bound is still on disk (gpurun_out/bench_ranks/rank<r>.json; AMK_BENCH_RANK_DIR overrides the directory)."""
+    d = os.environ.get("AMK_BENCH_RANK_DIR", os.path.join(ROOT, "gpurun_out", "bench_ranks"))
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"rank{rank}.json"), "w") as f:
+            json.dump(payload, f)
+    except OSError as e:
+        print(f"bench.py: rank {rank}: cannot write the per-rank file: {e}", file=sys.stderr)
+
+
 def dry_run(args):
     """The launch path without a GPU: rendezvous over gloo, the library's own partition (amk_shard_scene_range /
     amk_shard_padded_count), an all-gather shaped like the sweep's, max-over-ranks of a wall time, one JSON line from rank 0."""
@@ -247,6 +278,9 @@ def dry_run(args):
     local = torch.full((args.steps, padded, 4), float(rank), dtype=torch.float64)
     local[:, :, 0] = torch.arange(first.value, first.value + padded, dtype=torch.float64)[None, :]
     out = [torch.empty_like(local) for _ in range(world)]
+    rccl = rccl_report(torch)
+    write_rank_file(rank, {"rank": rank, "world": world, "device": "cpu (dry run)", "first_scene": first.value, "scenes": count.value,
+                           "rccl": rccl, "stage": "before the gather"})
     dist.all_gather(out, local)
     dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
     dist.all_reduce(dt, op=dist.ReduceOp.MAX)
@@ -256,7 +290,8 @@ def dry_run(args):
     if rank == 0:
         print(json.dumps({"metric": "dry run (launch path only)", "value": None, "unit": "MPC steps/s", "n_gpus": world,
                           "steps": args.steps, "warmup": args.warmup, "dry_run": True, "ranks_seen": world, "gather_ok": bool(ok),
-                          "scenes_per_rank": count.value, "padded_scenes_per_rank": padded, "max_over_ranks_s": float(dt.item())}), flush=True)
+                          "scenes_per_rank": count.value, "padded_scenes_per_rank": padded, "max_over_ranks_s": float(dt.item()),
+                          "rccl": rccl, "rank_files": os.environ.get("AMK_BENCH_RANK_DIR", os.path.join(ROOT, "gpurun_out", "bench_ranks"))}), flush=True)
     dist.destroy_process_group()
     return 0
 
@@ -375,7 +410,7 @@ def flight_main(args):
         parity = {"flights_vs_cpu_oracle": {"flights": nf, "periods": P, "separated": cmp["separated"],
                                             "dpos_max_while_flags_agree_m": cmp["dpos_max_while_together"],
                                             "dpos_final_max_of_separated_m": cmp["dpos_final_max_separated"],
-                                            "ok": bool(cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= max(1, nf // 8)),
+                                            "ok": bool(cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= 1),   # census: 1.2 % of flights separate over 150 periods (was nf // 8)
                                             "cpu_oracle_steps_per_s_all_cores": round(nf * P / t_cpu, 1), "cores": _flight.usable_cores(),
                                             "note": "same frames, same start; a flight separates when its flags differ in some period "
                                                     "(another branch at a rounding-level tie); tests/test_flight_gpu.py is the "
@@ -486,6 +521,8 @@ def main():
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = capi.load()
+    # SURVEY 8(d) / BASELINE.md 3: the achievable HBM rate beside the vendor peak, before the pipeline's buffers exist
+    hbm_measured = measured_hbm_peak(torch, lib) if rank == 0 and not args.dry_run else None
     collective = dist is not None   # the exchange step runs whenever a process group exists (RCCL also at world 1)
 
     prm = synth.MpcParams(T=args.T, K=args.K)
@@ -535,13 +572,30 @@ def main():
     max_rows = max(args.steps, args.steady_steps if args.steps < args.steady_steps else 0, nframes, args.warmup, 64)
     u_sweep = torch.zeros((max_rows, S, 4), dtype=torch.float64, device=dev)   # the sweep's controls, one row per step
     sh = None
+    rccl_info = None
+
+    def gather_or_die(what, timeout_s=float(os.environ.get("AMK_BENCH_GATHER_TIMEOUT_S", "180"))):
+        """amk_shard_wait behind every exchange step: a hung collective ends the rank with a message instead of the whole run
+        with the launcher's timeout."""
+        rc = sh.wait(timeout_s=timeout_s)
+        if rc == capi.AMK_OK:
+            return
+        msg = (f"bench.py: rank {rank}/{world}: {what} did not finish within {timeout_s:.0f} s (amk_shard_wait -> {rc}); RCCL bound: "
+               f"{rccl_info}; re-run with NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL")
+        print(msg, file=sys.stderr, flush=True)
+        write_rank_file(rank, {"rank": rank, "world": world, "error": msg})
+        os._exit(3)
+
     if collective:   # RCCL through the library's own binding (amk_shard_*); torch.distributed only carries the 128-byte id
         ids = [Shard.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         sh = Shard(rank, world, ids[0])
+        rccl_info = rccl_report(torch)
+        write_rank_file(rank, {"rank": rank, "world": world, "device": torch.cuda.get_device_name(dev), "local_rank": local_rank,
+                               "rccl": rccl_info, "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "stage": "communicator created"})
         warm = torch.zeros((world, 8), dtype=torch.float64, device=dev)
         sh.gather(warm[rank].clone(), warm)   # RCCL sets a communicator's channels up at its first collective: not in the clock
-        torch.cuda.synchronize()
+        gather_or_die("the communicator's first collective")
     step_no = [0]
     copy_stream = torch.cuda.Stream(device=dev) if args.inputs == "host" else None
     # diagnostics only (tools/experiments): AMK_BENCH_SKIP=build|step leaves that half out of every step -- the printed
@@ -597,8 +651,14 @@ def main():
             pl.drain()
         t_drain = time.perf_counter() - t0
         if collective:   # the ONE exchange step of the sweep: every rank's controls to every rank (ncclAllGather)
+            write_rank_file(rank, {"rank": rank, "world": world, "device": torch.cuda.get_device_name(dev), "steps": steps,
+                                   "local_steps_per_s": S * steps / t_drain, "drain_s": t_drain, "rccl": rccl_info,
+                                   "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"), "stage": "before the gather"})
+            tg = time.perf_counter()
             sh.gather(u_sweep[:steps], u_gather(steps))
+            gather_or_die("the sweep's gather")
             torch.cuda.synchronize()
+            phases["gather_ms_this_rank"] = 1e3 * (time.perf_counter() - tg)
         t_gather = time.perf_counter() - t0
         barrier()
         t_all = time.perf_counter() - t0
@@ -618,6 +678,7 @@ def main():
             return float(seconds)
         t = torch.tensor([seconds], dtype=torch.float64, device=dev)
         sh.max(t)
+        gather_or_die("the max over ranks")
         torch.cuda.synchronize()
         return float(t.item())
 
@@ -738,10 +799,12 @@ def main():
         valu_frac_timed = (solves_per_s * valu_per_solve * 4 / (N_CU * N_SIMD * CLOCK_GHZ * 1e9)) if valu_per_solve else None
         hbm = lambda nbytes, us: None if not us else round(nbytes / (us * 1e-6) / 1e9, 2)
         frac = lambda gbs: None if gbs is None else round(gbs / HBM_PEAK_GBS, 6)
+        fracm = lambda gbs: None if gbs is None or not hbm_measured else round(gbs / hbm_measured, 6)   # against the measured copy rate
         roof_solve_hbm = {
             "bound": "hbm", "kernel": f"mpc_solve_kernel<{N}>", "alg_bytes_per_launch": alg_launch,
             "avg_launch_us": solve_us, "achieved": hbm(alg_launch, solve_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": frac(hbm(alg_launch, solve_us)), "traffic": traffic, "traffic_source": traffic_src,
+            "frac": frac(hbm(alg_launch, solve_us)), "frac_of_measured_copy": fracm(hbm(alg_launch, solve_us)),
+            "traffic": traffic, "traffic_source": traffic_src,
             "rocprof_avg_us_same_command": rocprof_us("kt1", f"mpc_solve_kernel<{N}>"),
             "in_flight_submit_to_complete_ms": round(inflight_solve_ms, 4), "in_flight_launches": cnt[5],
             "in_flight_rocprof_avg_us": rocprof_us("kt20", f"mpc_solve_kernel<{N}>"),
@@ -777,7 +840,10 @@ def main():
                                        else "single GPU, no process group"),
                        "orchestration": f"amk_pipeline_* (C ABI): submit() per step, drain() at the end; {nslots} slots x gang {gang} "
                                         f"(= {gang} consecutive steps share one set of launches of {S * gang} scenes)",
-                       "queue_depth_per_slot": qdepth},
+                       "queue_depth_per_slot": qdepth,
+                       "rccl": rccl_info if collective else "no process group (single GPU, plain run): RCCL not used",
+                       "multi_gpu_measured": "no N > 1 line has been measured by this project (no multi-GPU node was available to it "
+                                             "in any round); per-rank files: gpurun_out/bench_ranks/"},
             "roofline": {"bound": "valu-issue (dependent fp64 / LDS latency at 2 waves per SIMD; neither HBM nor MFMA)",
                          "kernel": f"mpc_solve_kernel<{N}>",
                          "achieved": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),
@@ -799,9 +865,11 @@ def main():
             "roofline_kd_build": {"bound": "hbm", "kernel": "kd_build_kernel (one launch: obstacle + edge index of every scene)",
                                   "alg_bytes_per_launch": build_alg, "avg_launch_us": build_us,
                                   "achieved": hbm(build_alg, build_us), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": frac(hbm(build_alg, build_us)), "traffic": build_traffic,
+                                  "frac": frac(hbm(build_alg, build_us)), "frac_of_measured_copy": fracm(hbm(build_alg, build_us)),
+                                  "traffic": build_traffic,
                                   "alg_bytes_per_launch_survey_8d": 12 * S * gang * (n + ne),
                                   "frac_survey_8d": frac(hbm(12 * S * gang * (n + ne), build_us)),
+                                  "frac_survey_8d_of_measured_copy": fracm(hbm(12 * S * gang * (n + ne), build_us)),
                                   "rocprof_avg_us_same_command": rocprof_us("kt1", "kd_build_kernel"),
                                   "in_flight_submit_to_complete_ms": round(inflight_build_ms, 4), "in_flight_launches": cnt[7],
                                   "in_flight_rocprof_avg_us": rocprof_us("kt20", "kd_build_kernel"),
@@ -813,7 +881,13 @@ def main():
                                           "instead of a gather through a permutation (DESIGN.md section 4)"},
             "roofline_whole_step": {"alg_bytes_per_scene_step": step_bytes,
                                     "achieved": round(value * step_bytes / 1e9, 2), "unit": "GB/s",
-                                    "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5)},
+                                    "frac": round(value * step_bytes / 1e9 / HBM_PEAK_GBS, 5),
+                                    "frac_of_measured_copy": fracm(value * step_bytes / 1e9)},
+            "hbm_peak_vendor_gbs": HBM_PEAK_GBS,
+            "hbm_peak_measured_gbs": None if not hbm_measured else round(hbm_measured, 1),
+            "hbm_peak_measured_how": "float4 device copy of 1 GiB (amk__hbm_copy_probe, csrc/probe.hip): bytes read + bytes written "
+                                     "over the copy's duration, 10 repetitions, HIP events; every HBM fraction of this line is given "
+                                     "against the vendor peak (frac) and against this figure (frac_of_measured_copy)",
             "kernels_single_stream": lone,
             "parity": parity,
             "cpu_baseline": cpu,

@@ -31,7 +31,8 @@ typedef enum amk_status {
     AMK_ERR_INVALID_ARG = 1, /* NULL handle, k < 0, size mismatch ...                           */
     AMK_ERR_HIP = 2,         /* a HIP runtime call failed; see amk_last_hip_error()              */
     AMK_ERR_NO_DEVICE = 3,   /* no gfx950 device visible: there is NO CPU fallback               */
-    AMK_ERR_UNSUPPORTED = 4  /* e.g. k > AMK_MAX_K, N > AMK_MAX_HORIZON                          */
+    AMK_ERR_UNSUPPORTED = 4, /* e.g. k > AMK_MAX_K, N > AMK_MAX_HORIZON                          */
+    AMK_ERR_TIMEOUT = 5      /* amk_shard_wait: a collective did not finish in time               */
 } amk_status;
 
 #define AMK_MAX_K 64        /* neighbours per query (reference uses 1, 3, 8, <=10)               */
@@ -281,6 +282,7 @@ int amk_step_batch(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc, const amk_step_
  *                  size of the down-scaled image (mParamWidth / mParamHeight, :106-107)
  * Remaining arguments as amk_step_batch.  With n_frames = 1 and d_Twc = NULL the results equal amk_step_batch's.            */
 #define AMK_MAX_FRAMES 16
+#define AMK_MAX_MAP_FRAMES 101   /* frames of a keyframe map (amk_kfmap): current + max_frame_count <= 100 (mpc_parameters.yaml:73) */
 typedef struct amk_frame_camera {
     double fx, fy, cx, cy;
     double depth_max;
@@ -343,6 +345,16 @@ typedef struct amk_task_params {
 #define AMK_PIPELINE_DEFAULT_DEPTH 3
 #define AMK_PIPELINE_MAX_DEPTH 64
 #define AMK_PIPELINE_MAX_GANG 8
+/* FrameKDMap's keyframe parameters (the batched map itself: amk_kfmap_*, below) */
+typedef struct amk_kfmap amk_kfmap;
+typedef struct amk_kfmap_params {
+    int max_frame_count;       /* mParamMaxFrameCount, mpc_parameters.yaml:73; 1 ... AMK_MAX_MAP_FRAMES - 1; 0 (pipeline      */
+                               /* config only): no keyframe map, mVecQueryVector = [current]                                  */
+    int keyframe_th_count;     /* mParamKeyframeCountTh, :72 (>= 1)                                                           */
+    double keyframe_th_dist;   /* mParamKeyframeDistanceTh, :71                                                               */
+    double depth_min;          /* mParamDepthMin (DroneBehindPts :247)                                                        */
+    double Tbc[16];            /* mParamTbc, row-major                                                                        */
+} amk_kfmap_params;
 typedef struct amk_pipeline_config {
     int n_slots;            /* independent steps in flight                                                              */
     int n_scenes;           /* scenes per step (S of every handle)                                                      */
@@ -363,6 +375,13 @@ typedef struct amk_pipeline_config {
     amk_step_params step;
     amk_task_params task;   /* only read for frames submitted with d_odom (TASK mode, below)                                */
     amk_depth_params depth; /* only read for frames submitted with d_depth (below)                                          */
+    amk_kfmap_params keyframes;  /* max_frame_count > 0: every slot keeps a keyframe map (amk_kfmap) over its gang x n_scenes    */
+                            /* scenes and every frame runs AddVertex -> KeyframeThreadWorker's body -> the step over            */
+                            /* mVecQueryVector = [current, keyframes ...] (the reference's default regime: FrameKDMap.cpp:29-32, */
+                            /* 64-74).  The scene at position g of slot s must be the same robot every period (as in TASK mode).*/
+                            /* PtIsInFrame: for depth frames the camera is amk_pipeline_config.depth's, down-scaled (:21-24,     */
+                            /* 106-107); for cloud frames amk_pipeline_frame.camera + d_Twc_cur (required then: mCurFrame.Twc    */
+                            /* also feeds DroneBehindPts).  keyframes.Tbc is ignored: depth.Tbc is used.  0: single-frame map.   */
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
     const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame (NULL with d_depth)*/
@@ -384,7 +403,9 @@ typedef struct amk_pipeline_frame {
     /* for every re-plan pass (odom_age + decay for pass 0, odom_age + (i + 1) * iter_time for pass i >= 1), the step, PubCmd /  */
     /* PubSlowDownCmd (:345-350,369-397).                                                                                   */
     /* d_state_quad / d_pos_x are then ignored (may be NULL); d_ref_path_init != NULL first (re)sets mRefPath               */
-    /* (InitCircleState :14-23 or any re-initialisation) BEFORE GetInitPath, NULL keeps the slot's.                          */
+    /* (InitCircleState :14-23 or any re-initialisation) BEFORE GetInitPath, NULL keeps the slot's -- which must exist: the   */
+    /* first TASK frame at a position, and the first one after a launch of the slot failed half-way (the slot's persistent   */
+    /* state may have been shifted / reset by what was enqueued before the failure), must bring it (AMK_ERR_INVALID_ARG).     */
     const double *d_odom;          /* [S][10] or NULL: [mPos(3), yaw, mVel(3), mAcc(3)] as the callbacks left them       */
     double odom_age;               /* now - mTimePos at the start of the step, seconds (:183-184); 0 = fresh odometry    */
     double *d_cmd_out;             /* [S][3] or NULL: Command.acceleration -- u[0..2] when isSafety, else the slow-down  */
@@ -425,6 +446,7 @@ int amk_pipeline_gang(const amk_pipeline *p);       /* frames per launch (>= 1) 
 /* The slot's handles, to configure them (weights, limits, tie order, precision ...) and its stream.                       */
 amk_mpc *amk_pipeline_mpc(amk_pipeline *p, int slot);
 amk_kd *amk_pipeline_kd(amk_pipeline *p, int slot, int which /* 0 obstacle, 1 edge */);
+amk_kfmap *amk_pipeline_kfmap(amk_pipeline *p, int slot);   /* the slot's keyframe map (NULL without one), e.g. for amk_kfmap_state_host */
 void *amk_pipeline_stream(amk_pipeline *p, int slot);
 /* submit() hands back a ticket = position_in_gang * n_slots + slot (without a gang: the slot index, as before);
  * ticket % n_slots is the slot, for amk_pipeline_mpc / _kd / _stream.                                                    */
@@ -434,10 +456,47 @@ int amk_pipeline_wait(amk_pipeline *p, int ticket);   /* until that frame's step
  * block (launches an open gang).  A closed loop -- outputs -> the caller's kernels -> next submit(input_ready) -- then never
  * synchronises with the host.  The slot's NEWEST launch is the one waited for: call it before the next submit on that slot. */
 int amk_pipeline_wait_stream(amk_pipeline *p, int ticket, void *stream);
-int amk_pipeline_query(amk_pipeline *p, int ticket);  /* 1 finished / idle, 0 running or staged, -1 error                 */
+int amk_pipeline_query(amk_pipeline *p, int ticket);  /* 1 finished / idle, 0 running or staged, -1 error (also: the slot's     */
+                                                      /* newest launch failed half-way and dropped its frames; wait() says why) */
 int amk_pipeline_drain(amk_pipeline *p);              /* wait for every slot                                              */
 /* Device pointers of the frame's results (valid after wait): u [S][4], x0array [S][N][14], flags [S][4], ref_path [S][N][10] */
 int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x0array, int **d_flags, double **d_ref_path);
+
+/* ------------------------------------------------------------------------------------------ */
+/* The multi-frame map with keyframes, batched: FrameKDMap's keyframe list on the device       */
+/* ------------------------------------------------------------------------------------------ */
+/* The reference's keyframe thread is on by default (max_frame_count = 100, only_trust_vel = false: FrameKDMap.cpp:29-32),
+ * and every QueryNearest / GetNearestDistance of a control step runs over mVecQueryVector = [current frame, every keyframe
+ * but the newest] (:64-74,322-427).  amk_kfmap is that map for S scenes at once -- every scene with its own deque of
+ * keyframes -- entirely on the device: per control period
+ *   amk_kfmap_add_vertex   FrameKDMap::AddVertex after ProcessDepth (:39-51) for the scenes whose frame is not empty
+ *   amk_kfmap_update       one pass of KeyframeThreadWorker's body (:443-486): first keyframe / pop while the list is longer
+ *                          than max_frame_count or DroneBehindPts fails for the oldest (:233-252) / n x 1-NN sweep of the
+ *                          newest keyframe against the current frame, rebuild from >= keyframe_th_count outliers farther than
+ *                          keyframe_th_dist, InsertKeyFrame
+ *   amk_kfmap_step         the TASK branch over the map (amk_step_batch_frames' semantics: PtIsInFrame fast path, per-frame
+ *                          k' = min(k, size), merge, minimum distance over the frames)
+ * all stream-ordered, no host round trip.  A keyframe is not a copy: every scene owns max_frame_count + 2 physical slots in
+ * two pool indices, its current frame is built into a slot no keyframe holds, the deque is a list of slot numbers.
+ * amk_pipeline runs the three calls inside a TASK-mode slot when amk_pipeline_config.keyframes.max_frame_count > 0
+ * (any gang).  Twb = Twc * Tbc^-1 of DroneBehindPts uses the rigid inverse of Tbc.                                          */
+int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const amk_kfmap_params *prm, amk_kfmap **out);
+int amk_kfmap_destroy(amk_kfmap *map);
+int amk_kfmap_scenes(const amk_kfmap *map);
+int amk_kfmap_frames(const amk_kfmap *map);          /* frames of the query vector: 1 + max_frame_count                      */
+const double *amk_kfmap_twc(const amk_kfmap *map);   /* device [S][16]: mCurFrame.Twc (what BuildEdgeCloud multiplies with, :209) */
+/* Scenes [first_scene, first_scene + n_scenes): d_xyz [n][max_points][stride] / d_counts [n] (NULL = max_points) and the edge
+ * cloud likewise, d_Twc [n][16] = mat4Twb * mParamTbc of the frame.  A scene whose count is 0 keeps its map untouched (:39-41). */
+int amk_kfmap_add_vertex(amk_kfmap *map, int first_scene, int n_scenes, const float *d_xyz, const int *d_counts,
+                         const float *d_edge_xyz, const int *d_edge_counts, int point_stride, const double *d_Twc, void *stream);
+int amk_kfmap_update(amk_kfmap *map, void *stream);
+/* cam == NULL: no frustum test (every query counts as inside the current frame, as amk_step_batch_frames with d_Twc = NULL) */
+int amk_kfmap_step(amk_kfmap *map, const struct amk_frame_camera *cam, amk_mpc *mpc, const amk_step_params *prm,
+                   const double *d_state_quad, const double *d_pos_x, double *d_ref_path, double *d_u, double *d_x0array,
+                   int *d_flags, void *stream);
+/* Introspection (synchronises): per scene mKeyFrameMap.size(), mVecQueryVector.size(), the outliers of the last sweep and --
+ * h_frame_sizes [S][amk_kfmap_frames()] or NULL -- the obstacle-cloud size of every query frame (-1 behind the scene's last). */
+int amk_kfmap_state_host(amk_kfmap *map, int *h_n_keyframes, int *h_n_query_frames, int *h_last_outliers, int *h_frame_sizes);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Scenes sharded over the GPUs of a node (one process per GPU), RCCL over xGMI                 */
@@ -464,6 +523,14 @@ int amk_shard_padded_count(int world, int total);
 int amk_shard_gather(amk_shard *s, const double *d_local, long long n_doubles_per_rank, double *d_all, void *stream);
 int amk_shard_gather_u(amk_shard *s, const double *d_u_local, int n_local_scenes, double *d_u_all, void *stream);
 int amk_shard_max(amk_shard *s, double *d_values, int n, void *stream);   /* in-place max over ranks (timing)              */
+/* Which RCCL was bound (the copy already in the process -- e.g. PyTorch's -- if there is one, else librccl.so.1 from the loader
+ * path): file of ncclAllGather, ncclGetVersion's code, 1 if it had been loaded before this library asked.  A host prints
+ * this next to its results so that the first multi-GPU run can be diagnosed (bench.py: config.rccl).                       */
+int amk_shard_rccl_info(char *path, int path_len, int *version, int *was_loaded);
+/* Watchdog: host-side wait (polling, <= timeout_s) for everything queued on `stream`, the gathers included.
+ * AMK_ERR_TIMEOUT: a collective hangs (a rank that never entered it, a link, two RCCLs in one process): exit and re-run with
+ * NCCL_DEBUG=INFO NCCL_DEBUG_SUBSYS=INIT,COLL.                                                                             */
+int amk_shard_wait(amk_shard *s, void *stream, double timeout_s);
 
 /* ------------------------------------------------------------------------------------------ */
 /* Depth image -> obstacle cloud: FrameKDMap::ProcessDepth            FrameKDMap.cpp:75-138   */

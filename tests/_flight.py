@@ -322,8 +322,17 @@ def _depth_frame(world, x):
     return np.clip(np.round(d / c["pixel2meter"]), 0, 65535).astype(np.uint16), Twb
 
 
+def depth_camera():
+    """PtIsInFrame's camera for DEPTH_CAM: the intrinsics divided by the resize scale (FrameKDMap.cpp:21-24), the down-scaled image
+    size of ProcessDepth (:106-107).  -> (fx, fy, cx, cy, depth_max, width, height)"""
+    c = DEPTH_CAM
+    sc = c["resize_scale"]
+    return (c["fx"] / sc, c["fy"] / sc, c["cx"] / sc, c["cy"] / sc, c["depth_max"], int(c["cols"] / sc), int(c["rows"] / sc))
+
+
 def _oracle_depth_flight(job):
-    seed, cfg, periods, world_kw = job
+    seed, cfg, periods, world_kw = job[:4]
+    map_kw = job[4] if len(job) > 4 else None     # dict(max_frame_count, th_dist, th_count): fly with the keyframe map
     from tests import _oracle
     prm, _ = make_prm(cfg)
     world = flight.FlightWorld(seed, prm, 1000, **world_kw)
@@ -333,18 +342,36 @@ def _oracle_depth_flight(job):
     log["x"][0] = x
     log["n_cloud"] = np.zeros(periods, np.int32); log["n_edge"] = np.zeros(periods, np.int32)
     Twc = np.eye(4); kd = ke = None
+    kmap = None
+    if map_kw:
+        from tests import _kfmap
+        kmap = _kfmap.MapOracle(map_kw["max_frame_count"], map_kw["th_dist"], map_kw["th_count"], DEPTH_CAM["depth_min"], DEPTH_CAM["Tbc"])
+        log["n_keyframes"] = np.zeros(periods, np.int32); log["n_query_frames"] = np.zeros(periods, np.int32)
+        log["outliers"] = np.zeros(periods, np.int32); log["map_points"] = np.zeros(periods, np.int64)
     for t in range(periods):
         img, Twb = _depth_frame(world, x)
         cloud, _ = _oracle.depth_oracle(img, DEPTH_CAM, Twb)
-        if len(cloud):                                          # AddVertex, FrameKDMap.cpp:39-51
-            edge = _oracle.depth_edge_oracle(img, DEPTH_CAM, Twc)[0]
-            if kd is not None:
-                kd.close(); ke.close()
-            kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
-            Twc = Twb @ DEPTH_CAM["Tbc"]
-        log["n_cloud"][t] = kd.size(); log["n_edge"][t] = ke.size()
-        sq, px = flight.period_inputs(x[None], ref[None], prm)
-        r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
+        if kmap is not None:
+            if len(cloud):                                      # AddVertex (:39-51), then KeyframeThreadWorker's body (:443-486)
+                edge = _oracle.depth_edge_oracle(img, DEPTH_CAM, kmap.Twc)[0]   # the stale pose (:209)
+                kmap.add_vertex(cloud, edge, Twb @ DEPTH_CAM["Tbc"], stamp=t)
+            kmap.update()
+            nk, sizes = kmap.summary()
+            log["n_keyframes"][t] = nk; log["n_query_frames"][t] = len(sizes); log["outliers"][t] = max(kmap.last_outliers, 0)
+            log["map_points"][t] = int(np.sum(sizes))
+            log["n_cloud"][t] = kmap.cur.kd.size(); log["n_edge"][t] = kmap.cur.ke.size()
+            sq, px = flight.period_inputs(x[None], ref[None], prm)
+            r = kmap.step(mpc, prm, sq[0], px[0], ref, depth_camera())
+        else:
+            if len(cloud):                                          # AddVertex, FrameKDMap.cpp:39-51
+                edge = _oracle.depth_edge_oracle(img, DEPTH_CAM, Twc)[0]
+                if kd is not None:
+                    kd.close(); ke.close()
+                kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
+                Twc = Twb @ DEPTH_CAM["Tbc"]
+            log["n_cloud"][t] = kd.size(); log["n_edge"][t] = ke.size()
+            sq, px = flight.period_inputs(x[None], ref[None], prm)
+            r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
         a = flight.command(r["u"][None], r["flags"][None], x[None], prm)
         x = flight.apply_command(x[None], a, prm)[0]
         log["x"][t + 1] = x; log["u"][t] = r["u"]; log["flags"][t] = r["flags"]; log["cmd"][t] = a[0]
@@ -352,15 +379,18 @@ def _oracle_depth_flight(job):
     return log
 
 
-def oracle_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, workers=None):
+def oracle_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, workers=None, keyframes=None):
+    """keyframes: dict(max_frame_count, th_dist, th_count) flies with FrameKDMap's keyframe list (tests/_kfmap.py) and logs
+    n_keyframes / n_query_frames / outliers / map_points per period."""
     from tests import _oracle
     _oracle.build_oracle()
-    jobs = [(int(s), cfg, periods, world_kw or {}) for s in seeds]
+    jobs = [(int(s), cfg, periods, world_kw or {}, keyframes) for s in seeds]
     return _stack(_pool_map(_oracle_depth_flight, jobs, workers or usable_cores()))
 
 
-def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=None):
-    """The same flights through amk_pipeline frames that START at the depth image (d_depth + d_Twb) in TASK mode."""
+def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=None, keyframes=None):
+    """The same flights through amk_pipeline frames that START at the depth image (d_depth + d_Twb) in TASK mode.
+    keyframes: dict(max_frame_count, th_dist, th_count): every slot keeps a keyframe map (amk_pipeline_config.keyframes)."""
     import torch
     from avoid_mpc_amd.host import Pipeline, depth_params
     prm, _ = make_prm(cfg)
@@ -373,9 +403,14 @@ def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=
     x = np.stack([a for a, _ in st]); ref0 = np.stack([b for _, b in st])
     cap = int(c["cols"] / c["resize_scale"]) * int(c["rows"] / c["resize_scale"])
     dp = depth_params(c["pixel2meter"], c["depth_min"], c["depth_max"], c["resize_scale"], c["fx"], c["fy"], c["cx"], c["cy"], c["Tbc"])
-    pl = Pipeline(nb // gang, B, cap, cap, prm, queue_depth=1, gang=gang, depth=dp)
+    pl = Pipeline(nb // gang, B, cap, cap, prm, queue_depth=1, gang=gang, depth=dp,
+                  keyframes=dict(keyframes, depth_min=c["depth_min"]) if keyframes else None)
     logs = dict(x=np.zeros((F, periods + 1, 10)), u=np.zeros((F, periods, 4)), flags=np.zeros((F, periods, 4), np.int32),
                 cmd=np.zeros((F, periods, 3)))
+    if keyframes:
+        logs.update(n_keyframes=np.zeros((F, periods), np.int32), n_query_frames=np.zeros((F, periods), np.int32),
+                    outliers=np.zeros((F, periods), np.int32), map_points=np.zeros((F, periods), np.int64),
+                    n_cloud=np.zeros((F, periods), np.int32))
     logs["x"][:, 0] = x
     for t in range(periods):
         keep, tickets = [], []
@@ -395,6 +430,13 @@ def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=
             a = keep[b][3].cpu().numpy()
             x[sl] = flight.apply_command(x[sl], a, prm)
             logs["u"][sl, t] = o["u"]; logs["flags"][sl, t] = o["flags"]; logs["cmd"][sl, t] = a
+            if keyframes:   # batch b = position b % gang of slot b // gang ... in submission order: slot = ticket % n_slots
+                slot, pos = tk % pl.n_slots, tk // pl.n_slots
+                ms = pl.kfmap_state(slot)
+                ps = slice(pos * B, (pos + 1) * B)
+                logs["n_keyframes"][sl, t] = ms["n_keyframes"][ps]; logs["n_query_frames"][sl, t] = ms["n_query_frames"][ps]
+                logs["outliers"][sl, t] = ms["last_outliers"][ps]
+                logs["map_points"][sl, t] = np.maximum(ms["frame_sizes"][ps], 0).sum(axis=1); logs["n_cloud"][sl, t] = ms["frame_sizes"][ps, 0]
         logs["x"][:, t + 1] = x
     pl.close()
     logs["clearance"] = np.stack([w.clearance(logs["x"][i, :, 0:3]) for i, w in enumerate(worlds)])

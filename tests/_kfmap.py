@@ -76,10 +76,10 @@ class MapOracle:
         return True
 
     def update(self):                                                  # KeyframeThreadWorker's body (:443-486)
+        self.last_outliers = -1                                       # (bookkeeping of this restatement: outliers of THIS pass's sweep)
         if self.max_frame_count <= 0 or not self.need:
             return
         self.need = False
-        self.last_outliers = -1
         if not self.kfs:                                               # :446-449
             self.kfs.append(self.cur)
             return

@@ -9,6 +9,25 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _check_rccl_block_and_rank_files(out, rank_dir, world):
+    """the line says which RCCL the library bound and how many librccl files the process maps; every rank left
+    its own file BEFORE the gather (what a hung collective would leave behind)."""
+    r = out["rccl"]
+    assert set(r) >= {"amk_shard_bound", "torch_nccl_version", "librccl_files_mapped", "single_rccl_instance"}
+    b = r["amk_shard_bound"]
+    if b is not None:   # (a box without any librccl: the library reports AMK_ERR_UNSUPPORTED and the block says None)
+        assert os.path.basename(b["path"]).startswith("librccl") and b["version"] >= 0
+        # torch is imported in the same process: its bundled RCCL was there first and is the one that must have been bound
+        assert r["librccl_files_mapped"] is None or b["path"] in r["librccl_files_mapped"] or \
+            os.path.realpath(b["path"]) in [os.path.realpath(x) for x in r["librccl_files_mapped"]]
+        assert r["single_rccl_instance"] in (True, None), r
+    files = sorted(os.listdir(rank_dir))
+    assert files == [f"rank{i}.json" for i in range(world)], files
+    for i, f in enumerate(files):
+        d = json.load(open(os.path.join(rank_dir, f)))
+        assert d["rank"] == i and d["world"] == world and d["stage"] == "before the gather" and "rccl" in d
+
+
 def _run(extra, env_extra=None):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env.update(env_extra or {})
@@ -20,10 +39,11 @@ def _run(extra, env_extra=None):
     return json.loads(lines[0])
 
 
-def test_plain_invocation_spawns_its_ranks():
-    out = _run(["--gpus", "2", "--scenes", "5"])
+def test_plain_invocation_spawns_its_ranks(tmp_path):
+    out = _run(["--gpus", "2", "--scenes", "5"], {"AMK_BENCH_RANK_DIR": str(tmp_path)})
     assert out["n_gpus"] == 2 and out["ranks_seen"] == 2 and out["gather_ok"] and out["dry_run"]
     assert out["steps"] == 3 and out["warmup"] == 1 and out["scenes_per_rank"] == 5
+    _check_rccl_block_and_rank_files(out, str(tmp_path), 2)
 
 
 def test_single_rank_needs_no_launcher():
@@ -31,9 +51,10 @@ def test_single_rank_needs_no_launcher():
     assert out["n_gpus"] == 1 and out["gather_ok"]
 
 
-def test_under_a_launcher_the_world_size_wins():
+def test_under_a_launcher_the_world_size_wins(tmp_path):
     """The driver's own command line (`python -m torch.distributed.run ... bench.py --gpus N`): bench.py must not spawn again."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AMK_BENCH_RANK_DIR"] = str(tmp_path)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
                         "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "3", "--dry-run", "--steps", "2",
                         "--scenes", "7"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
@@ -42,3 +63,4 @@ def test_under_a_launcher_the_world_size_wins():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 3 and out["gather_ok"] and out["padded_scenes_per_rank"] == 7
+    _check_rccl_block_and_rank_files(out, str(tmp_path), 3)

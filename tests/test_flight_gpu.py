@@ -45,8 +45,9 @@ def test_flights_c2_gpu_equals_oracle():
     print("oracle", so)
     assert cmp["dpos_max_while_together"] <= 1e-6
     # a separated flight took another branch at a rounding-level tie (another iteration count, rarely another local minimum):
-    # allowed on <= 10 % of the flights (per-step census 0.2 % x 100 periods x ~1 solve); the closed loop must keep them close
-    assert cmp["separated"] <= max(1, F // 10), cmp["separation_period"]
+    # allowed on <= 3 % of the flights (the census over 1024 flights x 150 periods observed 1.2 %, profiles/r04_flight_census_1024.json);
+    # the closed loop must bring them back: the census saw 11 of 12 separated flights end within 3e-5 m of the oracle's
+    assert cmp["separated"] <= max(1, (3 * F) // 100), cmp["separation_period"]
     assert sg["capped_periods"] == 0 and so["capped_periods"] == 0
     # the same flying: clearance statistics agree (a separated flight may differ in the last digits of its minimum)
     assert abs(sg["min_clearance_median"] - so["min_clearance_median"]) < 0.02

@@ -241,7 +241,7 @@ def test_pipeline_survives_a_failed_launch(gang, stage):
           for fr in frames[:gang]]
     assert st[:-1] == [capi.AMK_OK] * (gang - 1) and st[-1] == capi.AMK_ERR_HIP       # the submit that launched reports it
     assert pl.lib.amk_pipeline_wait(pl.h, 0) == capi.AMK_ERR_HIP                        # ... and so does wait() on that slot
-    assert pl.lib.amk_pipeline_query(pl.h, 0) == 1                                      # nothing of it is left staged or running
+    assert pl.lib.amk_pipeline_query(pl.h, 0) == -1                                     # nothing of it is left staged or running: query() says "failed" 
     assert pl.lib.amk_pipeline_drain(pl.h) == capi.AMK_ERR_HIP
     # the failed launch consumed slot 0's turn: the next frames start on slot 1, fill whole gangs, and are the fresh pipeline's
     got = run(pl, frames)
@@ -253,6 +253,35 @@ def test_pipeline_survives_a_failed_launch(gang, stage):
                             fr["ref"].data_ptr(), None, None, 0.0, None, None)
     assert pl.lib.amk_pipeline_submit(pl.h, C.byref(f5), None) == capi.AMK_ERR_INVALID_ARG
     assert np.array_equal(run(pl, frames), want)
+    pl.close()
+
+
+def test_task_frames_need_a_reference_path_and_lose_it_with_a_failed_launch():
+    """a TASK frame shifts the mRefPath the slot keeps for its position -- the first one there must bring
+    d_ref_path_init (InitCircleState's role, AvoidanceStateMachine.cpp:14-23); and a launch that fails after the prologue has
+    already shifted the path: the slot's persistent state is declared lost, the next TASK frame must re-initialise it."""
+    import torch
+    from avoid_mpc_amd.host import Pipeline
+    prm = synth.MpcParams(T=0.33, K=3)
+    S, n, ne = 4, 5000, 500
+    fr = _frames(torch, prm, 1, S, n)[0]
+    odom = torch.zeros((S, 10), dtype=torch.float64, device="cuda"); odom[:, 2] = prm.height; odom[:, 4] = prm.speed
+    cmd = torch.zeros((S, 3), dtype=torch.float64, device="cuda")
+    pl = Pipeline(1, S, n, ne, prm, gang=1)
+
+    def task_frame(with_ref):
+        return capi.PipelineFrame(fr["cl"].data_ptr(), None, fr["ed"].data_ptr(), None, 3, 1, None, None,
+                                  fr["ref"].data_ptr() if with_ref else None, None, odom.data_ptr(), 0.0, cmd.data_ptr())
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(False)), None) == capi.AMK_ERR_INVALID_ARG   # no path yet
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(True)), None) == capi.AMK_OK
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(False)), None) == capi.AMK_OK                # the slot's own path
+    assert pl.lib.amk_pipeline_drain(pl.h) == capi.AMK_OK and pl.lib.amk_pipeline_query(pl.h, 0) == 1
+    assert pl.lib.amk__pipeline_inject_failure(pl.h, 2) == capi.AMK_OK                                       # after GetInitPath ran
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(False)), None) == capi.AMK_ERR_HIP
+    assert pl.lib.amk_pipeline_query(pl.h, 0) == -1
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(False)), None) == capi.AMK_ERR_INVALID_ARG   # the shifted path is not trusted
+    assert pl.lib.amk_pipeline_submit(pl.h, C.byref(task_frame(True)), None) == capi.AMK_OK
+    assert pl.lib.amk_pipeline_drain(pl.h) == capi.AMK_OK and pl.lib.amk_pipeline_query(pl.h, 0) == 1
     pl.close()
 
 

@@ -53,3 +53,44 @@ def test_gather_controls_on_rccl_from_several_streams():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+CHILD_INFO = r'''
+import os, sys, json
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch
+from avoid_mpc_amd import capi
+from avoid_mpc_amd.host import Shard
+torch.cuda.set_device(0)
+info = Shard.rccl_info()
+mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+sh = Shard(0, 1, Shard.unique_id())
+a = torch.arange(32, dtype=torch.float64, device="cuda"); b = torch.zeros_like(a)
+sh.gather(a, b)
+rc = sh.wait(timeout_s=60.0)
+mapped_after = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+print("INFO " + json.dumps(dict(info=info, mapped=mapped, mapped_after=mapped_after, wait=rc, equal=bool(torch.equal(a, b)),
+                                 bad_wait=sh.lib.amk_shard_wait(sh.h, None, -1.0))))
+'''
+
+
+def test_the_library_binds_the_rccl_that_is_already_in_the_process():
+    """VERDICT r4 #4: bench.py's ranks hold a torch.distributed "nccl" group (PyTorch's bundled librccl) AND amk_shard's own
+    communicator.  The library must take the copy that is already mapped (RTLD_NOLOAD) instead of loading a second one, say
+    which file it bound (dladdr of ncclAllGather), and its watchdog must return AMK_OK for a healthy gather."""
+    import json
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % ROOT + CHILD_INFO], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("INFO ")][0][5:])
+    assert d["equal"] and d["wait"] == 0 and d["bad_wait"] == 1, d        # AMK_OK; a non-positive timeout is AMK_ERR_INVALID_ARG
+    info = d["info"]
+    assert info and os.path.basename(info["path"]).startswith("librccl"), d
+    real = lambda xs: {os.path.realpath(x) for x in xs}
+    if d["mapped"]:   # import torch had mapped its RCCL before the library asked: that one must be the one bound, and no other appeared
+        assert info["loaded_before_amk"] and os.path.realpath(info["path"]) in real(d["mapped"]), d
+        assert real(d["mapped_after"]) == real(d["mapped"]), d
+    else:
+        assert len(real(d["mapped_after"])) == 1, d
+    print("bound RCCL:", info)
