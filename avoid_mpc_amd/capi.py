@@ -31,7 +31,7 @@ SYMBOLS = [
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
-    "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
+    "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_reset", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
     "amk_kfmap_update", "amk_kfmap_step", "amk_kfmap_state_host",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_solve_budget", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
@@ -193,6 +193,7 @@ def load():
         "amk_pipeline_outputs": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
         "amk_kfmap_create": (i, [i, i, i, C.POINTER(KfmapParams), C.POINTER(vp)]),
         "amk_kfmap_destroy": (i, [vp]),
+        "amk_kfmap_reset": (i, [vp, i, i, vp]),
         "amk_kfmap_scenes": (i, [vp]),
         "amk_kfmap_frames": (i, [vp]),
         "amk_kfmap_twc": (vp, [vp]),

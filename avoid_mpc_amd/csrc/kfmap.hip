@@ -51,9 +51,9 @@ using namespace amk;
 
 __global__ __launch_bounds__(256) void kf_init_kernel(int S, int P, int *__restrict__ cur_slot, int *__restrict__ kf_n,
                                                       int *__restrict__ kf_slots, int *__restrict__ need, double *__restrict__ Twc,
-                                                      int *__restrict__ fmap, int F) {
-    const int s = blockIdx.x * 256 + threadIdx.x;
-    if (s >= S) return;
+                                                      int *__restrict__ fmap, int F, int first, int n) {
+    const int s = first + blockIdx.x * 256 + threadIdx.x;
+    if (s >= first + n) return;
     cur_slot[s] = -1; kf_n[s] = 0; need[s] = 0;
     for (int i = 0; i < P; ++i) kf_slots[(size_t)s * P + i] = -1;
     for (int e = 0; e < 16; ++e) Twc[(size_t)s * 16 + e] = (e % 5 == 0) ? 1.0 : 0.0;
@@ -222,7 +222,7 @@ int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const am
         st = amk::hip_fail(e);
     if (st == AMK_OK) {
         hipLaunchKernelGGL(kf_init_kernel, dim3((n_scenes + 255) / 256), dim3(256), 0, nullptr, n_scenes, m->P, m->cur_slot.p, m->kf_n.p,
-                           m->kf_slots.p, m->need.p, m->Twc.p, m->fmap.p, m->F);
+                           m->kf_slots.p, m->need.p, m->Twc.p, m->fmap.p, m->F, 0, n_scenes);
         if ((e = hipGetLastError()) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) st = amk::hip_fail(e);
     }
     if (st != AMK_OK) {
@@ -238,6 +238,16 @@ int amk_kfmap_destroy(amk_kfmap *m) {
     if (m->obs) amk_kd_destroy(m->obs);
     if (m->edge) amk_kd_destroy(m->edge);
     delete m;
+    return AMK_OK;
+}
+
+// A new FrameKDMap for scenes [first_scene, first_scene + n_scenes): no current frame, no keyframe, Twc = identity (the state
+// after the constructor, FrameKDMap.cpp:6-33) -- a robot that starts over.  Stream-ordered.
+int amk_kfmap_reset(amk_kfmap *m, int first_scene, int n_scenes, void *stream) {
+    if (!m || first_scene < 0 || n_scenes < 1 || first_scene + n_scenes > m->S) return AMK_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(kf_init_kernel, dim3((n_scenes + 255) / 256), dim3(256), 0, (hipStream_t)stream, m->S, m->P, m->cur_slot.p,
+                       m->kf_n.p, m->kf_slots.p, m->need.p, m->Twc.p, m->fmap.p, m->F, first_scene, n_scenes);
+    AMK_HIP(hipGetLastError());
     return AMK_OK;
 }
 

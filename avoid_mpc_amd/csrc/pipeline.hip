@@ -243,6 +243,20 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     hipStream_t st = s.stream;
     for (const auto &f : s.open)   // inputs produced on the caller's streams: ordered on the device, not by the host
         if (f.input_ready) AMK_HIP(hipStreamWaitEvent(st, f.input_ready, 0));
+    // a robot that starts over (a TASK frame with d_ref_path_init: InitCircleState's role) also starts with a new FrameKDMap:
+    // no keyframes, mCurFrame.Twc = identity -- before the depth stage, whose edge cloud goes through that (stale) pose (:209)
+    for (int g = 0; g < (int)s.open.size(); ++g) {
+        const amk_pipeline::Staged &f = s.open[g];
+        if (!(f.odom && f.ref_path_init)) continue;
+        if (s.map) {
+            const int rr = amk_kfmap_reset(s.map, g * S, S, st);
+            if (rr != AMK_OK) return rr;
+        }
+        if (s.map && s.Twc.p) {   // (without a map the slot's Twc keeps its round-4 behaviour: it persists)
+            hipLaunchKernelGGL(pipeline_twc_init_kernel, dim3((S * 16 + 255) / 256), dim3(256), 0, st, s.Twc.p + (size_t)g * S * 16, S);
+            AMK_HIP(hipGetLastError());
+        }
+    }
     const float *cl[AMK_PIPELINE_MAX_GANG], *ed[AMK_PIPELINE_MAX_GANG];
     const int *cc[AMK_PIPELINE_MAX_GANG], *ec[AMK_PIPELINE_MAX_GANG];
     GatherArgs ga{};
@@ -321,6 +335,7 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
             const amk_pipeline::Staged &f = s.open[g];
             const double *twc = f.depth ? s.Twc.p + (size_t)g * S * 16 : f.Twc_cur;
             if (!twc) return AMK_ERR_INVALID_ARG;   // (submit() checked)
+
             rc = amk_kfmap_add_vertex(s.map, g * S, S, cl[g], cc[g], ed[g], ec[g], s.point_stride, twc, st);
             if (rc != AMK_OK) return rc;
         }

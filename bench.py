@@ -331,7 +331,11 @@ def flight_main(args):
     A, Bm, c = flight.affine_plant(prm.tau, prm.dt)
     ABt = torch.from_numpy(np.concatenate([A, Bm], axis=1).T.copy()).to(dev)      # [14, 10]: x' = [x, a_cmd, 0] @ ABt + c
     cvec = torch.from_numpy(c).to(dev)
-    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang)
+    kf = dict(max_frame_count=args.keyframes, th_dist=0.1, th_count=10, depth_min=0.1) if args.keyframes > 0 else None   # yaml :71-73,66
+    # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor looking along +x of the odometry frame (Tbc = I here)
+    kf_cam = capi.FrameCamera(32.0, 32.0, 32.0, 24.0, 100.0, 64, 48) if kf else None
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang, keyframes=kf)
+    Twc = [torch.eye(4, dtype=torch.float64, device=dev).repeat(S, 1, 1).contiguous() for _ in range(B)] if kf else None
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
         pl.mpc(i).set_precision(args.precision)
@@ -362,8 +366,12 @@ def flight_main(args):
                 for g in range(gang):
                     b = si * gang + g
                     cl, ed = frames[b % W][t]
+                    if kf:   # mCurFrame.Twc of the frame: the odometry position (R = I), written on the slot's stream behind the vehicle
+                        with torch.cuda.stream(slot_stream[si]):
+                            Twc[b][:, 0:3, 3] = x[b][:, 0:3]
                     tickets.append(pl.submit(cl, ed, ref_path_init=ref0_d[b] if t == 0 else None, odom=x[b], cmd_out=cmd[b],
-                                             keep_warm_start=t > 0, order_after_current_stream=False))
+                                             keep_warm_start=t > 0, order_after_current_stream=False,
+                                             Twc_cur=Twc[b] if kf else None, cam=kf_cam))
                     assert tickets[-1] % nslots == si
                 t_sub += time.perf_counter() - ts
                 with torch.cuda.stream(slot_stream[si]):      # queued behind the gang's launches on the same stream
@@ -403,7 +411,8 @@ def flight_main(args):
         cl = np.stack([frames[0][t][0][:nf].cpu().numpy() for t in range(P)], axis=1)     # [nf, P, n, 3]
         ed = np.stack([frames[0][t][1][:nf].cpu().numpy() for t in range(P)], axis=1)
         t0 = time.perf_counter()
-        o = _flight.oracle_flights_on_frames(cl, ed, x0[0, :nf], ref0[0, :nf], args.T, args.K)
+        o = _flight.oracle_flights_on_frames(cl, ed, x0[0, :nf], ref0[0, :nf], args.T, args.K,
+                                             keyframes=dict(kf, cam=(32.0, 32.0, 32.0, 24.0, 100.0, 64, 48)) if kf else None)
         t_cpu = time.perf_counter() - t0
         g = dict(x=np.concatenate([pos[0, :nf], np.zeros((nf, P + 1, 7))], axis=2), flags=fl[0, :nf], u=ug[0, :nf])
         cmp = _flight.compare(g, o, pos_tol=1e-6)
@@ -478,6 +487,10 @@ def main():
     ap.add_argument("--workload", default="cold", choices=("cold", "flight"),
                     help="cold (the headline: fresh frame + zero warm start every step) or flight (closed loop: every step is one "
                          "control period of a batch of flights -- fresh frame, GetInitPath, warm start, command, vehicle)")
+    ap.add_argument("--keyframes", type=int, default=0,
+                    help="flight workload: max_frame_count of the keyframe map every slot keeps (amk_pipeline_config.keyframes; 0: "
+                         "single-frame map).  The reference's default regime (FrameKDMap.cpp:29-32); mind the pool: (N + 2) x "
+                         "gang x scenes index slots per pipeline slot")
     ap.add_argument("--periods", type=int, default=0, help="flight workload: control periods per flight (0: from --steps)")
     ap.add_argument("--inputs", default="device", choices=("device", "host"),
                     help="host: every step's clouds, edge clouds and odometry start in pinned host memory and cross PCIe inside the "

@@ -382,6 +382,7 @@ typedef struct amk_pipeline_config {
                             /* PtIsInFrame: for depth frames the camera is amk_pipeline_config.depth's, down-scaled (:21-24,     */
                             /* 106-107); for cloud frames amk_pipeline_frame.camera + d_Twc_cur (required then: mCurFrame.Twc    */
                             /* also feeds DroneBehindPts).  keyframes.Tbc is ignored: depth.Tbc is used.  0: single-frame map.   */
+                            /* A TASK frame that brings d_ref_path_init (a robot that starts over) also resets its scenes' map.   */
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
     const float *d_cloud;          /* [S][max_points][point_stride]      obstacle cloud of the frame (NULL with d_depth)*/
@@ -482,6 +483,8 @@ int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x
  * (any gang).  Twb = Twc * Tbc^-1 of DroneBehindPts uses the rigid inverse of Tbc.                                          */
 int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const amk_kfmap_params *prm, amk_kfmap **out);
 int amk_kfmap_destroy(amk_kfmap *map);
+/* scenes [first_scene, first_scene + n_scenes) start over: no current frame, no keyframe, Twc = identity (stream-ordered) */
+int amk_kfmap_reset(amk_kfmap *map, int first_scene, int n_scenes, void *stream);
 int amk_kfmap_scenes(const amk_kfmap *map);
 int amk_kfmap_frames(const amk_kfmap *map);          /* frames of the query vector: 1 + max_frame_count                      */
 const double *amk_kfmap_twc(const amk_kfmap *map);   /* device [S][16]: mCurFrame.Twc (what BuildEdgeCloud multiplies with, :209) */

@@ -51,7 +51,9 @@ class _GivenFrames:
 
 def _oracle_flight(job):
     seed, cfg, periods, n_points, world_kw = job[:5]
-    task_kw = job[5] if len(job) > 5 else {}      # dict(task="global_goal", global_goal=[3]): GetInitPath's other task (:34-45)
+    task_kw = (job[5] if len(job) > 5 else None) or {}   # dict(task="global_goal", global_goal=[3]): GetInitPath's other task (:34-45)
+    map_kw = job[6] if len(job) > 6 else None     # dict(max_frame_count, th_dist, th_count, depth_min, cam): fly with the keyframe map;
+    # cloud frames carry no camera pose, so mCurFrame.Twc is the odometry position with R = I and Tbc = I (bench.py does the same)
     from tests import _oracle
     prm, n = make_prm(cfg) if isinstance(cfg, str) else (synth.MpcParams(T=cfg[0], K=cfg[1]), n_points)
     n = n_points or n
@@ -64,13 +66,25 @@ def _oracle_flight(job):
     mpc = _oracle.MpcOracle(prm.T, prm.dt, prm.K); mpc.configure(prm)
     log = _log_arrays(periods)
     log["x"][0] = x
+    kmap = None
+    if map_kw:
+        from tests import _kfmap
+        kmap = _kfmap.MapOracle(map_kw["max_frame_count"], map_kw["th_dist"], map_kw["th_count"], map_kw["depth_min"], np.eye(4))
+        log["n_keyframes"] = np.zeros(periods, np.int32); log["n_query_frames"] = np.zeros(periods, np.int32)
     for t in range(periods):
         cloud, edge = world.frame(t)
-        kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
         sq, px = flight.period_inputs(x[None], ref[None], prm, task=task_kw.get("task", "forward"),
                                       global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[None])
-        r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
-        kd.close(); ke.close()
+        if kmap is not None:
+            Twc = np.eye(4); Twc[:3, 3] = x[0:3]
+            kmap.add_vertex(cloud, edge, Twc, stamp=t)
+            kmap.update()
+            log["n_keyframes"][t], log["n_query_frames"][t] = len(kmap.kfs), len(kmap.frames())
+            r = kmap.step(mpc, prm, sq[0], px[0], ref, map_kw.get("cam"))
+        else:
+            kd, ke = _oracle.kd_oracle(cloud), _oracle.kd_oracle(edge)
+            r = _oracle.step_oracle(kd, ke, mpc, prm, sq[0], px[0], ref)
+            kd.close(); ke.close()
         a = flight.command(r["u"][None], r["flags"][None], x[None], prm)
         x = flight.apply_command(x[None], a, prm)[0]
         log["x"][t + 1] = x; log["u"][t] = r["u"]; log["flags"][t] = r["flags"]; log["cmd"][t] = a[0]
@@ -127,14 +141,15 @@ def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, w
     return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
 
 
-def oracle_flights_on_frames(clouds, edges, x0, ref0, T, K, cyl=None, workers=None):
+def oracle_flights_on_frames(clouds, edges, x0, ref0, T, K, cyl=None, workers=None, keyframes=None):
     """CPU-oracle flights on given frames: clouds [F, P, n, 3], edges [F, P, ne, 3] float32, x0 [F, 10], ref0 [F, N, 10];
-    cyl: optional (cx, cy, cr) [F, ncyl] for the clearance.  -> the same dict of arrays as oracle_flights."""
+    cyl: optional (cx, cy, cr) [F, ncyl] for the clearance.  -> the same dict of arrays as oracle_flights.
+    keyframes: dict(max_frame_count, th_dist, th_count, depth_min, cam) flies with FrameKDMap's keyframe list."""
     from tests import _oracle
     _oracle.build_oracle()
     F, P = clouds.shape[0], clouds.shape[1]
     jobs = [(dict(clouds=clouds[f], edges=edges[f], x0=x0[f], ref0=ref0[f], cyl=None if cyl is None else tuple(c[f] for c in cyl)),
-             (T, K), P, clouds.shape[2], {}) for f in range(F)]
+             (T, K), P, clouds.shape[2], {}, None, keyframes) for f in range(F)]
     return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
 
 
