@@ -472,8 +472,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
     const size_t o = (size_t)s * kcap + i;
     unsigned char f = 0;
     if (cur_sizes[sc] > 1) {  // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
-        const double d2 = amk::grid_nn1_thread(cur.scene(sc), (double)KX[o], (double)KY[o], (double)KZ[o]);
-        if (d2 < DBL_MAX && sqrt(d2) > th_dist) f = 1;
+        f = (unsigned char)amk::grid_outlier_thread(cur.scene(sc), (double)KX[o], (double)KY[o], (double)KZ[o], th_dist);
     }
     flags[o] = f;
 }

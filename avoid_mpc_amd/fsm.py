@@ -24,16 +24,17 @@ def cur_state_quad(pos, vel, acc, yaw, dt, use_odom_est=True):
     return sq
 
 
-def state_quads(pos, vel, acc, yaw, decay, max_iter, iter_time=None):
+def state_quads(pos, vel, acc, yaw, decay, max_iter, iter_time=None, age=0.0):
     """[max_iter][10].  The reference reads the wall clock inside the re-plan loop
     (:329-330,343): iteration 0 extrapolates by `decay`, iteration i by the measured duration of
     iteration i-1 on top of the time already spent.  The device loop has no host round trip, so the
     caller supplies a clock model: every outer iteration is assumed to take `iter_time` seconds
     (default: decay, the reference's own compute-latency assumption, mpc_parameters.yaml:77): pass 0 extrapolates by decay,
     pass i >= 1 by (i + 1) * iter_time = i passes spent + the duration of pass i - 1 (written iter_time + i * iter_time: the
-    bits of the default iter_time = decay are those of decay + i * decay)."""
+    bits of the default iter_time = decay are those of decay + i * decay).  age: now - mTimePos at the start of the step
+    (:183-184), on top of every pass."""
     it = decay if iter_time is None else iter_time
-    return np.stack([cur_state_quad(pos, vel, acc, yaw, (decay if i == 0 else it) + i * it) for i in range(max_iter)])
+    return np.stack([cur_state_quad(pos, vel, acc, yaw, (age + (decay if i == 0 else it)) + i * it) for i in range(max_iter)])
 
 
 def get_init_path(ref_path, speed, T, pos_x, farest_point, height, task="forward", global_goal=None, dt=None):

@@ -81,7 +81,7 @@ def oracle_chain(msgs, prm, ref0):
         if kd is not None:                                                                                 # Step, TASK :322-355
             fsm.get_init_path(ref, prm.speed, prm.T, o_pos[0], 500.0, prm.height)
             age = m["t_step"] - o_stamp
-            sq = fsm.state_quads(o_pos, o_vel, o_acc, yaw, prm.decay + age, prm.max_iter, iter_time=prm.decay)
+            sq = fsm.state_quads(o_pos, o_vel, o_acc, yaw, prm.decay, prm.max_iter, iter_time=prm.decay, age=age)
             s = _oracle.step_oracle(kd, ke, mpc, prm, sq, o_pos[0], ref)
             x = np.concatenate([o_pos, [yaw], o_vel, o_acc])
             r.update(flags=s["flags"], u=s["u"], cmd=flight.command(s["u"][None], s["flags"][None], x[None], prm)[0], ref=ref.copy())
