@@ -699,70 +699,45 @@ __device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx
 
 
 // The keyframe sweep does not need the nearest DISTANCE, only whether it exceeds th (FrameKDMap.cpp:470-475: outlier iff
-// sqrt(squared_distances[0]) > mParamKeyframeDistanceTh): the same ring walk, left as soon as the answer is known -- a point
-// within th ends it (inlier: sqrt is monotone, so the minimum is within th too), and so does a ring boundary farther than th
-// once a finite point has been seen (everything unvisited is farther still).  With th = 0.1 m against cells of ~64 points
-// most queries end inside their own cell; the exact walk visits the 26 neighbours as well.  Returns 1 = outlier, 0 = not
-// (also when the index holds no point at a finite distance: the reference then has no result to test).  Same flags as
-// `sqrt(grid_nn1_thread(...)) > th`, bit for bit (tests/test_keyframe_gpu.py, test_kfmap_gpu.py).
+// sqrt(squared_distances[0]) > mParamKeyframeDistanceTh) -- a FIXED-RADIUS question: a point within th of q lies in a cell that
+// the cube [q - th, q + th]^3 touches (cell_of is monotone per axis, clamping included), so only those cells are read -- one to
+// eight of them for th below the cell edge, against the 27 of the two rings the exact walk needs before it may stop (measured on
+// the 50 k-point flight frames: 20-24 ms per 512-scene sweep with the ring walk once the vehicles fly among the cylinders,
+// where most keyframe points have their nearest current point in a NEIGHBOUR cell or none within th).  Leaves at the first point
+// within th (sqrt is monotone: the minimum is within th too).  Returns 1 = outlier, 0 = not (also when the index holds no
+// point with finite coordinates: the reference then has no result to test).  Same flags as `sqrt(grid_nn1_thread(...)) > th`
+// (tests/test_keyframe_gpu.py, test_kfmap_gpu.py).
 __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double qx, double qy, double qz, double th) {
     const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
     const double h = gs.gp[3], inv_h = gs.gp[4];
     const int g[3] = {(int)gs.gp[5], (int)gs.gp[6], (int)gs.gp[7]};
     const double q[3] = {qx, qy, qz};
     if (!(qx == qx && qy == qy && qz == qz)) return 0;
-    int c[3], rmax = 0;
+    // (the cube is widened by a rounding allowance: a point whose computed distance is <= th may be th + 1 ulp away along one axis)
+    const double r = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]) + th);
+    int lo[3], hi[3];
     for (int a = 0; a < 3; ++a) {
-        c[a] = cell_of(q[a], b[a], inv_h, g[a]);
-        rmax = max(rmax, max(c[a], g[a] - 1 - c[a]));
+        lo[a] = cell_of(q[a] - r, b[a], inv_h, g[a]);
+        hi[a] = cell_of(q[a] + r, b[a], inv_h, g[a]);
     }
-    const double slack = 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]));
-    double best = DBL_MAX;
-    for (int r = 0; r <= rmax; ++r) {
-        for (int dz = max(-r, -c[2]); dz <= min(r, g[2] - 1 - c[2]); ++dz) {
-            const int iz = c[2] + dz;
-            for (int dy = max(-r, -c[1]); dy <= min(r, g[1] - 1 - c[1]); ++dy) {
-                const int iy = c[1] + dy;
-                const int rowbase = (iz * g[1] + iy) * g[0];
-                const bool face = (dy == -r || dy == r || dz == -r || dz == r);
-                const int x0 = c[0] - r, x1 = c[0] + r;
-                for (int pt = 0; pt < 2 * gs.nt; ++pt) {   // (part, tile)
-                    const int part = pt & 1;
-                    const int *cst = gs.cs + (size_t)(pt >> 1) * (kGridMaxCells + 2);
-                    int s0, s1;
-                    if (face) {
-                        if (part == 1) continue;
-                        const int a0 = max(x0, 0), a1 = min(x1, g[0] - 1);
-                        if (a0 > a1) break;
-                        s0 = cst[rowbase + a0];
-                        s1 = cst[rowbase + a1 + 1];
-                    } else {
-                        const int ix = part == 0 ? x0 : x1;
-                        if (ix < 0 || ix >= g[0] || (part == 1 && r == 0)) continue;
-                        s0 = cst[rowbase + ix];
-                        s1 = cst[rowbase + ix + 1];
-                    }
-                    for (int pos = s0; pos < s1; ++pos) {
-                        const float4 p4 = gs.pt[pos];
-                        const double d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
-                        if (sqrt(d) <= th) return 0;
-                        best = d < best ? d : best;
-                    }
+    for (int iz = lo[2]; iz <= hi[2]; ++iz)
+        for (int iy = lo[1]; iy <= hi[1]; ++iy) {
+            const int rowbase = (iz * g[1] + iy) * g[0];
+            for (int t = 0; t < gs.nt; ++t) {   // the run of cells [lo x, hi x] of this row, tile by tile
+                const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
+                const int s0 = cst[rowbase + lo[0]], s1 = cst[rowbase + hi[0] + 1];
+                for (int pos = s0; pos < s1; ++pos) {
+                    const float4 p4 = gs.pt[pos];
+                    if (sqrt(sq_dist(qx, qy, qz, p4.x, p4.y, p4.z)) <= th) return 0;
                 }
             }
         }
-        if (best < DBL_MAX) {
-            double dmin = DBL_MAX;
-            for (int a = 0; a < 3; ++a) {
-                if (c[a] - r > 0) dmin = fmin(dmin, fmax(0.0, q[a] - (b[a] + (double)(c[a] - r) * h)));
-                if (c[a] + r < g[a] - 1) dmin = fmin(dmin, fmax(0.0, (b[a] + (double)(c[a] + r + 1) * h) - q[a]));
-            }
-            if (dmin == DBL_MAX) break;
-            dmin = fmax(0.0, dmin - slack);
-            if (dmin > th || best < dmin * dmin) break;   // nothing unvisited is within th / nearer than the best
-        }
+    int finite = 0;   // an outlier needs a nearest point at all: does the index hold a point with finite coordinates?
+    for (int t = 0; t < gs.nt; ++t) {
+        const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
+        finite += cst[g[0] * g[1] * g[2]] - cst[0];   // (bucket ncell is the trash bucket of the non-finite points)
     }
-    return best < DBL_MAX && sqrt(best) > th ? 1 : 0;
+    return finite > 0 ? 1 : 0;
 }
 
 }  // namespace amk

@@ -17,6 +17,7 @@
 // A frame is only STAGED by submit() until its gang is full; wait() / drain() launch a partly filled gang.
 #include "mpc_handle.h"
 
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -330,6 +331,10 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         keep[g] = s.dcount.p + o;
     }
     // FrameKDMap::AddVertex: obstacle index and edge index of every frame (FrameKDMap.cpp:44-47)
+    static const bool trace_host = [] { const char *e = std::getenv("AMK_PIPELINE_TRACE"); return e && e[0] == '1'; }();
+    auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_h0 = trace_host ? now_us() : 0.0;
+    double t_h1 = 0.0, t_h2 = 0.0;
     if (s.map) {   // ... into the slot's keyframe map: the scenes' own physical slots, mCurFrame.Twc, then KeyframeThreadWorker's body
         for (int g = 0; g < filled; ++g) {
             const amk_pipeline::Staged &f = s.open[g];
@@ -339,7 +344,9 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
             rc = amk_kfmap_add_vertex(s.map, g * S, S, cl[g], cc[g], ed[g], ec[g], s.point_stride, twc, st);
             if (rc != AMK_OK) return rc;
         }
+        if (trace_host) t_h1 = now_us();
         rc = amk_kfmap_update(s.map, st);
+        if (trace_host) t_h2 = now_us();
     } else if (G == 1 && !any_depth) rc = amk_kd_build_pair(s.obstacle, cl[0], cc[0], s.edge, ed[0], ec[0], s.point_stride, st);
     else rc = amk::kd_build_gang(s.obstacle, s.edge, filled, S, cl, cc, ed, ec, s.point_stride, st, any_depth ? keep : nullptr);
     if (rc != AMK_OK) return rc;
@@ -374,6 +381,9 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
         rc = amk_step_batch(s.obstacle, s.edge, s.mpc, &c.step, sq, px, s.ref_path.p, u, s.x0array.p, s.flags.p, st);
     }
     s.mpc->run_scenes = 0;
+    if (trace_host)   // diagnostics (AMK_PIPELINE_TRACE=1): host microseconds spent enqueueing the stages of this launch
+        fprintf(stderr, "amk_pipeline launch: add_vertex %.0f us, map update %.0f us, step %.0f us (host enqueue time)\n", t_h1 - t_h0,
+                t_h2 - t_h1, now_us() - (s.map ? t_h2 : t_h0));
     if (rc != AMK_OK) return rc;
     if (G > 1 || any_task) {
         ScatterArgs sa{};
@@ -403,7 +413,12 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
 // failure.  The round robin moves on either way.
 int launch_slot(amk_pipeline *p, amk_pipeline::Slot &s) {
     if (s.open.empty()) return AMK_OK;
+    static const bool trace_host = [] { const char *e = std::getenv("AMK_PIPELINE_TRACE"); return e && e[0] == '1'; }();
+    const auto t0 = std::chrono::steady_clock::now();
     const int st = launch_gang(p, s);
+    if (trace_host)
+        fprintf(stderr, "amk_pipeline launch_gang total: %.0f us (host)\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
     if (st != AMK_OK) {
         // What had been enqueued before the failure stays enqueued: a TASK frame's GetInitPath may already have shifted the slot's
         // mRefPath, its warm start may have been reset, a depth frame's Twc may have moved on.  The slot's persistent
@@ -547,7 +562,12 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     // the event about to be re-recorded belongs to the launch issued `depth` launches ago.  depth 1 = at most one launch per
     // slot on the device (every launch then pays the host's reaction time between its predecessor's end and its own start).
     if (s.open.empty() && s.count - s.waited >= p->depth) {
+        static const bool trace_host = [] { const char *e = std::getenv("AMK_PIPELINE_TRACE"); return e && e[0] == '1'; }();
+        const auto t0 = std::chrono::steady_clock::now();
         const int ws = wait_event(s.done[s.count % p->depth]);
+        if (trace_host)
+            fprintf(stderr, "amk_pipeline submit: waited %.0f us for the launch issued %d launches ago on slot %d\n",
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), p->depth, si);
         if (ws != AMK_OK) return ws;
         s.waited = s.count - p->depth + 1;
     }
