@@ -720,6 +720,9 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
         lo[a] = cell_of(q[a] - r, b[a], inv_h, g[a]);
         hi[a] = cell_of(q[a] + r, b[a], inv_h, g[a]);
     }
+    // sqrt(d) <= th is decided without the square root except in a band of relative width 2e-15 around th^2 (the correctly rounded
+    // sqrt and the rounded square differ from the real ones by < 2.3e-16 relative: outside the band both tests agree)
+    const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
     for (int iz = lo[2]; iz <= hi[2]; ++iz)
         for (int iy = lo[1]; iy <= hi[1]; ++iy) {
             const int rowbase = (iz * g[1] + iy) * g[0];
@@ -728,7 +731,8 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
                 const int s0 = cst[rowbase + lo[0]], s1 = cst[rowbase + hi[0] + 1];
                 for (int pos = s0; pos < s1; ++pos) {
                     const float4 p4 = gs.pt[pos];
-                    if (sqrt(sq_dist(qx, qy, qz, p4.x, p4.y, p4.z)) <= th) return 0;
+                    const double d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
+                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) return 0;
                 }
             }
         }
