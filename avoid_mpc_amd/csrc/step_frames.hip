@@ -449,9 +449,16 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     }
     amk_frame_camera c{};
     if (cam) c = *cam;
+    // the merge keeps ceil(F K / 64) candidates per lane in registers: instantiated for 1 / 2 / 4 / 16 (a 4-frame map with K = 8 needs
+    // ONE; the 16-wide instantiation carries 32 key registers and 16 x unrolled selection loops: 204 VGPRs against 70-odd)
     const bool wide = F * K > 64 * kMaxCandPerLane || (g_force_wide && !any_exact);   // (only a keyframe map can be: F <= AMK_MAX_MAP_FRAMES)
-    auto merge_kernel = wide ? step_merge_plan_pack_kernel<false, kMaxCandPerLaneMap>
-                             : (any_exact ? step_merge_plan_pack_kernel<true> : step_merge_plan_pack_kernel<false>);
+    const int need_cpl = (F * K + 63) / 64;
+    auto merge_kernel = step_merge_plan_pack_kernel<false, kMaxCandPerLane>;
+    if (wide) merge_kernel = step_merge_plan_pack_kernel<false, kMaxCandPerLaneMap>;
+    else if (any_exact) merge_kernel = step_merge_plan_pack_kernel<true>;
+    else if (need_cpl <= 1) merge_kernel = step_merge_plan_pack_kernel<false, 1>;
+    else if (need_cpl <= 2) merge_kernel = step_merge_plan_pack_kernel<false, 2>;
+    else if (need_cpl <= 4) merge_kernel = step_merge_plan_pack_kernel<false, 4>;
     hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
     const int S8 = (S + 7) / 8 * 8;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {

@@ -54,9 +54,9 @@ def measured_hbm_peak(torch, lib, gib=1.0, reps=10):
     src.fill_(1)
     torch.cuda.synchronize()
     ms = C.c_double()
-    lib.amk__hbm_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+    lib.amk__hbm_copy_probe.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
     lib.amk__hbm_copy_probe.restype = C.c_int
-    rc = lib.amk__hbm_copy_probe(src.data_ptr(), dst.data_ptr(), nb, reps, None, C.byref(ms))
+    rc = lib.amk__hbm_copy_probe(src.data_ptr(), dst.data_ptr(), nb, reps, None, C.byref(ms), None)
     assert rc == 0, rc
     del src, dst
     torch.cuda.empty_cache()
@@ -899,8 +899,9 @@ def main():
             "hbm_peak_vendor_gbs": HBM_PEAK_GBS,
             "hbm_peak_measured_gbs": None if not hbm_measured else round(hbm_measured, 1),
             "hbm_peak_measured_how": "float4 device copy of 1 GiB (amk__hbm_copy_probe, csrc/probe.hip): bytes read + bytes written "
-                                     "over the copy's duration, 10 repetitions, HIP events; every HBM fraction of this line is given "
-                                     "against the vendor peak (frac) and against this figure (frac_of_measured_copy)",
+                                     "over the copy's duration, best of 18 launch shapes (2 / 4 / 8 loads in flight per thread, plain / "
+                                     "non-temporal, 8 / 16 / 32 blocks per CU), 10 repetitions each, HIP events; every HBM fraction of "
+                                     "this line is given against the vendor peak (frac) and against this figure (frac_of_measured_copy)",
             "kernels_single_stream": lone,
             "parity": parity,
             "cpu_baseline": cpu,

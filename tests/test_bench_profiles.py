@@ -1,6 +1,6 @@
-"""CPU: the committed bench line (profiles/r04_bench.json) carries the contract's fields, and every roofline fraction in it
-follows from the committed rocprofv3 summaries of the same commands (profiles/r04_kernel_stats_streams1.json, r04_pmc_*.json)
-within 10 % -- VERDICT r2 item 2, kept current every round ("my recomputation from profiles/r04_* lands within 10 % of every frac")."""
+"""CPU: the committed bench line (profiles/r05_bench.json) carries the contract's fields, and every roofline fraction in it
+follows from the committed rocprofv3 summaries of the same commands (profiles/r05_kernel_stats_streams1.json, r05_pmc_*.json)
+within 10 % -- VERDICT r2 item 2, kept current every round ("my recomputation from profiles/r05_* lands within 10 % of every frac")."""
 import json
 import os
 
@@ -9,16 +9,16 @@ P = lambda n: json.load(open(os.path.join(ROOT, "profiles", n)))
 
 
 def test_bench_line_has_the_contract_fields_and_consistent_rooflines():
-    line = P("r04_bench.json")["default_run"]
+    line = P("r05_bench.json")["default_run"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
         assert k in line, k
     assert line["n_gpus"] == 1 and line["dtype"] == "f64" and line["scaling"] == "weak" and line["vs_baseline"] is None
     assert "workload" in line["config"] and line["config"]["scenes_per_gpu"] == 256 and line["config"]["points"] == 50000
     assert abs(line["value"] - 256 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) / line["value"] < 1e-3
-    kt1 = P("r04_kernel_stats_streams1.json")["kernels"]
-    issue = P("r04_pmc_solve_issue.json")
-    traffic = P("r04_pmc_traffic.json")["kernels"]
+    kt1 = P("r05_kernel_stats_streams1.json")["kernels"]
+    issue = P("r05_pmc_solve_issue.json")
+    traffic = P("r05_pmc_traffic.json")["kernels"]
     within = lambda a, b, tol=0.10: abs(a - b) <= tol * abs(b)
     # dominant kernel, HBM view: algorithmic bytes / rocprof's single-stream duration / 8 TB/s
     h = line["roofline_hbm"]
@@ -41,6 +41,12 @@ def test_bench_line_has_the_contract_fields_and_consistent_rooflines():
     assert within(b["traffic"], traffic["kd_build_kernel"]["hbm_bytes_per_launch_x2"], 0.02)
     w = line["roofline_whole_step"]
     assert within(w["frac"], line["value"] * 670544 / 8e12, 1e-3)
+    # the achievable HBM rate (a measured device copy) beside the vendor peak, and every HBM fraction against both
+    m = line["hbm_peak_measured_gbs"]
+    assert line["hbm_peak_vendor_gbs"] == 8000.0 and 3000.0 < m < 8000.0
+    assert within(b["frac_of_measured_copy"], b["achieved"] / m, 1e-3) and within(h["frac_of_measured_copy"], h["achieved"] / m, 1e-2)
+    assert within(w["frac_of_measured_copy"], line["value"] * 670544 / (m * 1e9), 1e-3)
+    assert b["frac"] < b["frac_of_measured_copy"] <= 1.05
     # parity and baseline blocks
     fx = line["parity"]["fixtures"]
     assert fx["ok"] and all(fx[c]["converged"] == 64 and fx[c]["du_max"] <= 1e-3 for c in ("C1", "C2", "C5"))
