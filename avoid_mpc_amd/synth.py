@@ -57,6 +57,8 @@ CONFIGS = {
     "C1": dict(n=5000, T=0.33, K=3),
     "C2": dict(n=50000, T=0.66, K=8),
     "C5": dict(n=200000, T=1.0, K=8),
+    # the reference's own default problem (mpc_parameters.yaml:1-2,5,59-63): N = 30, K = 3, 640 x 480 / 10 -> <= 3072-point frames
+    "YAML": dict(n=3072, T=1.0, K=3),
 }
 
 

@@ -327,20 +327,24 @@ DEPTH_CAM = dict(rows=240, cols=320, pixel2meter=1e-3, depth_min=0.1, depth_max=
                  cy=120.0, Tbc=flight.TBC_YAML)
 
 
-def _depth_frame(world, x):
+YAML_CAM = dict(rows=480, cols=640, pixel2meter=1e-3, depth_min=0.1, depth_max=100.0, resize_scale=10.0, fx=320.0, fy=320.0, cx=320.0,
+                cy=240.0, Tbc=flight.TBC_YAML)   # mpc_parameters.yaml:59-70: the reference's own sensor, 640 x 480 / 10 -> <= 3072 points
+
+
+def _depth_frame(world, x, cam=None):
     """(depth uint16 [rows, cols] in millimetres, Twb) as the depth callback would hand them over: the pose is the odometry rounded
     to a micrometre, so that two drivers whose states agree to 1e-9 m render identical images."""
-    c = DEPTH_CAM
+    c = cam or DEPTH_CAM
     Twb = np.eye(4); Twb[:3, 3] = np.round(x[0:3], 6)          # Command.yaw = 0 holds the heading: R = I
     sel = (world.cx > x[0] - 2.0) & (world.cx < x[0] + 40.0)
     d = flight.render_depth((world.cx[sel], world.cy[sel], world.cr[sel]), Twb, c["Tbc"], c["rows"], c["cols"], c["fx"], c["fy"], c["cx"], c["cy"])
     return np.clip(np.round(d / c["pixel2meter"]), 0, 65535).astype(np.uint16), Twb
 
 
-def depth_camera():
+def depth_camera(cam=None):
     """PtIsInFrame's camera for DEPTH_CAM: the intrinsics divided by the resize scale (FrameKDMap.cpp:21-24), the down-scaled image
     size of ProcessDepth (:106-107).  -> (fx, fy, cx, cy, depth_max, width, height)"""
-    c = DEPTH_CAM
+    c = cam or DEPTH_CAM
     sc = c["resize_scale"]
     return (c["fx"] / sc, c["fy"] / sc, c["cx"] / sc, c["cy"] / sc, c["depth_max"], int(c["cols"] / sc), int(c["rows"] / sc))
 
@@ -348,6 +352,7 @@ def depth_camera():
 def _oracle_depth_flight(job):
     seed, cfg, periods, world_kw = job[:4]
     map_kw = job[4] if len(job) > 4 else None     # dict(max_frame_count, th_dist, th_count): fly with the keyframe map
+    DEPTH_CAM = (job[5] if len(job) > 5 else None) or globals()["DEPTH_CAM"]   # the sensor (default: the test sensor)
     from tests import _oracle
     prm, _ = make_prm(cfg)
     world = flight.FlightWorld(seed, prm, 1000, **world_kw)
@@ -364,7 +369,7 @@ def _oracle_depth_flight(job):
         log["n_keyframes"] = np.zeros(periods, np.int32); log["n_query_frames"] = np.zeros(periods, np.int32)
         log["outliers"] = np.zeros(periods, np.int32); log["map_points"] = np.zeros(periods, np.int64)
     for t in range(periods):
-        img, Twb = _depth_frame(world, x)
+        img, Twb = _depth_frame(world, x, DEPTH_CAM)
         cloud, _ = _oracle.depth_oracle(img, DEPTH_CAM, Twb)
         if kmap is not None:
             if len(cloud):                                      # AddVertex (:39-51), then KeyframeThreadWorker's body (:443-486)
@@ -376,7 +381,7 @@ def _oracle_depth_flight(job):
             log["map_points"][t] = int(np.sum(sizes))
             log["n_cloud"][t] = kmap.cur.kd.size(); log["n_edge"][t] = kmap.cur.ke.size()
             sq, px = flight.period_inputs(x[None], ref[None], prm)
-            r = kmap.step(mpc, prm, sq[0], px[0], ref, depth_camera())
+            r = kmap.step(mpc, prm, sq[0], px[0], ref, depth_camera(DEPTH_CAM))
         else:
             if len(cloud):                                          # AddVertex, FrameKDMap.cpp:39-51
                 edge = _oracle.depth_edge_oracle(img, DEPTH_CAM, Twc)[0]
@@ -394,22 +399,22 @@ def _oracle_depth_flight(job):
     return log
 
 
-def oracle_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, workers=None, keyframes=None):
+def oracle_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, workers=None, keyframes=None, cam=None):
     """keyframes: dict(max_frame_count, th_dist, th_count) flies with FrameKDMap's keyframe list (tests/_kfmap.py) and logs
     n_keyframes / n_query_frames / outliers / map_points per period."""
     from tests import _oracle
     _oracle.build_oracle()
-    jobs = [(int(s), cfg, periods, world_kw or {}, keyframes) for s in seeds]
+    jobs = [(int(s), cfg, periods, world_kw or {}, keyframes, cam) for s in seeds]
     return _stack(_pool_map(_oracle_depth_flight, jobs, workers or usable_cores()))
 
 
-def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=None, keyframes=None):
+def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=None, keyframes=None, cam=None):
     """The same flights through amk_pipeline frames that START at the depth image (d_depth + d_Twb) in TASK mode.
     keyframes: dict(max_frame_count, th_dist, th_count): every slot keeps a keyframe map (amk_pipeline_config.keyframes)."""
     import torch
     from avoid_mpc_amd.host import Pipeline, depth_params
     prm, _ = make_prm(cfg)
-    c = DEPTH_CAM
+    c = cam or DEPTH_CAM
     F = len(seeds); B = batch or F; nb = F // B
     assert F % B == 0 and nb % gang == 0
     dev = torch.device("cuda", torch.cuda.current_device())
@@ -431,7 +436,7 @@ def gpu_depth_flights(seeds, cfg="C1", periods=40, world_kw=None, gang=1, batch=
         keep, tickets = [], []
         for b in range(nb):
             sl = slice(b * B, (b + 1) * B)
-            fr = [_depth_frame(worlds[i], x[i]) for i in range(sl.start, sl.stop)]
+            fr = [_depth_frame(worlds[i], x[i], c) for i in range(sl.start, sl.stop)]
             depth = torch.from_numpy(np.stack([d for d, _ in fr]).view(np.int16)).to(dev)
             Twb = torch.from_numpy(np.stack([T for _, T in fr])).to(dev)
             odom = torch.from_numpy(x[sl]).to(dev); cmd = torch.empty((B, 3), dtype=torch.float64, device=dev)

@@ -160,3 +160,24 @@ def test_flights_with_the_keyframe_map(max_frames, gang, batch):
         upto = P if sep[f] < 0 else sep[f]
         for key in ("n_keyframes", "n_query_frames", "outliers", "map_points", "n_cloud"):
             assert np.array_equal(g[key][f, :upto], o[key][f, :upto]), (f, key, np.nonzero(g[key][f, :upto] != o[key][f, :upto])[0][:5])
+
+
+def test_a_flight_with_the_reference_yaml_configuration():
+    """The reference's own default configuration end to end (mpc_parameters.yaml): 640 x 480 depth images down-scaled by 10
+    (<= 3072-point frames), N = 30 (T = 1.0, dt = 0.033), nearest_point_num = 3, keyframe_th_dist 0.1, keyframe_th_count 10,
+    max_frame_count = 100 -- the pool holds 102 index slots per robot and the step runs over up to 101 query frames.  4 flights x
+    45 periods through the pipeline against the oracle's map."""
+    seeds = list(range(2400, 2404))
+    kw = dict(cyl_per_m=0.6, x_first=3.0, length=60.0)
+    kf = dict(max_frame_count=100, th_dist=0.1, th_count=10)
+    P = 45
+    o = _flight.oracle_depth_flights(seeds, "YAML", P, world_kw=kw, keyframes=kf, cam=_flight.YAML_CAM, workers=1)
+    g = _flight.gpu_depth_flights(seeds, "YAML", P, world_kw=kw, gang=2, batch=2, keyframes=kf, cam=_flight.YAML_CAM)
+    cmp = _flight.compare(g, o, pos_tol=1e-6)
+    print("\nyaml configuration, max_frame_count 100:", {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")},
+          "keyframes (mean / max):", float(o["n_keyframes"].mean()), int(o["n_keyframes"].max()), "query frames (max):",
+          int(o["n_query_frames"].max()), "points per frame:", float(o["n_cloud"].mean()))
+    assert cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] == 0
+    assert o["n_query_frames"].max() >= 4 and o["n_cloud"].max() <= 3072
+    for key in ("n_keyframes", "n_query_frames", "outliers", "map_points", "n_cloud"):
+        assert np.array_equal(g[key], o[key]), key
