@@ -15,7 +15,7 @@ base=torch.from_numpy(synth.make_cloud(n,7)[0]).cuda()
 for s in range(S): cl[s]=base[torch.randperm(n,device='cuda')]
 streams=[torch.cuda.Stream() for _ in range(NS)]
 mpcs=[MpcBatch(prm.T,prm.dt,prm.K,S) for _ in range(NS)]
-for m in mpcs: m.configure(prm)
+for m in mpcs: m.configure(prm); m.set_precision(int(os.environ.get("AMK_PREC","64")))
 kds=[KdBatch(S,n) for _ in range(NS)]
 outs=[(torch.empty((S,4),dtype=torch.float64,device='cuda'),torch.empty((S,4),dtype=torch.int32,device='cuda')) for _ in range(NS)]
 import ctypes as C
