@@ -1,4 +1,6 @@
-"""Closed-loop flights around the control step: the regime the reference actually runs in.
+"""BENCH AND TEST HARNESS (not part of the product path): closed-loop flights around the control step -- the world, the sensor
+frames, the vehicle and the host twins of the TASK prologue / epilogue that bench.py --workload flight and tests/_flight.py share.
+Nothing under csrc/ or include/ depends on it.
 
 The reference is a 30 Hz loop (timer of con_dt = 0.033 s, AM/src/AvoidanceStateMachine.cpp:110-111,
 AM/launch/mpc_obstacle_avoidance_sim.launch:8): every period takes a fresh depth frame
