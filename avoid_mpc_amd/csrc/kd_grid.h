@@ -744,85 +744,4 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
     return finite > 0 ? 1 : 0;
 }
 
-
-// The same answer for the 64 queries of a WAVEFRONT (the keyframe sweep's kernel, kd_index.hip).  A lane that meets a point within th
-// is done after a handful of tests -- but a query WITHOUT one (an outlier, or one whose only neighbour sits late in a bucket) reads every
-// candidate of its cube, a few hundred, and the wavefront lasts as long as its slowest lane.  So: phase 1, every lane on its own query,
-// gives up after kSweepLaneBudget tests; phase 2, the undecided queries one at a time by the whole wavefront -- lane j scans candidate
-// run j (a run = the cube's cells of one row in one tile: a handful of points), one ballot decides.  `active`: this lane holds a query.
-// Returns the lane's flag (1 = outlier); same flags as grid_outlier_thread.
-constexpr int kSweepLaneBudget = 16;
-__device__ __forceinline__ int grid_outlier_wave(const GridScene &gs, bool active, double qx, double qy, double qz, double th) {
-    const int lane = threadIdx.x & 63;
-    const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
-    const double h = gs.gp[3], inv_h = gs.gp[4];
-    const int g[3] = {(int)gs.gp[5], (int)gs.gp[6], (int)gs.gp[7]};
-    const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
-    auto within = [&](const float4 &p4, double x, double y, double z) {
-        const double d = sq_dist(x, y, z, p4.x, p4.y, p4.z);
-        return d <= t2lo || (d <= t2hi && sqrt(d) <= th);
-    };
-    // does the index hold a point with finite coordinates at all?  (bucket ncell of every tile is the trash bucket)
-    int fin = 0;
-    if (lane < gs.nt) {
-        const int *cst = gs.cs + (size_t)lane * (kGridMaxCells + 2);
-        fin = cst[g[0] * g[1] * g[2]] - cst[0];
-    }
-    const bool any_finite = __ballot(fin > 0) != 0ull;
-    const bool valid = active && qx == qx && qy == qy && qz == qz;
-    const double q[3] = {qx, qy, qz};
-    int lo[3] = {0, 0, 0}, hi[3] = {-1, -1, -1};
-    if (valid) {
-        const double r = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + fabs(b[0]) + fabs(b[1]) + fabs(b[2]) + th);
-        for (int a = 0; a < 3; ++a) {
-            lo[a] = cell_of(q[a] - r, b[a], inv_h, g[a]);
-            hi[a] = cell_of(q[a] + r, b[a], inv_h, g[a]);
-        }
-    }
-    // ---- phase 1: every lane on its own query, at most kSweepLaneBudget tests
-    int state = valid ? 2 : 0;   // 0: not an outlier (inlier / no query / NaN), 1: outlier, 2: undecided
-    if (valid) {
-        int tested = 0;
-        bool found = false, gave_up = false;
-        for (int iz = lo[2]; iz <= hi[2] && !found && !gave_up; ++iz)
-            for (int iy = lo[1]; iy <= hi[1] && !found && !gave_up; ++iy) {
-                const int rowbase = (iz * g[1] + iy) * g[0];
-                for (int t = 0; t < gs.nt && !found && !gave_up; ++t) {
-                    const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
-                    const int s0 = cst[rowbase + lo[0]], s1 = cst[rowbase + hi[0] + 1];
-                    for (int pos = s0; pos < s1; ++pos) {
-                        if (within(gs.pt[pos], qx, qy, qz)) { found = true; break; }
-                        if (++tested >= kSweepLaneBudget) { gave_up = true; break; }
-                    }
-                }
-            }
-        state = found ? 0 : (gave_up ? 2 : (any_finite ? 1 : 0));
-    }
-    // ---- phase 2: the undecided queries, one at a time, by the whole wavefront
-    unsigned long long todo = __ballot(state == 2);
-    while (todo) {
-        const int L = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const double ux = __shfl(qx, L), uy = __shfl(qy, L), uz = __shfl(qz, L);
-        const int l0 = __shfl(lo[0], L), l1 = __shfl(lo[1], L), l2 = __shfl(lo[2], L);
-        const int h0 = __shfl(hi[0], L), h1 = __shfl(hi[1], L), h2 = __shfl(hi[2], L);
-        const int ny = h1 - l1 + 1, nrows = ny * (h2 - l2 + 1), nruns = nrows * gs.nt;
-        bool found = false;
-        for (int base = 0; base < nruns && !__ballot(found); base += 64) {
-            const int rid = base + lane;
-            if (rid < nruns) {
-                const int t = rid % gs.nt, row = rid / gs.nt;
-                const int iy = l1 + row % ny, iz = l2 + row / ny;
-                const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
-                const int rowbase = (iz * g[1] + iy) * g[0];
-                const int s0 = cst[rowbase + l0], s1 = cst[rowbase + h0 + 1];
-                for (int pos = s0; pos < s1 && !found; ++pos) found = within(gs.pt[pos], ux, uy, uz);
-            }
-        }
-        const bool any = __ballot(found) != 0ull;
-        if (lane == L) state = any ? 0 : (any_finite ? 1 : 0);
-    }
-    return state;
-}
-
 }  // namespace amk

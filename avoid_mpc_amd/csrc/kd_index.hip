@@ -470,13 +470,16 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
     const int sc = cur_list ? cur_list[blockIdx.y] : s;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     const int n = ksizes[s];
-    if ((int)(blockIdx.x * blockDim.x) >= n) return;   // (block-uniform; the wavefronts of the last block run with idle lanes)
-    const bool active = i < n;
-    const float4 rec = active ? KGP[(size_t)s * kcap + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-    int f = 0;
-    if (cur_sizes[sc] > 1)   // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
-        f = amk::grid_outlier_wave(cur.scene(sc), active, (double)rec.x, (double)rec.y, (double)rec.z, th_dist);
-    if (active) flags[(size_t)s * kcap + __float_as_int(rec.w)] = (unsigned char)f;
+    if (i >= n) return;
+    const float4 rec = KGP[(size_t)s * kcap + i];
+    unsigned char f = 0;
+    if (cur_sizes[sc] > 1) {  // SearchForNearest(pt, 1) yields a result only then (kd_tree_two.h:119-124)
+        // (a wave-cooperative second phase for the queries that find no neighbour quickly -- lane j scanning candidate run j of one
+        // undecided query at a time -- was built and measured SLOWER: 8.3 ms per 512-scene sweep against 5.2-6.2; the runs of a
+        // 13-tile index hold ~5 points each, the phase was all bookkeeping)
+        f = (unsigned char)amk::grid_outlier_thread(cur.scene(sc), (double)rec.x, (double)rec.y, (double)rec.z, th_dist);
+    }
+    flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
 }
 
 // one block per scene: count the outliers; with >= th_count of them compact the keyframe's planes in place
