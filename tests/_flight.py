@@ -131,13 +131,19 @@ def usable_cores():
     return cores
 
 
-def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None, task_kw=None):
+CLOUD_CAM = (32.0, 32.0, 32.0, 24.0, 100.0, 64, 48)   # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor along +x
+
+
+def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None, task_kw=None, keyframes=None):
     """-> dict of arrays [F, ...]: x [F, periods + 1, 10], u, flags, cmd, clearance [F, periods + 1].
-    task_kw: dict(task="global_goal", global_goal=[F, 3]) flies GetInitPath's other task."""
+    task_kw: dict(task="global_goal", global_goal=[F, 3]) flies GetInitPath's other task.
+    keyframes: dict(max_frame_count, th_dist, th_count) flies with FrameKDMap's keyframe list (mCurFrame.Twc = the odometry
+    position, R = I, Tbc = I; PtIsInFrame through CLOUD_CAM) and logs n_keyframes / n_query_frames."""
     from tests import _oracle
     _oracle.build_oracle()
     tk = lambda i: {} if not task_kw else dict(task=task_kw["task"], global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[i])
-    jobs = [(int(s), cfg, periods, n_points, world_kw or {}, tk(i)) for i, s in enumerate(seeds)]
+    mk = dict(keyframes, depth_min=0.1, cam=CLOUD_CAM) if keyframes else None
+    jobs = [(int(s), cfg, periods, n_points, world_kw or {}, tk(i), mk) for i, s in enumerate(seeds)]
     return _stack(_pool_map(_oracle_flight, jobs, workers or usable_cores()))
 
 
@@ -154,7 +160,7 @@ def oracle_flights_on_frames(clouds, edges, x0, ref0, T, K, cyl=None, workers=No
 
 
 def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batch=None, tie_order=0, precision=64, mode="host",
-                gang=1, task_kw=None):
+                gang=1, task_kw=None, keyframes=None):
     """The same flights through amk_pipeline_*: one (slot, gang position) per batch of flights, one submit(keep_warm_start) per
     period.  mode "host": GetInitPath / clock model / command on the host (avoid_mpc_amd/flight.py), the pipeline gets
     state_quad, pos_x and the shifted path; mode "task": the pipeline's TASK mode -- the slot keeps mRefPath, the caller hands
@@ -174,7 +180,12 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
     x = np.stack([a for a, _ in st]); ref = np.stack([b for _, b in st])
     task = (task_kw or {}).get("task", "forward")
     goal = None if not task_kw or task_kw.get("global_goal") is None else np.ascontiguousarray(task_kw["global_goal"], np.float64)
-    pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang, task=task)
+    from avoid_mpc_amd import capi
+    pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang, task=task,
+                  keyframes=dict(keyframes, depth_min=0.1) if keyframes else None)
+    kcam = capi.FrameCamera(*CLOUD_CAM[:5], int(CLOUD_CAM[5]), int(CLOUD_CAM[6])) if keyframes else None
+    if keyframes:
+        logs_kf = dict(n_keyframes=np.zeros((F, periods), np.int32), n_query_frames=np.zeros((F, periods), np.int32))
     for i in range(nb // gang):
         pl.kd(i, 0).set_tie_order(tie_order); pl.kd(i, 1).set_tie_order(tie_order); pl.mpc(i).set_precision(precision)
     goal_d = None if goal is None else torch.from_numpy(goal).to(dev)
@@ -189,16 +200,20 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
             sl = slice(b * B, (b + 1) * B)
             fr = [worlds[i].frame(t) for i in range(sl.start, sl.stop)]
             clouds = torch.from_numpy(np.stack([c for c, _ in fr])).to(dev); edges = torch.from_numpy(np.stack([e for _, e in fr])).to(dev)
+            Twc = None
+            if keyframes:   # mCurFrame.Twc of the frame: the odometry position, R = I (Tbc = I)
+                Tw = np.tile(np.eye(4), (B, 1, 1)); Tw[:, :3, 3] = x[sl, 0:3]
+                Twc = torch.from_numpy(Tw).to(dev)
             if mode == "host":
                 bufs = (clouds, edges, torch.from_numpy(sq[sl]).to(dev), torch.from_numpy(px[sl]).to(dev), torch.from_numpy(ref[sl]).to(dev))
-                keep.append(bufs)
-                tickets.append(pl.submit(*bufs, keep_warm_start=t > 0))
+                keep.append(bufs + (Twc,))
+                tickets.append(pl.submit(*bufs, keep_warm_start=t > 0, Twc_cur=Twc, cam=kcam))
             else:
                 odom = torch.from_numpy(x[sl]).to(dev); cmd = torch.empty((B, 3), dtype=torch.float64, device=dev)
                 ref0 = torch.from_numpy(ref[sl]).to(dev) if t == 0 else None     # InitCircleState's role; afterwards the slot's own
-                keep.append((clouds, edges, odom, cmd, ref0))
+                keep.append((clouds, edges, odom, cmd, ref0, Twc))
                 tickets.append(pl.submit(clouds, edges, ref_path_init=ref0, odom=odom, cmd_out=cmd, keep_warm_start=t > 0,
-                                         global_goal=None if goal_d is None else goal_d[sl]))
+                                         global_goal=None if goal_d is None else goal_d[sl], Twc_cur=Twc, cam=kcam))
         for b, tk in enumerate(tickets):
             sl = slice(b * B, (b + 1) * B)
             pl.wait(tk)
@@ -211,8 +226,14 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
                 a = a_dev
             x[sl] = flight.apply_command(x[sl], a, prm)
             logs["u"][sl, t] = o["u"]; logs["flags"][sl, t] = o["flags"]; logs["cmd"][sl, t] = a
+            if keyframes:
+                ms = pl.kfmap_state(tk % pl.n_slots)
+                ps = slice((tk // pl.n_slots) * B, (tk // pl.n_slots + 1) * B)
+                logs_kf["n_keyframes"][sl, t] = ms["n_keyframes"][ps]; logs_kf["n_query_frames"][sl, t] = ms["n_query_frames"][ps]
         logs["x"][:, t + 1] = x
     pl.close()
+    if keyframes:
+        logs.update(logs_kf)
     logs["clearance"] = np.stack([w.clearance(logs["x"][i, :, 0:3]) for i, w in enumerate(worlds)])
     return logs
 

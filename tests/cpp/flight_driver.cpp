@@ -4,7 +4,10 @@
 // command back (PubCmd / PubSlowDownCmd, :345-350,369-397); GetInitPath, GetCurStateQuad, the re-plan loop and the warm start
 // live in the slot (include/avoid_mpc_amd.h: amk_pipeline_frame.d_odom).  The vehicle here is the test's: the MPC's own model, RK4 x 4 (avoid_mpc_amd/flight.py: plant_step, statement by statement).
 // Driven by tests/test_flight_gpu.py, which flies the same flights through the Python driver and compares bit for bit.
-//   flight_driver <in.bin> <out.bin>
+//   flight_driver <in.bin> <out.bin> [max_frame_count]
+// With max_frame_count > 0 every robot flies with FrameKDMap's keyframe list in the slot (amk_pipeline_config.keyframes: the
+// reference's default regime, FrameKDMap.cpp:29-32): cloud frames then bring mCurFrame.Twc -- here the odometry position with R = I,
+// Tbc = I -- and PtIsInFrame's camera (the yaml's 640 x 480 / 10 sensor looking along +x).
 // in.bin : int32 S, P, n, ne, K, max_iter ; double prm[9] = T dt speed safety decay height farest kp kd ; weights[25] tau[4] gains[4]
 //          lim[5] (aMinZ aMaxZ aMaxXy aMaxYawDot radius) ; x0[S*10] ; ref0[S*N*10] ;
 //          per period: float cloud[S*n*3], edge[S*ne*3]
@@ -47,6 +50,13 @@ int main(int argc, char **argv) {
     cfg.task.decay = prm[4]; cfg.task.iter_time = 0.0; cfg.task.height = prm[5]; cfg.task.farest_point = prm[6];
     cfg.task.slow_down_kp = prm[7]; cfg.task.slow_down_kd = prm[8]; cfg.task.a_max_xy = lim[2]; cfg.task.a_max_z = lim[1];
     cfg.task.use_odom_est = 1;
+    const int max_frames = argc > 3 ? atoi(argv[3]) : 0;
+    if (max_frames > 0) {   // mpc_parameters.yaml:66,71-73
+        cfg.keyframes.max_frame_count = max_frames; cfg.keyframes.keyframe_th_count = 10; cfg.keyframes.keyframe_th_dist = 0.1;
+        cfg.keyframes.depth_min = 0.1;
+    }
+    amk_frame_camera cam;
+    cam.fx = 32.0; cam.fy = 32.0; cam.cx = 32.0; cam.cy = 24.0; cam.depth_max = 100.0; cam.width = 64; cam.height = 48;
     amk_pipeline *pl = nullptr;
     CHECK(amk_pipeline_create(&cfg, &pl));
     amk_mpc *m = amk_pipeline_mpc(pl, 0);   // SetupMPC (AvoidanceStateMachine.cpp:55-70)
@@ -58,6 +68,9 @@ int main(int argc, char **argv) {
     hipMalloc((void **)&d_cl, sizeof(float) * S * n * 3); hipMalloc((void **)&d_ed, sizeof(float) * S * ne * 3);
     hipMalloc((void **)&d_x, sizeof(double) * S * 10); hipMalloc((void **)&d_ref0, sizeof(double) * S * N * 10);
     hipMalloc((void **)&d_cmd, sizeof(double) * S * 3);
+    double *d_Twc = nullptr;
+    std::vector<double> Twc((size_t)S * 16, 0.0);
+    if (max_frames > 0) hipMalloc((void **)&d_Twc, sizeof(double) * S * 16);
     hipMemcpy(d_ref0, ref0.data(), sizeof(double) * ref0.size(), hipMemcpyHostToDevice);
     std::vector<float> cl((size_t)S * n * 3), ed((size_t)S * ne * 3);
     std::vector<double> cmd((size_t)S * 3), xn((size_t)S * 10);
@@ -73,6 +86,15 @@ int main(int argc, char **argv) {
         fr.d_cloud = d_cl; fr.d_edge = d_ed; fr.point_stride = 3;
         fr.d_odom = d_x; fr.d_cmd_out = d_cmd; fr.keep_warm_start = t > 0;
         fr.d_ref_path_init = t == 0 ? d_ref0 : nullptr;     // InitCircleState's role; afterwards the slot's own mRefPath
+        if (max_frames > 0) {   // mCurFrame.Twc of the frame (what DepthCallback's pose would give): position = odometry, R = I
+            for (int s = 0; s < S; ++s) {
+                double *T = &Twc[16 * (size_t)s];
+                for (int e = 0; e < 16; ++e) T[e] = (e % 5 == 0) ? 1.0 : 0.0;
+                T[3] = x[10 * s]; T[7] = x[10 * s + 1]; T[11] = x[10 * s + 2];
+            }
+            hipMemcpy(d_Twc, Twc.data(), sizeof(double) * Twc.size(), hipMemcpyHostToDevice);
+            fr.d_Twc_cur = d_Twc; fr.camera = &cam;
+        }
         int ticket = -1;
         CHECK(amk_pipeline_submit(pl, &fr, &ticket));
         CHECK(amk_pipeline_wait(pl, ticket));

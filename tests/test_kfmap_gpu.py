@@ -181,3 +181,66 @@ def test_a_flight_with_the_reference_yaml_configuration():
     assert o["n_query_frames"].max() >= 4 and o["n_cloud"].max() <= 3072
     for key in ("n_keyframes", "n_query_frames", "outliers", "map_points", "n_cloud"):
         assert np.array_equal(g[key], o[key]), key
+
+
+def test_cloud_frame_flights_with_the_keyframe_map_and_the_cpp_fleet_host(tmp_path):
+    """Frames handed over as clouds (+ mCurFrame.Twc = the odometry position, PtIsInFrame through the yaml's 64 x 48 camera), as
+    bench.py --workload flight --keyframes does: the pipeline's slot map against the oracle's list, host-driven and TASK mode,
+    gang 1 and 2; then a C++ host that only knows include/avoid_mpc_amd.h (tests/cpp/flight_driver.cpp with a third argument)
+    flies the same flights bit for bit."""
+    import os
+    import struct
+    import subprocess
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seeds = list(range(2600, 2616))
+    kw = dict(cyl_per_m=1.5, x_first=3.0)
+    kf = dict(max_frame_count=4, th_dist=0.1, th_count=10)
+    P, n = 50, 3072
+    o = _flight.oracle_flights(seeds, "C1", P, n_points=n, world_kw=kw, keyframes=kf)
+    assert o["n_query_frames"].max() >= 3
+    runs = {}
+    for mode, gang, batch in (("host", 1, 16), ("task", 2, 4)):
+        g = _flight.gpu_flights(seeds, "C1", P, n_points=n, world_kw=kw, batch=batch, mode=mode, gang=gang, keyframes=kf)
+        cmp = _flight.compare(g, o, pos_tol=1e-6)
+        print(f"\ncloud frames + keyframes, {mode} mode, gang {gang}:", {k: v for k, v in cmp.items() if k not in ("separation_period", "dpos_final")},
+              "keyframes mean / max:", float(o["n_keyframes"].mean()), int(o["n_keyframes"].max()))
+        assert cmp["dpos_max_while_together"] <= 1e-6 and cmp["separated"] <= 1
+        sep = cmp["separation_period"]
+        for f in range(len(seeds)):
+            upto = P if sep[f] < 0 else sep[f]
+            assert np.array_equal(g["n_keyframes"][f, :upto], o["n_keyframes"][f, :upto]) and \
+                np.array_equal(g["n_query_frames"][f, :upto], o["n_query_frames"][f, :upto]), f
+        runs[mode] = g
+    assert np.array_equal(runs["host"]["x"], runs["task"]["x"]) and np.array_equal(runs["host"]["flags"], runs["task"]["flags"])
+    # ---- the C++ fleet host with the map in its slot
+    exe = str(tmp_path / "flight_driver")
+    libdir = os.path.join(ROOT, "avoid_mpc_amd")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "flight_driver.cpp"), "-o", exe, "-L", libdir, "-lavoid_mpc_amd",
+                           f"-Wl,-rpath,{libdir}"])
+    prm, _ = _flight.make_prm("C1")
+    S, Pc = 8, 30
+    worlds = [flight.FlightWorld(s, prm, n, **kw) for s in seeds[:S]]
+    st = [flight.initial_state(s, prm) for s in seeds[:S]]
+    fin, fout = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+    with open(fin, "wb") as f:
+        f.write(struct.pack("6i", S, Pc, n, n // 10, prm.K, prm.max_iter))
+        f.write(np.array([prm.T, prm.dt, prm.speed, prm.safety_distance, prm.decay, prm.height, 500.0, 0.3, 0.3]).tobytes())
+        f.write(np.array(prm.weights, np.float64).tobytes()); f.write(np.array(prm.tau, np.float64).tobytes())
+        f.write(np.array(prm.gain, np.float64).tobytes())
+        f.write(np.array([prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot, prm.radius]).tobytes())
+        f.write(np.stack([a for a, _ in st]).tobytes()); f.write(np.stack([b for _, b in st]).tobytes())
+        for t in range(Pc):
+            fr = [w.frame(t) for w in worlds]
+            f.write(np.stack([c for c, _ in fr]).tobytes()); f.write(np.stack([e for _, e in fr]).tobytes())
+    subprocess.check_call([exe, fin, fout, str(kf["max_frame_count"])])
+    want = runs["task"]
+    buf = open(fout, "rb").read()
+    off = 0
+    for t in range(Pc):
+        x = np.frombuffer(buf, np.float64, S * 10, off).reshape(S, 10); off += x.nbytes
+        cmd = np.frombuffer(buf, np.float64, S * 3, off).reshape(S, 3); off += cmd.nbytes
+        fl = np.frombuffer(buf, np.int32, S * 4, off).reshape(S, 4); off += fl.nbytes
+        assert np.array_equal(fl, want["flags"][:S, t]) and np.array_equal(cmd, want["cmd"][:S, t]), t
+        assert np.array_equal(x, want["x"][:S, t + 1]), t
+    assert off == len(buf)
