@@ -61,10 +61,11 @@ struct FrameExact {  // lives in device memory (too large for the kernel argumen
     int use_obs[AMK_MAX_FRAMES], use_edge[AMK_MAX_FRAMES];
 };
 
+// blockIdx.y = chunk of `fc` consecutive frames (fc = 1 for a list of handles: every frame exists; a keyframe map with room for
+// 101 frames holds ~6 on a flight, and a launch of 101 x S x (N + 4) / 4 blocks of which 94 % return at once is mostly dispatch)
 __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n_scenes, const double *__restrict__ ref_path,
-                                                              int N, int K, FrameBufs fb, const int *__restrict__ done) {
+                                                              int N, int K, FrameBufs fb, const int *__restrict__ done, int fc) {
     __shared__ GridWaveLds wl[4];
-    const int f = blockIdx.y;
     const int nq = N + 1;
     const int bps = (nq + 3) / 4;
     const int xcd = blockIdx.x & 7;
@@ -74,30 +75,34 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const int q = (j % bps) * 4 + w;
     if (s >= n_scenes || q >= nq || done[s]) return;
     const bool is_edge = q == N;
-    const int m = fs.scene_of(f, s);
-    if (m < 0) return;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
+    const double qx = qp[0], qy = qp[1], qz = qp[2];
     const int k = is_edge ? 1 : K;
-    double ld;
-    int li, lpos;
-    const GridScene gs = is_edge ? fs.edge_scene(f, m) : fs.obs_scene(f, m);
-    grid_knn(gs, qp[0], qp[1], qp[2], k, ld, li, lpos, &wl[w]);
-    if (lane < k) {
-        const bool ok = li != kNoIndex;
-        const float4 rec = gs.pt[lpos];
-        if (is_edge) {
-            const size_t o = (size_t)f * n_scenes + s;
-            fb.edge_d2[o] = ok ? ld : DBL_MAX;
-            fb.edge_pt[3 * o + 0] = ok ? rec.x : 0.f;
-            fb.edge_pt[3 * o + 1] = ok ? rec.y : 0.f;
-            fb.edge_pt[3 * o + 2] = ok ? rec.z : 0.f;
-        } else {
-            const size_t row = ((size_t)f * n_scenes + s) * N + q;
-            fb.knn_d2[row * K + lane] = ok ? ld : DBL_MAX;
-            float *o = fb.knn_pts + (row * K + lane) * 3;
-            o[0] = ok ? rec.x : 0.f;
-            o[1] = ok ? rec.y : 0.f;
-            o[2] = ok ? rec.z : 0.f;
+    const int f_end = min(fs.n, ((int)blockIdx.y + 1) * fc);
+    for (int f = blockIdx.y * fc; f < f_end; ++f) {
+        const int m = fs.scene_of(f, s);
+        if (m < 0) continue;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
+        double ld;
+        int li, lpos;
+        const GridScene gs = is_edge ? fs.edge_scene(f, m) : fs.obs_scene(f, m);
+        grid_knn(gs, qx, qy, qz, k, ld, li, lpos, &wl[w]);
+        if (lane < k) {
+            const bool ok = li != kNoIndex;
+            const float4 rec = gs.pt[lpos];
+            if (is_edge) {
+                const size_t o = (size_t)f * n_scenes + s;
+                fb.edge_d2[o] = ok ? ld : DBL_MAX;
+                fb.edge_pt[3 * o + 0] = ok ? rec.x : 0.f;
+                fb.edge_pt[3 * o + 1] = ok ? rec.y : 0.f;
+                fb.edge_pt[3 * o + 2] = ok ? rec.z : 0.f;
+            } else {
+                const size_t row = ((size_t)f * n_scenes + s) * N + q;
+                fb.knn_d2[row * K + lane] = ok ? ld : DBL_MAX;
+                float *o = fb.knn_pts + (row * K + lane) * 3;
+                o[0] = ok ? rec.x : 0.f;
+                o[1] = ok ? rec.y : 0.f;
+                o[2] = ok ? rec.z : 0.f;
+            }
         }
     }
 }
@@ -177,7 +182,19 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     double *__restrict__ knn_d2, double *__restrict__ ref_states, int *__restrict__ done, int *__restrict__ flags) {
     const int s = blockIdx.x, lane = threadIdx.x;
     if (done[s]) return;
-    const int F = fs.n;
+    // frames this scene's map holds: every loop below runs over them only (an absent frame contributes nothing to any query, and the
+    // candidate ids f K + j of the others do not move).  A map with room for 101 frames holds ~6 on a flight; each pass over
+    // absent frames is a chain of dependent loads (fmap, then the size) per frame.
+    int F = fs.n;
+    if (fs.fmap) {
+        int hi = 0;
+        for (int f0 = 0; f0 < fs.n; f0 += 64) {
+            const int f = f0 + lane;
+            const unsigned long long b = __ballot(f < fs.n && fs.fmap[(size_t)f * fs.S + s] >= 0);
+            if (b) hi = f0 + 64 - __clzll((long long)b);
+        }
+        F = hi;
+    }
     __shared__ GridWaveLds wl;
     __shared__ int cntq[AMK_MAX_HORIZON];
     double *rp = ref_path + (size_t)s * N * SD;
@@ -451,8 +468,10 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     if (cam) c = *cam;
     // the merge keeps ceil(F K / 64) candidates per lane in registers: instantiated for 1 / 2 / 4 / 16 (a 4-frame map with K = 8 needs
     // ONE; the 16-wide instantiation carries 32 key registers and 16 x unrolled selection loops: 204 VGPRs against 70-odd)
-    const bool wide = F * K > 64 * kMaxCandPerLane || (g_force_wide && !any_exact);   // (only a keyframe map can be: F <= AMK_MAX_MAP_FRAMES)
     const int need_cpl = (F * K + 63) / 64;
+    // a keyframe map beyond 4 candidates per lane takes the wide merge: 61 VGPRs (it runs beside the solves' waves; the 16-wide
+    // instantiation cannot), and with the loops bounded by the frames a scene actually holds its re-reads are few
+    const bool wide = F * K > 64 * kMaxCandPerLane || (fs.fmap && need_cpl > 4) || (g_force_wide && !any_exact);
     auto merge_kernel = step_merge_plan_pack_kernel<false, kMaxCandPerLane>;
     if (wide) merge_kernel = step_merge_plan_pack_kernel<false, kMaxCandPerLaneMap>;
     else if (any_exact) merge_kernel = step_merge_plan_pack_kernel<true>;
@@ -461,9 +480,10 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     else if (need_cpl <= 4) merge_kernel = step_merge_plan_pack_kernel<false, 4>;
     hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
     const int S8 = (S + 7) / 8 * 8;
+    const int fc = (fs.fmap && F > AMK_MAX_FRAMES) ? 8 : 1;   // frames per search block
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
-        hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path, N, K,
-                           fb, mpc->done.p);
+        hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), (F + fc - 1) / fc), dim3(256), 0, stream, fs, S, d_ref_path,
+                           N, K, fb, mpc->done.p, fc);
         if (any_exact)
             hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 3) / 4, F), dim3(256), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);
