@@ -13,7 +13,7 @@
 //
 // Per outer iteration:
 //   step_knn_frames_kernel        raw K-NN of the N reference points + edge 1-NN of point 0 in EVERY frame (grid.y = frame)
-//   step_merge_plan_pack_kernel   one wavefront per scene: PtIsInFrame per reference point, GetNearestDistance, PlanWapionts
+//   step_merge_plan_pack_kernel   one workgroup (4 wavefronts) per scene: PtIsInFrame per reference point, GetNearestDistance, PlanWapionts
 //                                 (snap to the nearest edge point over the frames, re-query), fast path / merge per
 //                                 reference point, padding, needReplan, early exit, GetRefStates
 //   mpc_solve_kernel              Solve + refill of the reference path (mpc_solve.hip)
@@ -63,6 +63,7 @@ struct FrameExact {  // lives in device memory (too large for the kernel argumen
 
 // blockIdx.y = chunk of `fc` consecutive frames (fc = 1 for a list of handles: every frame exists; a keyframe map with room for
 // 101 frames holds ~6 on a flight, and a launch of 101 x S x (N + 4) / 4 blocks of which 94 % return at once is mostly dispatch)
+template <bool MAP>
 __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n_scenes, const double *__restrict__ ref_path,
                                                               int N, int K, FrameBufs fb, const int *__restrict__ done, int fc) {
     __shared__ GridWaveLds wl[4];
@@ -78,13 +79,14 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const double qx = qp[0], qy = qp[1], qz = qp[2];
     const int k = is_edge ? 1 : K;
-    const int f_end = min(fs.n, ((int)blockIdx.y + 1) * fc);
-    for (int f = blockIdx.y * fc; f < f_end; ++f) {
-        const int m = fs.scene_of(f, s);
+    const GridPtrs pool = is_edge ? fs.edge[0] : fs.obs[0];   // (map mode: one set of pool pointers stays live over the loop)
+    const int f_end = MAP ? min(fs.n, ((int)blockIdx.y + 1) * fc) : (int)blockIdx.y + 1;
+    for (int f = MAP ? blockIdx.y * fc : blockIdx.y; f < f_end; ++f) {
+        const int m = MAP ? fs.fmap[(size_t)f * fs.S + s] : s;
         if (m < 0) continue;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
         double ld;
         int li, lpos;
-        const GridScene gs = is_edge ? fs.edge_scene(f, m) : fs.obs_scene(f, m);
+        const GridScene gs = MAP ? pool.scene(m) : (is_edge ? fs.edge[f] : fs.obs[f]).scene(m);
         grid_knn(gs, qx, qy, qz, k, ld, li, lpos, &wl[w]);
         if (lane < k) {
             const bool ok = li != kNoIndex;
@@ -175,12 +177,16 @@ constexpr int kMaxCandPerLaneMap = 0;   // the keyframe map beyond 64 kMaxCandPe
 // EXACT (some frame in AMK_TIES_NANOFLANN mode): a template parameter so that the default kernel needs no scratch memory.
 // CPL: merge candidates (frame, neighbour) a lane may hold -- F K <= 64 CPL.
 template <bool EXACT, int CPL = kMaxCandPerLane>
-__global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
+__global__ __launch_bounds__(4 * kWave) void step_merge_plan_pack_kernel(
     FrameSet fs, const FrameExact *__restrict__ fe, FrameBufs fb, int S, const double *__restrict__ Twc, amk_frame_camera cam, int N, int K, int nref, int iter,
     int max_iter, double speed, double T, double safety_distance, const double *__restrict__ state_quad,
     const double *__restrict__ pos_x, double *__restrict__ ref_path, float *__restrict__ knn_pts,
     double *__restrict__ knn_d2, double *__restrict__ ref_states, int *__restrict__ done, int *__restrict__ flags) {
-    const int s = blockIdx.x, lane = threadIdx.x;
+    // One workgroup per scene: nw = blockDim.x / 64 wavefronts (4; 1 when a frame is in AMK_TIES_NANOFLANN mode).  Wavefront 0
+    // decides PlanWapionts; the snapped point's re-queries (one search per frame) and the per-reference-point merges are dealt
+    // round-robin to the wavefronts, the rows that take QueryNearest's fast path are copied by all threads at once.
+    const int s = blockIdx.x, lane = threadIdx.x & 63, tid = threadIdx.x, nthr = blockDim.x;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
     if (done[s]) return;
     // frames this scene's map holds: every loop below runs over them only (an absent frame contributes nothing to any query, and the
     // candidate ids f K + j of the others do not move).  A map with room for 101 frames holds ~6 on a flight; each pass over
@@ -195,43 +201,78 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
         }
         F = hi;
     }
-    __shared__ GridWaveLds wl;
+    __shared__ GridWaveLds wl[4];
     __shared__ int cntq[AMK_MAX_HORIZON];
+    __shared__ int sh_safety, sh_snap;
+    __shared__ double sh_e[3];
     double *rp = ref_path + (size_t)s * N * SD;
     const double *Ts = Twc ? Twc + (size_t)s * 16 : nullptr;
     auto in_frame = [&](double x, double y, double z) { return Ts ? pt_in_frame(Ts, cam, x, y, z) : true; };
+    const int n_obs0 = fs.n_obs(0, s);
     // ---- PlanWapionts (:259-281) for reference point 0
-    const double p0x = rp[0], p0y = rp[1], p0z = rp[2];
-    double d2n = DBL_MAX;  // GetNearestDistance: 1-NN per frame exists iff the frame holds more than one point
-    for (int f = 0; f < F; ++f)
-        if (fs.n_obs(f, s) > 1) d2n = fmin(d2n, fb.knn_d2[(((size_t)f * S + s) * N) * K]);
-    int is_safety = 1;
-    if (!(sqrt(d2n) > safety_distance)) {
-        // QueryNearest(p1, 1, ..., queryEdge = true): fast path iff the current edge cloud holds >= 1 point and p1 is in frame
-        double best = DBL_MAX;
-        int bf = -1;
-        if (fs.n_edge(0, s) >= 1 && in_frame(p0x, p0y, p0z)) {
-            if (fs.n_edge(0, s) > 1 && fb.edge_d2[s] < DBL_MAX) { best = fb.edge_d2[s]; bf = 0; }
-        } else {
-            for (int f = 0; f < F; ++f) {  // k' = min(1, size_f): a result iff size_f > 1; ties keep the earlier frame
-                if (fs.n_edge(f, s) > 1) {
-                    const double d = fb.edge_d2[(size_t)f * S + s];
-                    if (d < best) { best = d; bf = f; }
-                }
+    if (w == 0) {
+        const double p0x = rp[0], p0y = rp[1], p0z = rp[2];
+        // GetNearestDistance: 1-NN per frame exists iff the frame holds more than one point (lane = frame)
+        unsigned long long d2n_key = ~0ull;
+        for (int f0 = 0; f0 < F; f0 += 64) {
+            const int f = f0 + lane;
+            if (f < F && fs.n_obs(f, s) > 1) {
+                const double d = fb.knn_d2[(((size_t)f * S + s) * N) * K];
+                // fmin semantics: a NaN distance is ignored; d >= 0, so the bit pattern orders like the value
+                if (d == d) { const unsigned long long k64 = (unsigned long long)__double_as_longlong(d); d2n_key = k64 < d2n_key ? k64 : d2n_key; }
             }
         }
-        if (bf < 0) {
-            is_safety = 0;
-        } else {
-            const float *ep = fb.edge_pt + 3 * ((size_t)bf * S + s);
-            const double ex = (double)ep[0], ey = (double)ep[1], ez = (double)ep[2];
-            for (int f = 0; f < F; ++f) {  // the snapped point is what ProcessWaypoints queries next (:210-215)
-                double gld;
-                int gli, glpos;
-                const int mf = fs.scene_of(f, s);
-                if (mf < 0) continue;   // (wave-uniform)
+        d2n_key = wave_min_u64(d2n_key);
+        const double d2n = d2n_key == ~0ull ? DBL_MAX : __longlong_as_double((long long)d2n_key);
+        int is_safety = 1, snap = 0;
+        if (!(sqrt(d2n) > safety_distance)) {
+            // QueryNearest(p1, 1, ..., queryEdge = true): fast path iff the current edge cloud holds >= 1 point and p1 is in frame
+            int bf = -1;
+            if (fs.n_edge(0, s) >= 1 && in_frame(p0x, p0y, p0z)) {
+                if (fs.n_edge(0, s) > 1 && fb.edge_d2[s] < DBL_MAX) bf = 0;
+            } else {
+                // k' = min(1, size_f): a result iff size_f > 1; ties keep the earlier frame (lane = frame; strict < in frame order)
+                unsigned long long bk = ~0ull;
+                int mf = 0x7fffffff;
+                for (int f0 = 0; f0 < F; f0 += 64) {
+                    const int f = f0 + lane;
+                    if (f < F && fs.n_edge(f, s) > 1) {
+                        const double d = fb.edge_d2[(size_t)f * S + s];
+                        if (d < DBL_MAX) {
+                            const unsigned long long k64 = (unsigned long long)__double_as_longlong(d);
+                            if (k64 < bk) { bk = k64; mf = f; }
+                        }
+                    }
+                }
+                const unsigned long long wb = wave_min_u64(bk);
+                if (wb != ~0ull) {
+                    int win = bk == wb ? mf : 0x7fffffff;
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) win = min(win, __shfl_xor(win, off));
+                    bf = win;
+                }
+            }
+            if (bf < 0) {
+                is_safety = 0;
+            } else {
+                snap = 1;
+                const float *ep = fb.edge_pt + 3 * ((size_t)bf * S + s);
+                if (lane == 0) { sh_e[0] = (double)ep[0]; sh_e[1] = (double)ep[1]; sh_e[2] = (double)ep[2]; }
+            }
+        }
+        if (lane == 0) { sh_safety = is_safety; sh_snap = snap; flags[4 * s + 0] = is_safety; }
+    }
+    __syncthreads();
+    const int is_safety = sh_safety;
+    if (sh_snap) {
+        const double ex = sh_e[0], ey = sh_e[1], ez = sh_e[2];
+        for (int f = w; f < F; f += nw) {  // the snapped point is what ProcessWaypoints queries next (:210-215)
+            double gld;
+            int gli, glpos;
+            const int mf = fs.scene_of(f, s);
+            if (mf >= 0) {   // (wave-uniform)
                 const GridScene gs = fs.obs_scene(f, mf);
-                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl);
+                grid_knn(gs, ex, ey, ez, K, gld, gli, glpos, &wl[w]);
                 if (lane < K) {
                     const bool ok = gli != kNoIndex;
                     const float4 rec = gs.pt[glpos];
@@ -240,8 +281,10 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
                     float *o = fb.knn_pts + (row * K + lane) * 3;
                     o[0] = ok ? rec.x : 0.f; o[1] = ok ? rec.y : 0.f; o[2] = ok ? rec.z : 0.f;
                 }
+            }
+            if constexpr (EXACT) {   // (nw == 1: the barriers below are this wavefront's own)
                 __syncthreads();
-                if (EXACT && fe->use_obs[f]) {  // AMK_TIES_NANOFLANN frame: the re-query by the reference's traversal (lane 0)
+                if (mf >= 0 && fe->use_obs[f]) {  // AMK_TIES_NANOFLANN frame: the re-query by the reference's traversal (lane 0)
                     __shared__ double xr[AMK_MAX_K];
                     __shared__ int xi[AMK_MAX_K], xgot;
                     __shared__ ExactStackStorage xstack;  // LDS, not scratch: one lane walks the tree
@@ -258,26 +301,31 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
                     __syncthreads();
                 }
             }
-            if (lane == 0) { rp[0] = ex; rp[1] = ey; rp[2] = ez; }
         }
+        if (tid == 0) { rp[0] = ex; rp[1] = ey; rp[2] = ez; }
     }
-    if (lane == 0) flags[4 * s + 0] = is_safety;
     __threadfence_block();
     __syncthreads();
     // ---- ProcessWaypoints' queries (:204-215): fast path or merge over the frames, per reference point
-    for (int i = 0; i < N; ++i) {
-        const double qx = rp[i * SD], qy = rp[i * SD + 1], qz = rp[i * SD + 2];
-        const size_t orow = ((size_t)s * N + i) * K;
-        if (fs.n_obs(0, s) >= K && in_frame(qx, qy, qz)) {  // QueryNearestWithCurFrame (:254-275, 339-345)
-            const int cnt = fs.n_obs(0, s) > K ? K : 0;      // kd_tree_two.h:119-124
-            if (lane < K) {
-                const size_t irow = ((size_t)s * N + i) * K + lane;  // frame 0
-                knn_d2[orow + lane] = fb.knn_d2[irow];
-                for (int c = 0; c < 3; ++c) knn_pts[(orow + lane) * 3 + c] = fb.knn_pts[irow * 3 + c];
+    // QueryNearestWithCurFrame (:254-275, 339-345) for the reference points the current image sees (lane = reference point)
+    bool inf = false;
+    if (lane < N) inf = n_obs0 >= K && in_frame(rp[lane * SD], rp[lane * SD + 1], rp[lane * SD + 2]);
+    const unsigned long long fast = __ballot(inf);
+    {
+        const int cnt_fast = n_obs0 > K ? K : 0;      // kd_tree_two.h:119-124
+        const size_t base = (size_t)s * N * K;        // frame 0's rows of this scene = the output rows' layout
+        for (int e = tid; e < N * K; e += nthr) {
+            const int i = e / K;
+            if ((fast >> i) & 1ull) {
+                knn_d2[base + e] = fb.knn_d2[base + e];
+                for (int c = 0; c < 3; ++c) knn_pts[(base + e) * 3 + c] = fb.knn_pts[(base + e) * 3 + c];
             }
-            if (lane == 0) cntq[i] = cnt;
-            continue;
         }
+        if (w == 0 && inf) cntq[lane] = cnt_fast;
+    }
+    for (int i = w; i < N; i += nw) {
+        if ((fast >> i) & 1ull) continue;
+        const size_t orow = ((size_t)s * N + i) * K;
         // QueryNearestThreadWorker over mVecQueryVector (:276-321) + sort (:371): candidate c = f * K + j
         const int ncand = F * K;
         int cnt = 0;
@@ -361,29 +409,29 @@ __global__ __launch_bounds__(kWave) void step_merge_plan_pack_kernel(
     // ---- padding, needReplan (:216-231), early exit (:333-335), GetRefStates (:236-257)
     bool need = false;
     if (lane < N) need = (cntq[lane] == 0) || (sqrt(knn_d2[((size_t)s * N + lane) * K]) <= safety_distance);
-    const bool need_replan = __ballot(need) != 0ull;
+    const bool need_replan = __ballot(need) != 0ull;   // (every wavefront evaluates the same rows: one decision per workgroup)
     if (!need_replan && iter > 0 && is_safety) {
-        if (lane == 0) done[s] = 1;
+        if (tid == 0) done[s] = 1;
         return;
     }
     double *P = ref_states + (size_t)s * nref;
     const double *sq = state_quad + ((size_t)s * max_iter + iter) * SD;
-    if (lane < SD) P[lane] = sq[lane];
-    for (int e = lane; e < SD * N; e += 64) P[SD + e] = rp[e];
-    for (int e = lane; e < 3 * K * N; e += 64) {
+    if (tid < SD) P[tid] = sq[tid];
+    for (int e = tid; e < SD * N; e += nthr) P[SD + e] = rp[e];
+    for (int e = tid; e < 3 * K * N; e += nthr) {
         const int i = e / (3 * K), jj = (e / 3) % K;
         P[SD + SD * N + e] = (jj < cntq[i]) ? (double)knn_pts[(size_t)s * N * K * 3 + e] : 10000.0;
     }
-    if (lane < SD) {
+    if (tid < SD) {
         const double *last = rp + (N - 1) * SD;
-        double v = last[lane];
-        if (lane == 0) {
+        double v = last[tid];
+        if (tid == 0) {
             double dX = speed * T - fmax(0., last[0] - pos_x[s]);
             dX = fmax(0., dX);
             v += dX;
         }
-        if (lane == 1) v = 0.;
-        P[SD + SD * N + 3 * K * N + lane] = v;
+        if (tid == 1) v = 0.;
+        P[SD + SD * N + 3 * K * N + tid] = v;
     }
 }
 
@@ -482,12 +530,16 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     const int S8 = (S + 7) / 8 * 8;
     const int fc = (fs.fmap && F > AMK_MAX_FRAMES) ? 8 : 1;   // frames per search block
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
-        hipLaunchKernelGGL(step_knn_frames_kernel, dim3(S8 * ((N + 4) / 4), (F + fc - 1) / fc), dim3(256), 0, stream, fs, S, d_ref_path,
-                           N, K, fb, mpc->done.p, fc);
+        if (fs.fmap)
+            hipLaunchKernelGGL(step_knn_frames_kernel<true>, dim3(S8 * ((N + 4) / 4), (F + fc - 1) / fc), dim3(256), 0, stream, fs, S,
+                               d_ref_path, N, K, fb, mpc->done.p, fc);
+        else
+            hipLaunchKernelGGL(step_knn_frames_kernel<false>, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path,
+                               N, K, fb, mpc->done.p, 1);
         if (any_exact)
             hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 3) / 4, F), dim3(256), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);
-        hipLaunchKernelGGL(merge_kernel, dim3(S), dim3(kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
+        hipLaunchKernelGGL(merge_kernel, dim3(S), dim3(any_exact ? kWave : 4 * kWave), 0, stream, fs, fe_dev, fb, S, d_Twc, c, N, K, mpc->nref,
                            iter, prm->mpc_max_iter, prm->speed, mpc->T, prm->safety_distance, d_state_quad, d_pos_x,
                            d_ref_path, mpc->knn_pts.p, mpc->knn_d2.p, mpc->ref_states.p, mpc->done.p, d_flags);
         AMK_HIP(hipGetLastError());
