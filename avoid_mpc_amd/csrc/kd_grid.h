@@ -707,6 +707,14 @@ __device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx
 // within th (sqrt is monotone: the minimum is within th too).  Returns 1 = outlier, 0 = not (also when the index holds no
 // point with finite coordinates: the reference then has no result to test).  Same flags as `sqrt(grid_nn1_thread(...)) > th`
 // (tests/test_keyframe_gpu.py, test_kfmap_gpu.py).
+#ifndef AMK_SWEEP_TILES
+#define AMK_SWEEP_TILES 2
+#endif
+#ifndef AMK_SWEEP_RECS
+#define AMK_SWEEP_RECS 8
+#endif
+constexpr int kSweepTiles = AMK_SWEEP_TILES;   // tiles whose bucket-table entries a sweep thread reads in one step
+constexpr int kSweepRecs = AMK_SWEEP_RECS;     // records of a run it reads in one step
 __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double qx, double qy, double qz, double th) {
     const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
     const double h = gs.gp[3], inv_h = gs.gp[4];
@@ -726,13 +734,33 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
     for (int iz = lo[2]; iz <= hi[2]; ++iz)
         for (int iy = lo[1]; iy <= hi[1]; ++iy) {
             const int rowbase = (iz * g[1] + iy) * g[0];
-            for (int t = 0; t < gs.nt; ++t) {   // the run of cells [lo x, hi x] of this row, tile by tile
-                const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
-                const int s0 = cst[rowbase + lo[0]], s1 = cst[rowbase + hi[0] + 1];
-                for (int pos = s0; pos < s1; ++pos) {
-                    const float4 p4 = gs.pt[pos];
-                    const double d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
-                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) return 0;
+            // the run of cells [lo x, hi x] of this row, tile by tile.  The walk is a chain of dependent loads (bucket table, then
+            // the run's records) and nothing else: the table entries of kSweepTiles tiles are fetched together, then kSweepRecs
+            // records of a run at a time (a run holds ~5; indices past its end repeat its last record, which decides nothing
+            // new).  Wider steps cost registers, and the kernel lives on the number of threads in flight: see the table in
+            // profiles/r05_sweep_mlp.txt.
+            for (int t0 = 0; t0 < gs.nt; t0 += kSweepTiles) {
+                int s0[kSweepTiles], s1[kSweepTiles];
+#pragma unroll
+                for (int u = 0; u < kSweepTiles; ++u) {
+                    const int *cst = gs.cs + (size_t)min(t0 + u, gs.nt - 1) * (kGridMaxCells + 2);
+                    s0[u] = cst[rowbase + lo[0]];
+                    s1[u] = t0 + u < gs.nt ? cst[rowbase + hi[0] + 1] : s0[u];
+                }
+#pragma unroll
+                for (int u = 0; u < kSweepTiles; ++u) {
+                    for (int pos = s0[u]; pos < s1[u]; pos += kSweepRecs) {
+                        const int last = s1[u] - 1;
+                        float4 p[kSweepRecs];
+#pragma unroll
+                        for (int e = 0; e < kSweepRecs; ++e) p[e] = gs.pt[min(pos + e, last)];
+                        double d = sq_dist(qx, qy, qz, p[0].x, p[0].y, p[0].z);
+#pragma unroll
+                        for (int e = 1; e < kSweepRecs; ++e) d = fmin(d, sq_dist(qx, qy, qz, p[e].x, p[e].y, p[e].z));
+                        // (the test is monotone in d: the minimum decides for all.  NaN distances: records never hold them --
+                        // NaN-x points are dropped by the build, other non-finite ones sit in the trash bucket)
+                        if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) return 0;
+                    }
                 }
             }
         }
