@@ -95,9 +95,15 @@ struct LdsMap {
         dX = take((N + 1) * SD); dU = take(N * UD);
         q = take((N + 1) * SD); r = take(N * UD); rb = take(N * UD); Rb = take(N * UD); gU = take(N * UD);
         H6 = take(N * 21); rotQ = take(N * 6);
-        P = take(100); p = take(SD); lam = take(SD); M = take(56); Hm = take(10); G = take(40);
-        Atp = take(SD); Atl = take(SD); qu = take(UD); Y = 0; Z = 0; D = 0;
-        Xt = take((N + 1) * SD); Ut = take(N * UD); red = take(16);
+        // the backward sweep's temporaries (P .. qu: 250 reals, born and dead inside riccati_backward) live in the trial
+        // states' storage (Xt: written and read by the line search only): 2 KB less per scene, which at N = 30 is the
+        // difference between 5 and 6 scenes per CU (28.2 -> 26.2 KB of the 160).  M / Hm / G hold structural zeros the sweep
+        // relies on: solve_scene clears them before every iteration's first sweep.
+        constexpr int kRic = 100 + 3 * SD + 56 + 10 + 40 + SD + UD;
+        Xt = take((N + 1) * SD > kRic ? (N + 1) * SD : kRic);
+        P = Xt; p = P + 100; lam = p + SD; M = lam + SD; Hm = M + 56; G = Hm + 10;
+        Atp = G + 40; Atl = Atp + SD; qu = Atl + SD; Y = 0; Z = 0; D = 0;
+        Ut = take(N * UD); red = take(16);
         // buffers with disjoint lifetimes share storage: the barrier-shifted control gradient / Hessian (rb, Rb) are
         // dead once the backward sweep has run; the dual steps are born after the forward roll and consumed by the
         // update that follows the line search.  (Not on q / r: the first trial point is evaluated WITH derivatives,

@@ -886,6 +886,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             sm[L.rb + e] = sm[L.r + e] - mu * isl + mu * isu;
             sm[L.Rb + e] = RL(2.0) * prm[PRM_W + 20 + i] + sm[L.zl + e] * isl + sm[L.zu + e] * isu;
         }
+        for (int e = lane; e < 56 + 10 + 40; e += 64) sm[L.M + e] = RL(0.0);  // (the line search's trial states lay here)
         __syncthreads();
         real delta = RL(0.0);
         int reg_now = 0;

@@ -61,11 +61,27 @@ struct FrameExact {  // lives in device memory (too large for the kernel argumen
     int use_obs[AMK_MAX_FRAMES], use_edge[AMK_MAX_FRAMES];
 };
 
-// blockIdx.y = chunk of `fc` consecutive frames (fc = 1 for a list of handles: every frame exists; a keyframe map with room for
+// PtIsInFrame (FrameKDMap.cpp:215-231): Twc rigid, its inverse is [R' | -R' t]
+__device__ __forceinline__ bool pt_in_frame(const double *__restrict__ T, const amk_frame_camera &cam, double px, double py,
+                                            double pz) {
+#pragma clang fp contract(off)   // two kernels take this decision for the same point (the searches skip what the merge will not read): same bits in both
+    const double dx = px - T[3], dy = py - T[7], dz = pz - T[11];
+    const double x = T[0] * dx + T[4] * dy + T[8] * dz;
+    const double y = T[1] * dx + T[5] * dy + T[9] * dz;
+    const double z = T[2] * dx + T[6] * dy + T[10] * dz;
+    if (z > cam.depth_max || z < 0) return false;
+    const double u = cam.fx * x / z + cam.cx;
+    const double v = cam.fy * y / z + cam.cy;
+    if (u < 0 || u >= cam.width || v < 0 || v >= cam.height) return false;
+    return true;
+}
+
+// blockIdx.y = the frame (a list of handles: every frame exists) or a chunk of consecutive frames (a keyframe map with room for
 // 101 frames holds ~6 on a flight, and a launch of 101 x S x (N + 4) / 4 blocks of which 94 % return at once is mostly dispatch)
 template <bool MAP>
 __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n_scenes, const double *__restrict__ ref_path,
-                                                              int N, int K, FrameBufs fb, const int *__restrict__ done, int fc) {
+                                                              int N, int K, FrameBufs fb, const int *__restrict__ done, int fc,
+                                                              const double *__restrict__ Twc, amk_frame_camera cam) {
     __shared__ GridWaveLds wl[4];
     const int nq = N + 1;
     const int bps = (nq + 3) / 4;
@@ -79,9 +95,21 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const double qx = qp[0], qy = qp[1], qz = qp[2];
     const int k = is_edge ? 1 : K;
+    // Frames behind the current one are searched only for the queries that will read them: QueryNearest answers from the current
+    // frame alone when that frame holds >= k points and the query projects into the current image (FrameKDMap.cpp:339-345) -- on a
+    // flight nearly every reference point does.  The merge kernel takes the same decision from the same numbers (reference point 0
+    // may be moved by the snap in between and GetNearestDistance reads its rows in every frame: it is always searched everywhere).
+    bool cur_only = false;
+    if (q != 0) {
+        const int n0 = is_edge ? fs.n_edge(0, s) : fs.n_obs(0, s);
+        cur_only = n0 >= k && (!Twc || pt_in_frame(Twc + (size_t)s * 16, cam, qx, qy, qz));
+    }
     const GridPtrs pool = is_edge ? fs.edge[0] : fs.obs[0];   // (map mode: one set of pool pointers stays live over the loop)
-    const int f_end = MAP ? min(fs.n, ((int)blockIdx.y + 1) * fc) : (int)blockIdx.y + 1;
-    for (int f = MAP ? blockIdx.y * fc : blockIdx.y; f < f_end; ++f) {
+    // map mode: chunk c = frames [fc (2^c - 1), fc (2^(c+1) - 1)) -- 8, 16, 32, ... of them: a map on a flight holds ~6 frames of its
+    // 101, and every chunk beyond the first is a grid of blocks that find nothing to do
+    const int f_end = MAP ? min(fs.n, fc * ((2 << blockIdx.y) - 1)) : (int)blockIdx.y + 1;
+    for (int f = MAP ? fc * ((1 << blockIdx.y) - 1) : blockIdx.y; f < f_end; ++f) {
+        if (cur_only && f > 0) break;
         const int m = MAP ? fs.fmap[(size_t)f * fs.S + s] : s;
         if (m < 0) continue;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
         double ld;
@@ -145,20 +173,6 @@ __global__ __launch_bounds__(256) void step_knn_frames_exact_kernel(const FrameE
             o[0] = px; o[1] = py; o[2] = pz;
         }
     }
-}
-
-// PtIsInFrame (FrameKDMap.cpp:215-231): Twc rigid, its inverse is [R' | -R' t]
-__device__ __forceinline__ bool pt_in_frame(const double *__restrict__ T, const amk_frame_camera &cam, double px, double py,
-                                            double pz) {
-    const double dx = px - T[3], dy = py - T[7], dz = pz - T[11];
-    const double x = T[0] * dx + T[4] * dy + T[8] * dz;
-    const double y = T[1] * dx + T[5] * dy + T[9] * dz;
-    const double z = T[2] * dx + T[6] * dy + T[10] * dz;
-    if (z > cam.depth_max || z < 0) return false;
-    const double u = cam.fx * x / z + cam.cx;
-    const double v = cam.fy * y / z + cam.cy;
-    if (u < 0 || u >= cam.width || v < 0 || v >= cam.height) return false;
-    return true;
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v) {
@@ -528,14 +542,16 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     else if (need_cpl <= 4) merge_kernel = step_merge_plan_pack_kernel<false, 4>;
     hipLaunchKernelGGL(step_frames_begin_kernel, dim3((S + 255) / 256), dim3(256), 0, stream, S, mpc->done.p, d_flags, d_u);
     const int S8 = (S + 7) / 8 * 8;
-    const int fc = (fs.fmap && F > AMK_MAX_FRAMES) ? 8 : 1;   // frames per search block
+    const int fc = 8;   // map mode: frames of the first chunk of search blocks (the chunks double: 8, 16, 32, ...)
+    int n_chunks = 1;
+    while (fc * ((1 << n_chunks) - 1) < F) ++n_chunks;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         if (fs.fmap)
-            hipLaunchKernelGGL(step_knn_frames_kernel<true>, dim3(S8 * ((N + 4) / 4), (F + fc - 1) / fc), dim3(256), 0, stream, fs, S,
-                               d_ref_path, N, K, fb, mpc->done.p, fc);
+            hipLaunchKernelGGL(step_knn_frames_kernel<true>, dim3(S8 * ((N + 4) / 4), n_chunks), dim3(256), 0, stream, fs, S,
+                               d_ref_path, N, K, fb, mpc->done.p, fc, d_Twc, c);
         else
             hipLaunchKernelGGL(step_knn_frames_kernel<false>, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path,
-                               N, K, fb, mpc->done.p, 1);
+                               N, K, fb, mpc->done.p, 1, d_Twc, c);
         if (any_exact)
             hipLaunchKernelGGL(step_knn_frames_exact_kernel, dim3((S * (N + 1) + 3) / 4, F), dim3(256), 0, stream, fe_dev, S,
                                d_ref_path, N, K, fb, mpc->done.p);

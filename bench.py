@@ -332,10 +332,14 @@ def flight_main(args):
     ABt = torch.from_numpy(np.concatenate([A, Bm], axis=1).T.copy()).to(dev)      # [14, 10]: x' = [x, a_cmd, 0] @ ABt + c
     cvec = torch.from_numpy(c).to(dev)
     kf = dict(max_frame_count=args.keyframes, th_dist=0.1, th_count=10, depth_min=0.1) if args.keyframes > 0 else None   # yaml :71-73,66
-    # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor looking along +x of the odometry frame (Tbc = I here)
+    # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor (mpc_parameters.yaml:59-66) with the yaml's extrinsic
+    # T_b_c (:67-71: 5 cm ahead of the body's origin, looking along its +x); mCurFrame.Twc = Twb * T_b_c, Twb = [I | odometry position]
     kf_cam = capi.FrameCamera(32.0, 32.0, 32.0, 24.0, 100.0, 64, 48) if kf else None
-    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang, keyframes=kf)
-    Twc = [torch.eye(4, dtype=torch.float64, device=dev).repeat(S, 1, 1).contiguous() for _ in range(B)] if kf else None
+    from avoid_mpc_amd.host import depth_params
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang, keyframes=kf,
+                  depth=depth_params(Tbc=flight.TBC_YAML) if kf else None)
+    tbc = torch.from_numpy(flight.TBC_YAML).to(dev)
+    Twc = [tbc.repeat(S, 1, 1).contiguous() for _ in range(B)] if kf else None
     for i in range(nslots):
         pl.kd(i, 0).set_tie_order(args.tie_order); pl.kd(i, 1).set_tie_order(args.tie_order)
         pl.mpc(i).set_precision(args.precision)
@@ -366,9 +370,9 @@ def flight_main(args):
                 for g in range(gang):
                     b = si * gang + g
                     cl, ed = frames[b % W][t]
-                    if kf:   # mCurFrame.Twc of the frame: the odometry position (R = I), written on the slot's stream behind the vehicle
+                    if kf:   # mCurFrame.Twc of the frame, written on the slot's stream behind the vehicle
                         with torch.cuda.stream(slot_stream[si]):
-                            Twc[b][:, 0:3, 3] = x[b][:, 0:3]
+                            torch.add(x[b][:, 0:3], tbc[0:3, 3], out=Twc[b][:, 0:3, 3])
                     tickets.append(pl.submit(cl, ed, ref_path_init=ref0_d[b] if t == 0 else None, odom=x[b], cmd_out=cmd[b],
                                              keep_warm_start=t > 0, order_after_current_stream=False,
                                              Twc_cur=Twc[b] if kf else None, cam=kf_cam))

@@ -53,7 +53,8 @@ def _oracle_flight(job):
     seed, cfg, periods, n_points, world_kw = job[:5]
     task_kw = (job[5] if len(job) > 5 else None) or {}   # dict(task="global_goal", global_goal=[3]): GetInitPath's other task (:34-45)
     map_kw = job[6] if len(job) > 6 else None     # dict(max_frame_count, th_dist, th_count, depth_min, cam): fly with the keyframe map;
-    # cloud frames carry no camera pose, so mCurFrame.Twc is the odometry position with R = I and Tbc = I (bench.py does the same)
+    # cloud frames carry no camera pose: mCurFrame.Twc = Twb * T_b_c with Twb = the odometry position (R = I) and the yaml's camera
+    # extrinsic (flight.TBC_YAML: the camera looks along the body's +x), as bench.py and tests/cpp/flight_driver.cpp do
     from tests import _oracle
     prm, n = make_prm(cfg) if isinstance(cfg, str) else (synth.MpcParams(T=cfg[0], K=cfg[1]), n_points)
     n = n_points or n
@@ -69,14 +70,14 @@ def _oracle_flight(job):
     kmap = None
     if map_kw:
         from tests import _kfmap
-        kmap = _kfmap.MapOracle(map_kw["max_frame_count"], map_kw["th_dist"], map_kw["th_count"], map_kw["depth_min"], np.eye(4))
+        kmap = _kfmap.MapOracle(map_kw["max_frame_count"], map_kw["th_dist"], map_kw["th_count"], map_kw["depth_min"], flight.TBC_YAML)
         log["n_keyframes"] = np.zeros(periods, np.int32); log["n_query_frames"] = np.zeros(periods, np.int32)
     for t in range(periods):
         cloud, edge = world.frame(t)
         sq, px = flight.period_inputs(x[None], ref[None], prm, task=task_kw.get("task", "forward"),
                                       global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[None])
         if kmap is not None:
-            Twc = np.eye(4); Twc[:3, 3] = x[0:3]
+            Twc = cloud_frame_twc(x[None])[0]
             kmap.add_vertex(cloud, edge, Twc, stamp=t)
             kmap.update()
             log["n_keyframes"][t], log["n_query_frames"][t] = len(kmap.kfs), len(kmap.frames())
@@ -131,14 +132,23 @@ def usable_cores():
     return cores
 
 
-CLOUD_CAM = (32.0, 32.0, 32.0, 24.0, 100.0, 64, 48)   # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor along +x
+CLOUD_CAM = (32.0, 32.0, 32.0, 24.0, 100.0, 64, 48)   # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor
+
+
+def cloud_frame_twc(x):
+    """mCurFrame.Twc of cloud frames, [n, 4, 4]: Twb * T_b_c (FrameKDMap.cpp:50) with Twb = [I | odometry position] and the yaml's
+    extrinsic (mpc_parameters.yaml:67-71): the camera sits 5 cm ahead of the body's origin and looks along its +x."""
+    x = np.asarray(x, np.float64)
+    T = np.tile(flight.TBC_YAML, (len(x), 1, 1))
+    T[:, :3, 3] += x[:, 0:3]
+    return T
 
 
 def oracle_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, workers=None, task_kw=None, keyframes=None):
     """-> dict of arrays [F, ...]: x [F, periods + 1, 10], u, flags, cmd, clearance [F, periods + 1].
     task_kw: dict(task="global_goal", global_goal=[F, 3]) flies GetInitPath's other task.
-    keyframes: dict(max_frame_count, th_dist, th_count) flies with FrameKDMap's keyframe list (mCurFrame.Twc = the odometry
-    position, R = I, Tbc = I; PtIsInFrame through CLOUD_CAM) and logs n_keyframes / n_query_frames."""
+    keyframes: dict(max_frame_count, th_dist, th_count) flies with FrameKDMap's keyframe list (mCurFrame.Twc = cloud_frame_twc of
+    the odometry; PtIsInFrame through CLOUD_CAM) and logs n_keyframes / n_query_frames."""
     from tests import _oracle
     _oracle.build_oracle()
     tk = lambda i: {} if not task_kw else dict(task=task_kw["task"], global_goal=None if task_kw.get("global_goal") is None else np.asarray(task_kw["global_goal"])[i])
@@ -181,8 +191,10 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
     task = (task_kw or {}).get("task", "forward")
     goal = None if not task_kw or task_kw.get("global_goal") is None else np.ascontiguousarray(task_kw["global_goal"], np.float64)
     from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import depth_params
     pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang, task=task,
-                  keyframes=dict(keyframes, depth_min=0.1) if keyframes else None)
+                  keyframes=dict(keyframes, depth_min=0.1) if keyframes else None,
+                  depth=depth_params(Tbc=flight.TBC_YAML) if keyframes else None)   # (T_b_c reaches the slot's map through the depth configuration)
     kcam = capi.FrameCamera(*CLOUD_CAM[:5], int(CLOUD_CAM[5]), int(CLOUD_CAM[6])) if keyframes else None
     if keyframes:
         logs_kf = dict(n_keyframes=np.zeros((F, periods), np.int32), n_query_frames=np.zeros((F, periods), np.int32))
@@ -201,9 +213,8 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
             fr = [worlds[i].frame(t) for i in range(sl.start, sl.stop)]
             clouds = torch.from_numpy(np.stack([c for c, _ in fr])).to(dev); edges = torch.from_numpy(np.stack([e for _, e in fr])).to(dev)
             Twc = None
-            if keyframes:   # mCurFrame.Twc of the frame: the odometry position, R = I (Tbc = I)
-                Tw = np.tile(np.eye(4), (B, 1, 1)); Tw[:, :3, 3] = x[sl, 0:3]
-                Twc = torch.from_numpy(Tw).to(dev)
+            if keyframes:   # mCurFrame.Twc of the frame
+                Twc = torch.from_numpy(cloud_frame_twc(x[sl])).to(dev)
             if mode == "host":
                 bufs = (clouds, edges, torch.from_numpy(sq[sl]).to(dev), torch.from_numpy(px[sl]).to(dev), torch.from_numpy(ref[sl]).to(dev))
                 keep.append(bufs + (Twc,))

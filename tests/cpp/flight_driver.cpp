@@ -6,8 +6,9 @@
 // Driven by tests/test_flight_gpu.py, which flies the same flights through the Python driver and compares bit for bit.
 //   flight_driver <in.bin> <out.bin> [max_frame_count]
 // With max_frame_count > 0 every robot flies with FrameKDMap's keyframe list in the slot (amk_pipeline_config.keyframes: the
-// reference's default regime, FrameKDMap.cpp:29-32): cloud frames then bring mCurFrame.Twc -- here the odometry position with R = I,
-// Tbc = I -- and PtIsInFrame's camera (the yaml's 640 x 480 / 10 sensor looking along +x).
+// reference's default regime, FrameKDMap.cpp:29-32): cloud frames then bring mCurFrame.Twc = Twb * T_b_c -- Twb = [I | odometry position],
+// T_b_c the yaml's extrinsic (mpc_parameters.yaml:67-71: the camera looks along the body's +x) -- and PtIsInFrame's camera (the yaml's
+// 640 x 480 / 10 sensor).
 // in.bin : int32 S, P, n, ne, K, max_iter ; double prm[9] = T dt speed safety decay height farest kp kd ; weights[25] tau[4] gains[4]
 //          lim[5] (aMinZ aMaxZ aMaxXy aMaxYawDot radius) ; x0[S*10] ; ref0[S*N*10] ;
 //          per period: float cloud[S*n*3], edge[S*ne*3]
@@ -26,6 +27,8 @@ template <class T>
 static void rd(FILE *f, T *p, size_t n) {
     if (fread(p, sizeof(T), n, f) != n) { fprintf(stderr, "short read\n"); exit(2); }
 }
+
+static const double kTbc[16] = {0.0, 0.0, 1.0, 0.05, -1.0, 0.0, 0.0, 0.0, 0.0, -1.0, 0.0, 0.01, 0.0, 0.0, 0.0, 1.0};   // mpc_parameters.yaml:67-71
 
 int main(int argc, char **argv) {
     if (argc < 3) return 1;
@@ -54,6 +57,7 @@ int main(int argc, char **argv) {
     if (max_frames > 0) {   // mpc_parameters.yaml:66,71-73
         cfg.keyframes.max_frame_count = max_frames; cfg.keyframes.keyframe_th_count = 10; cfg.keyframes.keyframe_th_dist = 0.1;
         cfg.keyframes.depth_min = 0.1;
+        for (int e = 0; e < 16; ++e) cfg.depth.Tbc[e] = kTbc[e];   // (mParamTbc reaches the slot's map through the depth configuration)
     }
     amk_frame_camera cam;
     cam.fx = 32.0; cam.fy = 32.0; cam.cx = 32.0; cam.cy = 24.0; cam.depth_max = 100.0; cam.width = 64; cam.height = 48;
@@ -86,11 +90,11 @@ int main(int argc, char **argv) {
         fr.d_cloud = d_cl; fr.d_edge = d_ed; fr.point_stride = 3;
         fr.d_odom = d_x; fr.d_cmd_out = d_cmd; fr.keep_warm_start = t > 0;
         fr.d_ref_path_init = t == 0 ? d_ref0 : nullptr;     // InitCircleState's role; afterwards the slot's own mRefPath
-        if (max_frames > 0) {   // mCurFrame.Twc of the frame (what DepthCallback's pose would give): position = odometry, R = I
+        if (max_frames > 0) {   // mCurFrame.Twc of the frame (what DepthCallback's pose would give): [I | odometry position] * T_b_c
             for (int s = 0; s < S; ++s) {
                 double *T = &Twc[16 * (size_t)s];
-                for (int e = 0; e < 16; ++e) T[e] = (e % 5 == 0) ? 1.0 : 0.0;
-                T[3] = x[10 * s]; T[7] = x[10 * s + 1]; T[11] = x[10 * s + 2];
+                for (int e = 0; e < 16; ++e) T[e] = kTbc[e];
+                T[3] += x[10 * s]; T[7] += x[10 * s + 1]; T[11] += x[10 * s + 2];
             }
             hipMemcpy(d_Twc, Twc.data(), sizeof(double) * Twc.size(), hipMemcpyHostToDevice);
             fr.d_Twc_cur = d_Twc; fr.camera = &cam;
