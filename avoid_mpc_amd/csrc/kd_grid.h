@@ -711,7 +711,7 @@ __device__ __forceinline__ double grid_nn1_thread(const GridScene &gs, double qx
 #define AMK_SWEEP_TILES 2
 #endif
 #ifndef AMK_SWEEP_RECS
-#define AMK_SWEEP_RECS 8
+#define AMK_SWEEP_RECS 6
 #endif
 constexpr int kSweepTiles = AMK_SWEEP_TILES;   // tiles whose bucket-table entries a sweep thread reads in one step
 constexpr int kSweepRecs = AMK_SWEEP_RECS;     // records of a run it reads in one step
@@ -731,8 +731,13 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
     // sqrt(d) <= th is decided without the square root except in a band of relative width 2e-15 around th^2 (the correctly rounded
     // sqrt and the rounded square differ from the real ones by < 2.3e-16 relative: outside the band both tests agree)
     const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
-    for (int iz = lo[2]; iz <= hi[2]; ++iz)
-        for (int iy = lo[1]; iy <= hi[1]; ++iy) {
+    // rows (iy, iz) of the cube, the query's OWN row first: that is where a point within th most likely lies, and the first one ends the walk
+    const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
+    const int own = (cell_of(q[2], b[2], inv_h, g[2]) - lo[2]) * ny + (cell_of(q[1], b[1], inv_h, g[1]) - lo[1]);
+    for (int r = 0; r < nrows; ++r) {
+        {
+            const int rr = r == 0 ? own : (r <= own ? r - 1 : r);
+            const int iz = lo[2] + rr / ny, iy = lo[1] + rr % ny;
             const int rowbase = (iz * g[1] + iy) * g[0];
             // the run of cells [lo x, hi x] of this row, tile by tile.  The walk is a chain of dependent loads (bucket table, then
             // the run's records) and nothing else: the table entries of kSweepTiles tiles are fetched together, then kSweepRecs
@@ -764,6 +769,7 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
                 }
             }
         }
+    }
     int finite = 0;   // an outlier needs a nearest point at all: does the index hold a point with finite coordinates?
     for (int t = 0; t < gs.nt; ++t) {
         const int *cst = gs.cs + (size_t)t * (kGridMaxCells + 2);
