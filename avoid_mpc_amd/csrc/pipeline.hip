@@ -472,10 +472,11 @@ int amk_pipeline_create(const amk_pipeline_config *cfg, amk_pipeline **out) {
         if ((st = amk_mpc_create(cfg->T, cfg->dt, cfg->nearest_point_num, GS, &s.mpc)) != AMK_OK) break;
         if (cfg->keyframes.max_frame_count > 0) {
             amk_kfmap_params kp = cfg->keyframes;
-            std::memcpy(kp.Tbc, cfg->depth.Tbc, sizeof kp.Tbc);
-            bool zero = true;
-            for (double v : kp.Tbc) zero = zero && v == 0.0;
-            if (zero) kp.Tbc[0] = kp.Tbc[5] = kp.Tbc[10] = kp.Tbc[15] = 1.0;   // (no depth configuration: camera frame = body frame)
+            auto all_zero = [](const double *T) { bool z = true; for (int e = 0; e < 16; ++e) z = z && T[e] == 0.0; return z; };
+            // mParamTbc: the map's own field when it is set, else the depth configuration's (one extrinsic serves both in the
+            // reference, FrameKDMap.cpp:15), else camera frame = body frame
+            if (all_zero(kp.Tbc)) std::memcpy(kp.Tbc, cfg->depth.Tbc, sizeof kp.Tbc);
+            if (all_zero(kp.Tbc)) kp.Tbc[0] = kp.Tbc[5] = kp.Tbc[10] = kp.Tbc[15] = 1.0;
             if ((st = amk_kfmap_create(GS, cfg->max_points, cfg->max_edge_points, &kp, &s.map)) != AMK_OK) break;
         }
         const size_t S = GS, N = amk_mpc_horizon(s.mpc);

@@ -293,7 +293,7 @@ class Pipeline:
 
     def __init__(self, n_slots, n_scenes, max_points, max_edge_points, prm, queue_depth=0, gang=0, farest_point=500.0,
                  slow_down_kp=0.3, slow_down_kd=0.3, iter_time=0.0, use_odom_est=True, depth=None, task="forward", keyframes=None):
-        """keyframes: dict(max_frame_count, th_dist, th_count, depth_min) -> every slot keeps a keyframe map (amk_kfmap)."""
+        """keyframes: dict(max_frame_count, th_dist, th_count, depth_min[, Tbc]) -> every slot keeps a keyframe map (amk_kfmap)."""
         self.lib = capi.load()
         task = capi.TaskParams(float(prm.decay), float(iter_time), float(farest_point), float(prm.height), float(slow_down_kp),
                                float(slow_down_kd), float(prm.a_max_xy), float(prm.a_max_z), int(bool(use_odom_est)),
@@ -302,8 +302,7 @@ class Pipeline:
                                   int(prm.K), int(queue_depth), int(gang),
                                   capi.StepParams(float(prm.speed), float(prm.safety_distance), int(prm.max_iter), 0), task,
                                   depth if depth is not None else capi.DepthParams(),
-                                  capi.KfmapParams(int(keyframes["max_frame_count"]), int(keyframes["th_count"]), float(keyframes["th_dist"]),
-                                                   float(keyframes["depth_min"])) if keyframes else capi.KfmapParams())
+                                  self._kfmap_params(keyframes))
         h = C.c_void_p()
         capi.check(self.lib.amk_pipeline_create(C.byref(cfg), C.byref(h)), "amk_pipeline_create")
         self.h, self.n_slots, self.S, self.prm = h, int(n_slots), int(n_scenes), prm
@@ -316,6 +315,19 @@ class Pipeline:
                      KdBatch(hs, max_edge_points, handle=self.lib.amk_pipeline_kd(h, i, 1))) for i in range(n_slots)]
         for m in self._mpc:
             m.configure(prm)
+
+    @staticmethod
+    def _kfmap_params(keyframes):
+        """amk_kfmap_params of the configuration; keyframes["Tbc"] (4 x 4, optional) is mParamTbc -- absent: the depth configuration's."""
+        if not keyframes:
+            return capi.KfmapParams()
+        kp = capi.KfmapParams(int(keyframes["max_frame_count"]), int(keyframes["th_count"]), float(keyframes["th_dist"]),
+                              float(keyframes["depth_min"]))
+        if keyframes.get("Tbc") is not None:
+            T = np.asarray(keyframes["Tbc"], np.float64).reshape(16)
+            for i in range(16):
+                kp.Tbc[i] = float(T[i])
+        return kp
 
     def kfmap_state(self, slot):
         """State of the slot's keyframe map (amk_kfmap_state_host): dict(n_keyframes, n_query_frames, last_outliers, frame_sizes)."""

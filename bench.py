@@ -335,9 +335,8 @@ def flight_main(args):
     # PtIsInFrame's camera for cloud frames: the yaml's 640 x 480 / 10 sensor (mpc_parameters.yaml:59-66) with the yaml's extrinsic
     # T_b_c (:67-71: 5 cm ahead of the body's origin, looking along its +x); mCurFrame.Twc = Twb * T_b_c, Twb = [I | odometry position]
     kf_cam = capi.FrameCamera(32.0, 32.0, 32.0, 24.0, 100.0, 64, 48) if kf else None
-    from avoid_mpc_amd.host import depth_params
-    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang, keyframes=kf,
-                  depth=depth_params(Tbc=flight.TBC_YAML) if kf else None)
+    pl = Pipeline(nslots, S, n, ne, prm, queue_depth=args.queue_depth if args.queue_depth > 0 else 2, gang=gang,
+                  keyframes=dict(kf, Tbc=flight.TBC_YAML) if kf else None)
     tbc = torch.from_numpy(flight.TBC_YAML).to(dev)
     Twc = [tbc.repeat(S, 1, 1).contiguous() for _ in range(B)] if kf else None
     for i in range(nslots):

@@ -353,7 +353,8 @@ typedef struct amk_kfmap_params {
     int keyframe_th_count;     /* mParamKeyframeCountTh, :72 (>= 1)                                                           */
     double keyframe_th_dist;   /* mParamKeyframeDistanceTh, :71                                                               */
     double depth_min;          /* mParamDepthMin (DroneBehindPts :247)                                                        */
-    double Tbc[16];            /* mParamTbc, row-major                                                                        */
+    double Tbc[16];            /* mParamTbc, row-major (amk_pipeline_config: all zero = take amk_depth_params.Tbc, and if that  */
+                               /* is all zero too the identity: camera frame = body frame)                                    */
 } amk_kfmap_params;
 typedef struct amk_pipeline_config {
     int n_slots;            /* independent steps in flight                                                              */

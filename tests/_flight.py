@@ -191,10 +191,8 @@ def gpu_flights(seeds, cfg="C2", periods=100, n_points=None, world_kw=None, batc
     task = (task_kw or {}).get("task", "forward")
     goal = None if not task_kw or task_kw.get("global_goal") is None else np.ascontiguousarray(task_kw["global_goal"], np.float64)
     from avoid_mpc_amd import capi
-    from avoid_mpc_amd.host import depth_params
     pl = Pipeline(nb // gang, B, n, n // 10, prm, queue_depth=1, gang=gang, task=task,
-                  keyframes=dict(keyframes, depth_min=0.1) if keyframes else None,
-                  depth=depth_params(Tbc=flight.TBC_YAML) if keyframes else None)   # (T_b_c reaches the slot's map through the depth configuration)
+                  keyframes=dict(keyframes, depth_min=0.1, Tbc=flight.TBC_YAML) if keyframes else None)
     kcam = capi.FrameCamera(*CLOUD_CAM[:5], int(CLOUD_CAM[5]), int(CLOUD_CAM[6])) if keyframes else None
     if keyframes:
         logs_kf = dict(n_keyframes=np.zeros((F, periods), np.int32), n_query_frames=np.zeros((F, periods), np.int32))

@@ -57,7 +57,7 @@ int main(int argc, char **argv) {
     if (max_frames > 0) {   // mpc_parameters.yaml:66,71-73
         cfg.keyframes.max_frame_count = max_frames; cfg.keyframes.keyframe_th_count = 10; cfg.keyframes.keyframe_th_dist = 0.1;
         cfg.keyframes.depth_min = 0.1;
-        for (int e = 0; e < 16; ++e) cfg.depth.Tbc[e] = kTbc[e];   // (mParamTbc reaches the slot's map through the depth configuration)
+        for (int e = 0; e < 16; ++e) cfg.keyframes.Tbc[e] = kTbc[e];   // mParamTbc
     }
     amk_frame_camera cam;
     cam.fx = 32.0; cam.fy = 32.0; cam.cx = 32.0; cam.cy = 24.0; cam.depth_max = 100.0; cam.width = 64; cam.height = 48;

@@ -52,6 +52,9 @@ if not PROFILES_ONLY:
                "under_rocprofv3_kernel_trace": last_json(os.path.join(src, "bench_under_rocprof.json")),
                "flight_workload_10x2_same_box": last_json(os.path.join(src, "bench_flight_10x2.json")),
                "flight_workload_keyframes_3_10x2": last_json(os.path.join(src, "bench_flight_keyframes3.json")),
+               "flight_yaml_config_keyframes_100_12x4": last_json(os.path.join(src, "bench_flight_yaml_keyframes100.json")),
+               "flight_yaml_config_keyframes_100_16x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_keyframes100_16x4.json")),
+               "flight_yaml_config_single_frame_12x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_single_frame.json")),
                "solve_budget_16_same_box": last_json(os.path.join(src, "bench_budget16.json")),
                "solve_budget_16_20_steps_same_box": last_json(os.path.join(src, "bench_budget16_20steps.json"))},
               open(os.path.join(dst, "r05_bench.json"), "w"), indent=1)
@@ -133,7 +136,7 @@ issue["valu_issue_util_at_saturation"] = issue["valu_instructions_per_wave_solve
 issue["lds_array_util_at_saturation (conflict level of the lone wave)"] = issue["lds_array_busy_cycles_per_wave"] / clk_per_solve_per_cu
 issue["wave_time_stretch_at_saturation"] = 8 * clk_per_solve_per_cu / issue["wave_cycles_per_wave"]
 issue["bound"] = ("dependent-operation latency at limited occupancy: a wave alone issues VALU %.0f %% of its time, LDS %.0f %%, "
-                  "and waits %.0f %%; LDS capacity (19.8 KB per scene) allows 8 waves per CU = 2 per SIMD, and at that occupancy "
+                  "and waits %.0f %%; the register file (230 VGPRs per wave; LDS: 17.8 KB per scene) allows 8 waves per CU = 2 per SIMD, and at that occupancy "
                   "the VALU pipes are %.0f %% busy and the LDS array %.0f %% -- neither is saturated, a wave just runs %.2fx "
                   "slower than alone because its dependent fp64 operations and LDS round trips interleave with one other "
                   "wave's; HBM and MFMA are not involved" % (
@@ -161,6 +164,18 @@ if os.path.exists(os.path.join(src, "kt_flight", "kt_results.db")):
         "rocprofv3 --kernel-trace --stats -- python bench.py --workload flight --periods 24 --no-parity (10 slots x gang 4, TASK mode; raw .db "
         "under gpurun_out/%s).  Cijk_* is the vehicle's addmm (torch, part of the workload).  rocprofv3's vgpr column is half the compiler's.\n\n" % tag
         + "\n".join(keep) + "\n")
+for sub, out, what in (("kt_flight_kf3", "r05_kernel_stats_flight_keyframes3_streams1.md",
+                        "--workload flight --keyframes 3 --streams 1 --gang 2 (50 k-point frames, 512-scene launches, one stream: clean kernel durations)"),
+                       ("kt_flight_yaml", "r05_kernel_stats_flight_yaml_keyframes100_streams1.md",
+                        "--workload flight --config yaml --keyframes 100 --streams 1 (3072-point frames, N = 30, K = 3, max_frame_count 100, 1024-scene launches, one stream)")):
+    dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(src, sub)) for f in fs if f.endswith(".db")]
+    if dbs:
+        md = run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), dbs[0]])
+        rows = [l for l in md.splitlines() if l.startswith("|")]
+        keep = rows[:2] + [l for l in rows[2:] if any(t in l for t in ("mpc_", "kd_", "kf_", "step_", "pipeline_", "Cijk", "rocclr"))]
+        open(os.path.join(dst, out), "w").write(
+            "rocprofv3 --kernel-trace --stats -- python bench.py %s (the closed loop with the keyframe map; raw .db under gpurun_out/%s).  "
+            "rocprofv3's vgpr column is half the compiler's.\n\n" % (what, tag) + "\n".join(keep) + "\n")
 for name, out in (("flight_c2_gpu_vs_oracle.json", "r05_flight_c2_gpu_vs_oracle.json"), ("rccl_presence.txt", "r05_rccl_presence.txt"),
                   ("exact_mode_cost.txt", "r05_exact_mode_cost.txt"), ("flight_tests.txt", "r05_flight_tests.txt"),
                   ("burst_timeline_10x4.txt", "r05_burst_timeline_10x4.txt")):

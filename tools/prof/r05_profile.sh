@@ -42,6 +42,12 @@ python tools/experiments/burst_timeline.py 10 4 20 > $OUT/burst_timeline_10x4.tx
 # 8. round 5: the keyframe map in the closed loop (10 slots x gang 2: the pool holds (N + 2) index slots per scene), the budgeted solve
 python bench.py --workload flight --streams 10 --gang 2 > $OUT/bench_flight_10x2.json 2>> $OUT/bench.err
 python bench.py --workload flight --streams 10 --gang 2 --keyframes 3 > $OUT/bench_flight_keyframes3.json 2>> $OUT/bench.err
+# 8b. the reference's own configuration (3072-point frames, N = 30, K = 3), with its default keyframe map (max_frame_count 100) and without
+python bench.py --workload flight --config yaml --keyframes 100 > $OUT/bench_flight_yaml_keyframes100.json 2>> $OUT/bench.err
+python bench.py --workload flight --config yaml --keyframes 100 --streams 16 --no-cpu-baseline --no-parity > $OUT/bench_flight_yaml_keyframes100_16x4.json 2>> $OUT/bench.err
+python bench.py --workload flight --config yaml --no-cpu-baseline --no-parity > $OUT/bench_flight_yaml_single_frame.json 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt_flight_kf3 -o kt -- python bench.py --workload flight --keyframes 3 --streams 1 --gang 2 --no-parity --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
+rocprofv3 --kernel-trace --stats -d $OUT/kt_flight_yaml -o kt -- python bench.py --workload flight --config yaml --keyframes 100 --streams 1 --no-parity --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 python bench.py --solve-budget 16 --no-cpu-baseline --no-parity > $OUT/bench_budget16.json 2>> $OUT/bench.err
 python bench.py --solve-budget 16 --steps 20 --warmup 5 --no-cpu-baseline --no-parity > $OUT/bench_budget16_20steps.json 2>> $OUT/bench.err
 cat $OUT/ms_parts.txt
