@@ -83,8 +83,8 @@ __global__ __launch_bounds__(512) void step_scan_kernel(const float *__restrict_
 // Same outputs through the bucketed indices (kd_grid.h), both trees in one launch: wavefront q < N answers
 // the K-NN of reference point q in the obstacle index, wavefront q == N the 1-NN of reference point 0 in
 // the edge index (the Edge-KD-tree query of PlanWapionts, :270).
-// <= 64 VGPRs (tests/test_abi.py): a CU that holds its 8 solve waves (2 x 224 registers per SIMD, 158.6 of 160 KB of LDS) still
-// has 64 registers per SIMD and 5 KB of LDS free -- exactly one block of this kernel (one wave per SIMD, 4.1 KB), which then runs
+// <= 48 VGPRs: a CU that holds its 8 solve waves (2 x 232 registers per SIMD, 142.6 of 160 KB of LDS since round 5) still
+// has 48 registers per SIMD and 17 KB of LDS free -- exactly one block of this kernel (one wave per SIMD), which then runs
 // in the issue slots the latency-bound solves leave empty instead of waiting for a CU to drain.
 __global__ __launch_bounds__(256) void step_knn_grid_kernel(GridPtrs gobs, GridPtrs gedge, int n_scenes,
                                                             const double *__restrict__ ref_path, int N, int K,

@@ -883,8 +883,8 @@ def main():
                                  "committed profile) x 4 issue cycles / (1024 SIMDs x 2.4 GHz): the share of the chip's VALU issue "
                                  "slots the dominant kernel fills while the builds and searches of the other steps share the CUs; "
                                  "frac_at_saturation_solves_only is the same quantity with nothing but solves resident "
-                                 "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (LDS 19.8 KB and 224 "
-                                 "VGPRs per scene) cannot cover ~32-cycle dependent fp64 issue and LDS round trips "
+                                 "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (230 VGPRs and 17.8 KB of LDS "
+                                 "per scene) cannot cover ~32-cycle dependent fp64 issue and LDS round trips "
                                  f"(profiles/{PROFILE_TAG}_pmc_solve_issue.md, DESIGN.md section 5)"},
             "roofline_hbm": roof_solve_hbm,
             "roofline_solve_issue": issue,
