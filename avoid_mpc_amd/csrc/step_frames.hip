@@ -83,14 +83,23 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
                                                               int N, int K, FrameBufs fb, const int *__restrict__ done, int fc,
                                                               const double *__restrict__ Twc, amk_frame_camera cam) {
     __shared__ GridWaveLds wl[4];
-    const int nq = N + 1;
-    const int bps = (nq + 3) / 4;
+    // map mode: reference point 0 is searched in EVERY frame (GetNearestDistance reads it, the snap may move it) -- one wavefront
+    // walking the ~6 frames of a flight's map in turn was the tail of every launch.  Frames 1 .. fc - 1 of the first chunk get a
+    // wavefront each: "queries" N + 1 .. N + fc - 1 are reference point 0 in frame q - N.
+    const int nq = N + 1, nv = MAP ? fc - 1 : 0;
+    const int bps = (nq + nv + 3) / 4;
     const int xcd = blockIdx.x & 7;
     const int j = blockIdx.x >> 3;
     const int s = (j / bps) * 8 + xcd;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)  /* wave-uniform: keeps what derives from it in SGPRs */, lane = threadIdx.x & 63;
-    const int q = (j % bps) * 4 + w;
-    if (s >= n_scenes || q >= nq || done[s]) return;
+    int q = (j % bps) * 4 + w;
+    if (s >= n_scenes || q >= nq + nv || done[s]) return;
+    int f_only = -1;
+    if (q >= nq) {
+        if (blockIdx.y != 0) return;
+        f_only = q - N;
+        q = 0;
+    }
     const bool is_edge = q == N;
     const double *qp = ref_path + ((size_t)s * N + (is_edge ? 0 : q)) * SD;
     const double qx = qp[0], qy = qp[1], qz = qp[2];
@@ -107,8 +116,13 @@ __global__ __launch_bounds__(256) void step_knn_frames_kernel(FrameSet fs, int n
     const GridPtrs pool = is_edge ? fs.edge[0] : fs.obs[0];   // (map mode: one set of pool pointers stays live over the loop)
     // map mode: chunk c = frames [fc (2^c - 1), fc (2^(c+1) - 1)) -- 8, 16, 32, ... of them: a map on a flight holds ~6 frames of its
     // 101, and every chunk beyond the first is a grid of blocks that find nothing to do
-    const int f_end = MAP ? min(fs.n, fc * ((2 << blockIdx.y) - 1)) : (int)blockIdx.y + 1;
-    for (int f = MAP ? fc * ((1 << blockIdx.y) - 1) : blockIdx.y; f < f_end; ++f) {
+    int f_begin = MAP ? fc * ((1 << blockIdx.y) - 1) : blockIdx.y;
+    int f_end = MAP ? min(fs.n, fc * ((2 << blockIdx.y) - 1)) : (int)blockIdx.y + 1;
+    if (MAP && blockIdx.y == 0) {
+        if (f_only >= 0) { f_begin = f_only; f_end = min(f_end, f_only + 1); }
+        else if (q == 0) f_end = min(f_end, 1);   // (its other frames of this chunk: the wavefronts above)
+    }
+    for (int f = f_begin; f < f_end; ++f) {
         if (cur_only && f > 0) break;
         const int m = MAP ? fs.fmap[(size_t)f * fs.S + s] : s;
         if (m < 0) continue;   // (map mode: this scene's map has no frame f; nobody reads its rows -- n_obs / n_edge are 0)
@@ -547,7 +561,7 @@ static int run_frames(const FrameSet &fs, amk_kd *const *obstacle, amk_kd *const
     while (fc * ((1 << n_chunks) - 1) < F) ++n_chunks;
     for (int iter = 0; iter < prm->mpc_max_iter; ++iter) {
         if (fs.fmap)
-            hipLaunchKernelGGL(step_knn_frames_kernel<true>, dim3(S8 * ((N + 4) / 4), n_chunks), dim3(256), 0, stream, fs, S,
+            hipLaunchKernelGGL(step_knn_frames_kernel<true>, dim3(S8 * ((N + 1 + (fc - 1) + 3) / 4), n_chunks), dim3(256), 0, stream, fs, S,
                                d_ref_path, N, K, fb, mpc->done.p, fc, d_Twc, c);
         else
             hipLaunchKernelGGL(step_knn_frames_kernel<false>, dim3(S8 * ((N + 4) / 4), F), dim3(256), 0, stream, fs, S, d_ref_path,

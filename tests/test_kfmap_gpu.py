@@ -184,7 +184,7 @@ def test_a_flight_with_the_reference_yaml_configuration():
 
 
 def test_cloud_frame_flights_with_the_keyframe_map_and_the_cpp_fleet_host(tmp_path):
-    """Frames handed over as clouds (+ mCurFrame.Twc = the odometry position, PtIsInFrame through the yaml's 64 x 48 camera), as
+    """Frames handed over as clouds (+ mCurFrame.Twc = [I | odometry position] * the yaml's T_b_c, PtIsInFrame through the yaml's 64 x 48 camera), as
     bench.py --workload flight --keyframes does: the pipeline's slot map against the oracle's list, host-driven and TASK mode,
     gang 1 and 2; then a C++ host that only knows include/avoid_mpc_amd.h (tests/cpp/flight_driver.cpp with a third argument)
     flies the same flights bit for bit."""
