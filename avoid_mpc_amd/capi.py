@@ -221,6 +221,7 @@ def load():
         "amk_depth_to_edge_cloud_host": (i, [vp, i, i, i, C.c_longlong, i, C.POINTER(DepthParams), vp, vp, i, C.c_longlong, vp]),
     }
     sig["amk__kd_set_mode"] = (i, [vp, i])  # internal: 0 bucketed index, 1 streaming scan
+    sig["amk__sweep_set_target"] = (None, [i])  # internal (tests, A/B): the pool's sweep against 1 a fine hashed grid of the current frame (default), 0 the frame's own index
     for name, (res, args) in sig.items():
         fn = getattr(lib, name, None)
         if fn is None:

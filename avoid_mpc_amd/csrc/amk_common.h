@@ -112,6 +112,11 @@ struct amk_kd {
     amk::DevBuf<double> ex_low, ex_high, ex_nbbox, ex_root;
     amk::DevBuf<unsigned char> flags; // [S][cap] keyframe sweep: 1 = outlier
     amk::DevBuf<int> sweep_cnt;       // [S][2]   {outliers, rebuilt}
+    // the keyframe map's pool only (kd_sweep_mapped): the sweep's target, per sweep ROW -- the current frame's points once more, sorted
+    // into a fine hashed grid (cells of 2.5 th), rebuilt before every sweep
+    amk::DevBuf<float4> sw_gpt;       // [rows][cap]               records, bucket by bucket
+    amk::DevBuf<int> sw_cs;           // [rows][kSweepBuckets + 1] bucket starts; the last entry = points with finite coordinates
+    int sw_rows = 0;
     // staging for the *_host conveniences: a private stream and one pinned host block, so that a single-query
     // SearchForNearest costs one small H2D copy, one launch, one D2H copy and a wait on THIS stream only (a device-wide
     // synchronisation would stall every other stream of the process: a ROS node calls this ~100 times per control period)

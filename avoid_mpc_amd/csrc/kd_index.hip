@@ -482,6 +482,13 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
     flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
 }
 
+// (A persistent-lane version of this kernel -- a wavefront owns 256-1024 records, its lanes draw queries as they finish -- was built when
+// the sensor-like flights showed that nearly every wavefront holds an outlier and runs at the outlier's pace: 9.3 -> 6.1 ms per
+// 512-scene sweep of 50 k-point frames, but slower on 3072-point frames, and beside the point once the pool swept against a fine grid:
+// tools/experiments/patches/r05_sweep_persistent_lanes.patch, profiles/r05_sweep_target.txt.)
+static int g_sweep_target = [] { const char *e = getenv("AMK_SWEEP_TARGET"); return e ? atoi(e) : 1; }();   // 1: the pool sweeps against a fine hashed grid of the current frame (below); 0: against the frame's own index (A/B, tests)
+extern "C" void amk__sweep_set_target(int v) { g_sweep_target = v; }
+
 // one block per scene: count the outliers; with >= th_count of them compact the keyframe's planes in place
 // (order preserved: the write cursor never passes the read cursor) and refresh size / bbox / max|coordinate|
 __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
@@ -636,6 +643,159 @@ __global__ __launch_bounds__(amk::kGridBuildThreads) void kd_grid_build_list_ker
                           ntiles, gparams);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The pool's sweep target as a FINE HASHED GRID.  The frames' own indices have cells of ~1 m at 50 k points (<= 1024 cells: what the
+// K-NN searches want), the sweep asks "any point within th = 0.1 m?": a query read 70 (inlier) to 1200 (outlier) candidates of the
+// few cells its cube touches -- 8.4 ms per 512-scene sweep even with every cell's points in one run, 62 % of a flight's kernel time
+// once the frames are a forward-looking sensor's and every robot sweeps every period (profiles/r05_sweep_target.txt).  Here the
+// current frame of every sweep row is sorted once more into cubic cells of edge 2.5 th on a world-fixed lattice, hashed into
+// kSweepBuckets buckets (a bucket may hold several cells: more candidates, the same answer -- the distance test decides): the cube of
+// a query touches <= 2 cells per axis, ~5 points each on a surface.  Points with a non-finite coordinate stay out (they are
+// within th of nothing); their absence is what `finite == 0` reports.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSweepBuckets = 16384;   // 64 KB of LDS histogram per build block
+constexpr int kSweepBuildThreads = 1024;
+
+__device__ __forceinline__ long long sweep_cell(double p, double inv_h) {
+    double c = floor(p * inv_h);
+    c = c < -1e15 ? -1e15 : (c > 1e15 ? 1e15 : c);   // monotone, and a long long for every float
+    return (long long)c;
+}
+__device__ __forceinline__ int sweep_bucket(long long ix, long long iy, long long iz) {
+    const unsigned long long h = (unsigned long long)ix * 73856093ull ^ (unsigned long long)iy * 19349663ull ^ (unsigned long long)iz * 83492791ull;
+    return (int)((h ^ (h >> 17)) & (unsigned long long)(kSweepBuckets - 1));
+}
+
+// one block per sweep row: counting sort of the current frame's points by bucket (LDS histogram, block scan, LDS cursors)
+__global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel(
+    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap, const int *__restrict__ sizes,
+    double inv_h, float4 *__restrict__ recs, int *__restrict__ table, const int *__restrict__ kf_list, const int *__restrict__ cur_list) {
+    extern __shared__ int hist[];   // [kSweepBuckets] + [kSweepBuildThreads / 64] wave sums
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    if (kf_list[row] < 0) return;   // (block-uniform)
+    const int sc = cur_list[row];
+    const int n = sizes[sc];
+    const float *xs = X + (size_t)sc * cap, *ys = Y + (size_t)sc * cap, *zs = Z + (size_t)sc * cap;
+    int *wsum = hist + kSweepBuckets;
+    int *tab = table + (size_t)row * (kSweepBuckets + 1);
+    float4 *out = recs + (size_t)row * cap;
+    for (int i = tid; i < kSweepBuckets; i += kSweepBuildThreads) hist[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += kSweepBuildThreads) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+        if (amk::finite3(x, y, z)) atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h))], 1);
+    }
+    __syncthreads();
+    // exclusive scan of the kSweepBuckets counts: kSweepBuckets / kSweepBuildThreads consecutive buckets per thread
+    constexpr int per = kSweepBuckets / kSweepBuildThreads;
+    int loc = 0;
+    for (int j = 0; j < per; ++j) loc += hist[tid * per + j];
+    const int incl = amk::wave_incl_scan_i32(loc);
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int j = 0; j < w; ++j) base += wsum[j];
+    int run = base + incl - loc;
+    for (int j = 0; j < per; ++j) {
+        const int c = hist[tid * per + j];
+        hist[tid * per + j] = run;   // the bucket's cursor
+        tab[tid * per + j] = run;
+        run += c;
+    }
+    if (tid == kSweepBuildThreads - 1) tab[kSweepBuckets] = run;   // = the points with finite coordinates
+    __syncthreads();
+    for (int i = tid; i < n; i += kSweepBuildThreads) {
+        const float x = xs[i], y = ys[i], z = zs[i];
+        if (amk::finite3(x, y, z)) {
+            const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h))], 1);
+            out[pos] = make_float4(x, y, z, __int_as_float(i));   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
+        }
+    }
+}
+
+// one thread per keyframe record (record order): the <= 8 cells of its cube, its own cell first; their table entries fetched together,
+// then kSweepStepH records of a run per step.  A query whose cube would span more than two cells along an axis (coordinates so large
+// that the rounding allowance exceeds the cell) takes the walk over the frame's own index instead.
+constexpr int kSweepStepH = 4;
+__global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
+                                                                 const float4 *__restrict__ trecs, const int *__restrict__ table,
+                                                                 double inv_h, const float4 *__restrict__ KGP, int kcap,
+                                                                 const int *__restrict__ ksizes, double th,
+                                                                 unsigned char *__restrict__ flags, const int *__restrict__ kf_list,
+                                                                 const int *__restrict__ cur_list) {
+    const int row = blockIdx.y;
+    const int s = kf_list[row];
+    if (s < 0) return;
+    const int sc = cur_list[row];
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ksizes[s]) return;
+    const float4 rec = KGP[(size_t)s * kcap + i];
+    const int *tab = table + (size_t)row * (kSweepBuckets + 1);
+    const float4 *pts = trecs + (size_t)row * kcap;
+    unsigned char f = 0;
+    const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
+    // SearchForNearest(pt, 1) yields a result only for a tree of more than one point (kd_tree_two.h:119-124), and an outlier needs a
+    // nearest point at all: a point with finite coordinates
+    if (cur_sizes[sc] > 1 && tab[kSweepBuckets] > 0 && qx == qx && qy == qy && qz == qz) {
+        const double h = 1.0 / inv_h;
+        const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);   // (rounding allowance, as grid_outlier_thread's)
+        const long long lx = sweep_cell(qx - rr, inv_h), hx = sweep_cell(qx + rr, inv_h);
+        const long long ly = sweep_cell(qy - rr, inv_h), hy = sweep_cell(qy + rr, inv_h);
+        const long long lz = sweep_cell(qz - rr, inv_h), hz = sweep_cell(qz + rr, inv_h);
+        if (hx - lx > 1 || hy - ly > 1 || hz - lz > 1) {
+            f = (unsigned char)amk::grid_outlier_thread(cur.scene(sc), qx, qy, qz, th);
+        } else {
+            const long long ox = sweep_cell(qx, inv_h), oy = sweep_cell(qy, inv_h), oz = sweep_cell(qz, inv_h);   // own cell: within [l, h]
+            const int nx = (int)(hx - lx) + 1, ny = (int)(hy - ly) + 1, nz = (int)(hz - lz) + 1, nc = nx * ny * nz;
+            const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+            int s0[8], s1[8];
+            f = 1;
+            {   // the query's own cell first, on its own: half the inliers end here and never ask for the other seven buckets
+                const int b = sweep_bucket(ox, oy, oz);
+                s0[0] = tab[b];
+                s1[0] = tab[b + 1];
+                for (int pos = s0[0]; f && pos < s1[0]; pos += kSweepStepH) {
+                    const int last = s1[0] - 1;
+                    float4 pr[kSweepStepH];
+#pragma unroll
+                    for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
+                    double d = amk::sq_dist(qx, qy, qz, pr[0].x, pr[0].y, pr[0].z);
+#pragma unroll
+                    for (int e = 1; e < kSweepStepH; ++e) d = fmin(d, amk::sq_dist(qx, qy, qz, pr[e].x, pr[e].y, pr[e].z));
+                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;   // (the test is monotone in d: the minimum decides for all)
+                }
+            }
+            if (f) {
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {   // cell k: bit set = the OTHER cell of that axis
+                s0[k] = s1[k] = 0;
+                if (k < nc) {
+                    const int kx = k % nx, ky = (k / nx) % ny, kz = k / (nx * ny);
+                    const long long cx = kx ? lx + hx - ox : ox, cy = ky ? ly + hy - oy : oy, cz = kz ? lz + hz - oz : oz;
+                    const int b = sweep_bucket(cx, cy, cz);
+                    s0[k] = tab[b];
+                    s1[k] = tab[b + 1];
+                }
+            }
+#pragma unroll
+            for (int k = 1; k < 8; ++k) {
+                for (int pos = s0[k]; f && pos < s1[k]; pos += kSweepStepH) {
+                    const int last = s1[k] - 1;
+                    float4 pr[kSweepStepH];
+#pragma unroll
+                    for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
+                    double d = amk::sq_dist(qx, qy, qz, pr[0].x, pr[0].y, pr[0].z);
+#pragma unroll
+                    for (int e = 1; e < kSweepStepH; ++e) d = fmin(d, amk::sq_dist(qx, qy, qz, pr[e].x, pr[e].y, pr[e].z));
+                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;
+                }
+            }
+            }
+        }
+    }
+    flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
+}
+
 namespace amk {
 static int pool_planes(amk_kd *kd) {   // the index-ordered planes of a pool handle: written by every build, compacted by the sweeps
     const size_t tot = (size_t)kd->n_scenes * kd->cap;
@@ -678,7 +838,30 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
     if (st != AMK_OK) return st;
     if (!pool->flags.p) AMK_HIP(pool->flags.alloc((size_t)pool->n_scenes * pool->cap));
     const amk::GridPtrs cur{pool->gpt.p, pool->cell_start.p, pool->gparams.p, pool->cap, pool->ntiles};
-    if (pool->max_points > 0)
+    if (pool->max_points > 0 && g_sweep_target) {   // the current frames once more, as fine hashed grids (one per sweep row)
+        if (pool->sw_rows < n_rows) {
+            if (pool->sw_rows > 0) AMK_HIP(hipDeviceSynchronize());   // (growing: earlier sweeps may still read the old arrays)
+            AMK_HIP(pool->sw_gpt.alloc((size_t)n_rows * pool->cap));
+            AMK_HIP(pool->sw_cs.alloc((size_t)n_rows * (kSweepBuckets + 1)));
+            pool->sw_rows = n_rows;
+            static bool attr_set = false;
+            if (!attr_set) {
+                AMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kd_sweep_hash_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64))));
+                attr_set = true;
+            }
+        }
+        static const double factor = [] { const char *e = getenv("AMK_SWEEP_CELL"); const double v = e ? atof(e) : 2.5; return v >= 2.1 ? v : 2.5; }();
+        const double cell = fmax(factor * th_dist, 1e-3);   // edge of a cell: the cube [q - th, q + th] touches <= 2 cells per axis
+        const double inv_h = 1.0 / cell;
+        hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64),
+                           stream, pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, inv_h, pool->sw_gpt.p, pool->sw_cs.p, d_kf_list,
+                           d_cur_list);
+        hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
+                           pool->sw_gpt.p, pool->sw_cs.p, inv_h, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list,
+                           d_cur_list);
+    }
+    else if (pool->max_points > 0)
         hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
                            pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list, d_cur_list);
     hipLaunchKernelGGL(kd_sweep_compact_kernel, dim3(n_rows), dim3(kCompactThreads), 0, stream, pool->x.p, pool->y.p, pool->z.p,

@@ -323,7 +323,11 @@ def flight_main(args):
     W = min(B, 4)                                            # distinct world sets (frames of W x P x 169 MB stay resident)
     # the corridor outlasts the flights (80 m holds the default 52 periods; beyond its last cylinder a frame degenerates)
     world_len = max(80.0, 8.0 + prm.speed * prm.dt * P + 30.0 + 10.0)
-    worlds = [flight.FlightWorldsTorch(S, n, prm, 9000 + w, dev, length=world_len) for w in range(W)]
+    # with the keyframe map the frames are what a forward-looking sensor returns: nothing behind the vehicle (points from 1 m ahead
+    # of the nominal position on).  A 360-degree cloud makes DroneBehindPts (FrameKDMap.cpp:233-252) pop every keyframe the period
+    # after its insertion -- its nearest points are beside and behind the drone at once -- and the map would stand empty half the time
+    back = (-1.0 if args.frames_behind is None else args.frames_behind) if args.keyframes > 0 else (6.0 if args.frames_behind is None else args.frames_behind)
+    worlds = [flight.FlightWorldsTorch(S, n, prm, 9000 + w, dev, length=world_len, back=back) for w in range(W)]
     t_gen = time.perf_counter()
     frames = [[worlds[w].frame(t) for t in range(P)] for w in range(W)]
     torch.cuda.synchronize()
@@ -498,6 +502,9 @@ def main():
                     help="flight workload: max_frame_count of the keyframe map every slot keeps (amk_pipeline_config.keyframes; 0: "
                          "single-frame map).  The reference's default regime (FrameKDMap.cpp:29-32); mind the pool: (N + 2) x "
                          "gang x scenes index slots per pipeline slot")
+    ap.add_argument("--frames-behind", type=float, default=None,
+                    help="flight workload: how far behind the nominal position a frame's points reach, metres (default 6; with "
+                         "--keyframes -1: the frame starts 1 m ahead, as a forward-looking sensor's does)")
     ap.add_argument("--periods", type=int, default=0, help="flight workload: control periods per flight (0: from --steps)")
     ap.add_argument("--inputs", default="device", choices=("device", "host"),
                     help="host: every step's clouds, edge clouds and odometry start in pinned host memory and cross PCIe inside the "

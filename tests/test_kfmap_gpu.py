@@ -38,14 +38,16 @@ def _scripted_frames(seed, prm, periods, world_kw):
     return world, xs
 
 
-@pytest.mark.parametrize("max_frames,th_count,wide", [(3, 10, 0), (6, 10, 1), (12, 40, 0), (100, 10, 0)])
-def test_map_follows_the_reference_list(max_frames, th_count, wide, torch_cuda):
+@pytest.mark.parametrize("max_frames,th_count,wide,target", [(3, 10, 0, 1), (6, 10, 1, 1), (12, 40, 0, 0), (100, 10, 0, 1)])
+def test_map_follows_the_reference_list(max_frames, th_count, wide, target, torch_cuda):
     """(wide = 1: the merge of maps with more than 1024 (frame, neighbour) candidates -- candidates re-read every round -- forced
-    on a small map; max_frames = 100: the yaml's own max_frame_count, mpc_parameters.yaml:73)"""
+    on a small map; max_frames = 100: the yaml's own max_frame_count, mpc_parameters.yaml:73; target = 0: the sweep against the
+    current frame's own index instead of its fine hashed grid, the default)"""
     torch = torch_cuda
     from avoid_mpc_amd import capi
     from avoid_mpc_amd.host import KfMap, MpcBatch
     capi.load().amk__frames_force_wide(int(wide))
+    capi.load().amk__sweep_set_target(int(target))
     prm, _ = _flight.make_prm("C1")
     c = _flight.DEPTH_CAM
     S, P = 6, 36
@@ -114,6 +116,7 @@ def test_map_follows_the_reference_list(max_frames, th_count, wide, torch_cuda):
     print(f"max_frame_count {max_frames}: keyframes at the end {nk_final}, query frames {[len(m.frames()) for m in omaps]}")
     gmap.close()
     capi.load().amk__frames_force_wide(0)
+    capi.load().amk__sweep_set_target(1)
 
 
 def test_argument_errors(torch_cuda):

@@ -1,0 +1,7 @@
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+O=gpurun_out/r05kfAp; mkdir -p $O; : > $O/err.txt
+for tg in 1 0; do
+rm -rf $O/kt; AMK_SWEEP_TARGET=$tg AMK_SWEEP_VARIANT=0 timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --workload flight --keyframes 3 --streams 1 --gang 2 --no-parity --no-cpu-baseline > /dev/null 2>> $O/err.txt
+db=$(find $O/kt -name "*.db" | head -1); echo "== target $tg"; python tools/rocprof_summary.py $db | grep -v "at::native\|Cijk\|rocprim" | head -14 | cut -c1-150
+done
+rm -rf $O/kt
