@@ -115,7 +115,7 @@ struct amk_kd {
     // the keyframe map's pool only (kd_sweep_mapped): the sweep's target, per sweep ROW -- the current frame's points once more, sorted
     // into a fine hashed grid (cells of 2.5 th), rebuilt before every sweep
     amk::DevBuf<float4> sw_gpt;       // [rows][cap]               records, bucket by bucket
-    amk::DevBuf<int> sw_cs;           // [rows][kSweepBuckets + 1] bucket starts; the last entry = points with finite coordinates
+    amk::DevBuf<int> sw_cs;           // [rows][buckets + 1] bucket starts; the last entry = points with finite coordinates
     int sw_rows = 0;
     // staging for the *_host conveniences: a private stream and one pinned host block, so that a single-query
     // SearchForNearest costs one small H2D copy, one launch, one D2H copy and a wait on THIS stream only (a device-wide

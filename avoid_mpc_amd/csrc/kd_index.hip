@@ -653,7 +653,7 @@ __global__ __launch_bounds__(amk::kGridBuildThreads) void kd_grid_build_list_ker
 // a query touches <= 2 cells per axis, ~5 points each on a surface.  Points with a non-finite coordinate stay out (they are
 // within th of nothing); their absence is what `finite == 0` reports.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSweepBuckets = 16384;   // 64 KB of LDS histogram per build block
+constexpr int kSweepBuckets = 16384;   // at most: 64 KB of LDS histogram per build block; a pool of small frames takes fewer (sweep_buckets)
 constexpr int kSweepBuildThreads = 1024;
 
 __device__ __forceinline__ long long sweep_cell(double p, double inv_h) {
@@ -661,33 +661,40 @@ __device__ __forceinline__ long long sweep_cell(double p, double inv_h) {
     c = c < -1e15 ? -1e15 : (c > 1e15 ? 1e15 : c);   // monotone, and a long long for every float
     return (long long)c;
 }
-__device__ __forceinline__ int sweep_bucket(long long ix, long long iy, long long iz) {
+__device__ __forceinline__ int sweep_bucket(long long ix, long long iy, long long iz, int nb) {
     const unsigned long long h = (unsigned long long)ix * 73856093ull ^ (unsigned long long)iy * 19349663ull ^ (unsigned long long)iz * 83492791ull;
-    return (int)((h ^ (h >> 17)) & (unsigned long long)(kSweepBuckets - 1));
+    return (int)((h ^ (h >> 17)) & (unsigned long long)(nb - 1));
+}
+// buckets of a pool's sweep grids: a power of two, about two per point, between 1024 and kSweepBuckets
+static int sweep_buckets(int max_points) {
+    int nb = 1024;
+    while (nb < kSweepBuckets && nb < 2 * max_points) nb *= 2;
+    return nb;
 }
 
 // one block per sweep row: counting sort of the current frame's points by bucket (LDS histogram, block scan, LDS cursors)
 __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel(
     const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap, const int *__restrict__ sizes,
-    double inv_h, float4 *__restrict__ recs, int *__restrict__ table, const int *__restrict__ kf_list, const int *__restrict__ cur_list) {
-    extern __shared__ int hist[];   // [kSweepBuckets] + [kSweepBuildThreads / 64] wave sums
+    double inv_h, int nb, float4 *__restrict__ recs, int *__restrict__ table, const int *__restrict__ kf_list,
+    const int *__restrict__ cur_list) {
+    extern __shared__ int hist[];   // [nb] + [kSweepBuildThreads / 64] wave sums
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     if (kf_list[row] < 0) return;   // (block-uniform)
     const int sc = cur_list[row];
     const int n = sizes[sc];
     const float *xs = X + (size_t)sc * cap, *ys = Y + (size_t)sc * cap, *zs = Z + (size_t)sc * cap;
-    int *wsum = hist + kSweepBuckets;
-    int *tab = table + (size_t)row * (kSweepBuckets + 1);
+    int *wsum = hist + nb;
+    int *tab = table + (size_t)row * (nb + 1);
     float4 *out = recs + (size_t)row * cap;
-    for (int i = tid; i < kSweepBuckets; i += kSweepBuildThreads) hist[i] = 0;
+    for (int i = tid; i < nb; i += kSweepBuildThreads) hist[i] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += kSweepBuildThreads) {
         const float x = xs[i], y = ys[i], z = zs[i];
-        if (amk::finite3(x, y, z)) atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h))], 1);
+        if (amk::finite3(x, y, z)) atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h), nb)], 1);
     }
     __syncthreads();
-    // exclusive scan of the kSweepBuckets counts: kSweepBuckets / kSweepBuildThreads consecutive buckets per thread
-    constexpr int per = kSweepBuckets / kSweepBuildThreads;
+    // exclusive scan of the nb counts: nb / kSweepBuildThreads consecutive buckets per thread (nb >= 1024 = the block)
+    const int per = nb / kSweepBuildThreads;
     int loc = 0;
     for (int j = 0; j < per; ++j) loc += hist[tid * per + j];
     const int incl = amk::wave_incl_scan_i32(loc);
@@ -702,12 +709,12 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
         tab[tid * per + j] = run;
         run += c;
     }
-    if (tid == kSweepBuildThreads - 1) tab[kSweepBuckets] = run;   // = the points with finite coordinates
+    if (tid == kSweepBuildThreads - 1) tab[nb] = run;   // = the points with finite coordinates
     __syncthreads();
     for (int i = tid; i < n; i += kSweepBuildThreads) {
         const float x = xs[i], y = ys[i], z = zs[i];
         if (amk::finite3(x, y, z)) {
-            const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h))], 1);
+            const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h), nb)], 1);
             out[pos] = make_float4(x, y, z, __int_as_float(i));   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
         }
     }
@@ -719,7 +726,7 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
 constexpr int kSweepStepH = 4;
 __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
                                                                  const float4 *__restrict__ trecs, const int *__restrict__ table,
-                                                                 double inv_h, const float4 *__restrict__ KGP, int kcap,
+                                                                 double inv_h, int nb, const float4 *__restrict__ KGP, int kcap,
                                                                  const int *__restrict__ ksizes, double th,
                                                                  unsigned char *__restrict__ flags, const int *__restrict__ kf_list,
                                                                  const int *__restrict__ cur_list) {
@@ -730,13 +737,13 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ksizes[s]) return;
     const float4 rec = KGP[(size_t)s * kcap + i];
-    const int *tab = table + (size_t)row * (kSweepBuckets + 1);
+    const int *tab = table + (size_t)row * (nb + 1);
     const float4 *pts = trecs + (size_t)row * kcap;
     unsigned char f = 0;
     const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
     // SearchForNearest(pt, 1) yields a result only for a tree of more than one point (kd_tree_two.h:119-124), and an outlier needs a
     // nearest point at all: a point with finite coordinates
-    if (cur_sizes[sc] > 1 && tab[kSweepBuckets] > 0 && qx == qx && qy == qy && qz == qz) {
+    if (cur_sizes[sc] > 1 && tab[nb] > 0 && qx == qx && qy == qy && qz == qz) {
         const double h = 1.0 / inv_h;
         const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);   // (rounding allowance, as grid_outlier_thread's)
         const long long lx = sweep_cell(qx - rr, inv_h), hx = sweep_cell(qx + rr, inv_h);
@@ -751,7 +758,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
             int s0[8], s1[8];
             f = 1;
             {   // the query's own cell first, on its own: half the inliers end here and never ask for the other seven buckets
-                const int b = sweep_bucket(ox, oy, oz);
+                const int b = sweep_bucket(ox, oy, oz, nb);
                 s0[0] = tab[b];
                 s1[0] = tab[b + 1];
                 for (int pos = s0[0]; f && pos < s1[0]; pos += kSweepStepH) {
@@ -772,7 +779,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
                 if (k < nc) {
                     const int kx = k % nx, ky = (k / nx) % ny, kz = k / (nx * ny);
                     const long long cx = kx ? lx + hx - ox : ox, cy = ky ? ly + hy - oy : oy, cz = kz ? lz + hz - oz : oz;
-                    const int b = sweep_bucket(cx, cy, cz);
+                    const int b = sweep_bucket(cx, cy, cz, nb);
                     s0[k] = tab[b];
                     s1[k] = tab[b + 1];
                 }
@@ -839,10 +846,11 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
     if (!pool->flags.p) AMK_HIP(pool->flags.alloc((size_t)pool->n_scenes * pool->cap));
     const amk::GridPtrs cur{pool->gpt.p, pool->cell_start.p, pool->gparams.p, pool->cap, pool->ntiles};
     if (pool->max_points > 0 && g_sweep_target) {   // the current frames once more, as fine hashed grids (one per sweep row)
+        const int nb = sweep_buckets(pool->max_points);
         if (pool->sw_rows < n_rows) {
             if (pool->sw_rows > 0) AMK_HIP(hipDeviceSynchronize());   // (growing: earlier sweeps may still read the old arrays)
             AMK_HIP(pool->sw_gpt.alloc((size_t)n_rows * pool->cap));
-            AMK_HIP(pool->sw_cs.alloc((size_t)n_rows * (kSweepBuckets + 1)));
+            AMK_HIP(pool->sw_cs.alloc((size_t)n_rows * (nb + 1)));
             pool->sw_rows = n_rows;
             static bool attr_set = false;
             if (!attr_set) {
@@ -854,12 +862,12 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
         static const double factor = [] { const char *e = getenv("AMK_SWEEP_CELL"); const double v = e ? atof(e) : 2.5; return v >= 2.1 ? v : 2.5; }();
         const double cell = fmax(factor * th_dist, 1e-3);   // edge of a cell: the cube [q - th, q + th] touches <= 2 cells per axis
         const double inv_h = 1.0 / cell;
-        hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64),
-                           stream, pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, inv_h, pool->sw_gpt.p, pool->sw_cs.p, d_kf_list,
-                           d_cur_list);
+        hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (nb + kSweepBuildThreads / 64),
+                           stream, pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, inv_h, nb, pool->sw_gpt.p, pool->sw_cs.p,
+                           d_kf_list, d_cur_list);
         hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
-                           pool->sw_gpt.p, pool->sw_cs.p, inv_h, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list,
-                           d_cur_list);
+                           pool->sw_gpt.p, pool->sw_cs.p, inv_h, nb, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p,
+                           d_kf_list, d_cur_list);
     }
     else if (pool->max_points > 0)
         hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
