@@ -720,10 +720,30 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
     }
 }
 
+// kSweepStepH records against one query.  The counters of the first version said what bounds this kernel: 3 000 VALU instructions per
+// wavefront, nearly all fp64 (11 per candidate: three conversions, the differences, the squares, the sum) at a quarter of the fp32
+// rate -- the arithmetic, not the loads (TA 66 % busy, 81 % of L2 requests hit).  So the candidates are screened in fp32 first: both
+// points ARE floats, the fp32 squared distance is within 3e-7 relative of the real one, and a candidate above t2 (1 + 1e-5) cannot pass
+// the exact test; only the few below it get the fp64 distance and the exact test (same bits as before: same flags).
+__device__ __forceinline__ bool sweep_step_hits(const float4 &q, const float4 (&pr)[4], float t2f, double qx, double qy, double qz, double th,
+                                                double t2lo, double t2hi) {
+    bool hit = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float dx = q.x - pr[e].x, dy = q.y - pr[e].y, dz = q.z - pr[e].z;
+        const float d32 = dx * dx + dy * dy + dz * dz;
+        if (d32 <= t2f) {
+            const double d = amk::sq_dist(qx, qy, qz, pr[e].x, pr[e].y, pr[e].z);
+            hit = hit || d <= t2lo || (d <= t2hi && sqrt(d) <= th);
+        }
+    }
+    return hit;
+}
+
 // one thread per keyframe record (record order): the <= 8 cells of its cube, its own cell first; their table entries fetched together,
 // then kSweepStepH records of a run per step.  A query whose cube would span more than two cells along an axis (coordinates so large
 // that the rounding allowance exceeds the cell) takes the walk over the frame's own index instead.
-constexpr int kSweepStepH = 4;
+constexpr int kSweepStepH = 4;   // (= the array bound of sweep_step_hits)
 __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
                                                                  const float4 *__restrict__ trecs, const int *__restrict__ table,
                                                                  double inv_h, int nb, const float4 *__restrict__ KGP, int kcap,
@@ -755,6 +775,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
             const long long ox = sweep_cell(qx, inv_h), oy = sweep_cell(qy, inv_h), oz = sweep_cell(qz, inv_h);   // own cell: within [l, h]
             const int nx = (int)(hx - lx) + 1, ny = (int)(hy - ly) + 1, nz = (int)(hz - lz) + 1, nc = nx * ny * nz;
             const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+            const float t2f = (float)(t2 * (1.0 + 1e-5)) * (1.0f + 1e-6f);   // fp32 screen: above it no candidate can pass the exact test
             int s0[8], s1[8];
             f = 1;
             {   // the query's own cell first, on its own: half the inliers end here and never ask for the other seven buckets
@@ -766,10 +787,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
                     float4 pr[kSweepStepH];
 #pragma unroll
                     for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
-                    double d = amk::sq_dist(qx, qy, qz, pr[0].x, pr[0].y, pr[0].z);
-#pragma unroll
-                    for (int e = 1; e < kSweepStepH; ++e) d = fmin(d, amk::sq_dist(qx, qy, qz, pr[e].x, pr[e].y, pr[e].z));
-                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;   // (the test is monotone in d: the minimum decides for all)
+                    if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
                 }
             }
             if (f) {
@@ -791,10 +809,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
                     float4 pr[kSweepStepH];
 #pragma unroll
                     for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
-                    double d = amk::sq_dist(qx, qy, qz, pr[0].x, pr[0].y, pr[0].z);
-#pragma unroll
-                    for (int e = 1; e < kSweepStepH; ++e) d = fmin(d, amk::sq_dist(qx, qy, qz, pr[e].x, pr[e].y, pr[e].z));
-                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;
+                    if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
                 }
             }
             }

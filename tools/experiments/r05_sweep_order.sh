@@ -1,18 +1,16 @@
-# the hashed sweep with the keyframe's points in the order of last sweep's grid (1) or in record order (0): flags (tests), flights, kernel time
+# the hashed sweep: flags (tests), sensor-like flights of both regimes with parity, mark / build kernel time of regime A
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05order; mkdir -p $O; : > $O/err.txt
 [ -z "$SKIPTESTS" ] && timeout 900 python -m pytest tests/test_keyframe_gpu.py tests/test_kfmap_gpu.py -x -q 2>&1 | tail -3
-for od in 1 0; do
-  AMK_SWEEP_ORDER=$od timeout 900 python bench.py --workload flight --keyframes 3 --streams 10 --gang 2 > $O/A.json 2>> $O/err.txt
-  AMK_SWEEP_ORDER=$od timeout 900 python bench.py --workload flight --config yaml --keyframes 100 > $O/B.json 2>> $O/err.txt
-  python - <<PY
+timeout 900 python bench.py --workload flight --keyframes 3 --streams 10 --gang 2 > $O/A.json 2>> $O/err.txt
+timeout 900 python bench.py --workload flight --config yaml --keyframes 100 > $O/B.json 2>> $O/err.txt
+python - <<PY
 import json
 for r in "AB":
     d = json.loads([l for l in open("$O/%s.json" % r).read().splitlines() if l.startswith("{")][-1])
     p = (d.get("parity") or {}).get("flights_vs_cpu_oracle") or {}
-    print("order $od regime", r, d["value"], d["flight"]["x_final_mean_m"], d["flight"]["solves_per_step"], {k: p.get(k) for k in ("separated", "dpos_max_while_flags_agree_m", "ok")})
+    print("regime", r, d["value"], d["flight"]["x_final_mean_m"], d["flight"]["solves_per_step"], {k: p.get(k) for k in ("separated", "dpos_max_while_flags_agree_m", "ok")})
 PY
-  rm -rf $O/kt; AMK_SWEEP_ORDER=$od timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --workload flight --keyframes 3 --streams 1 --gang 2 --periods 30 --no-parity --no-cpu-baseline > /dev/null 2>> $O/err.txt
-  db=$(find $O/kt -name "*.db" | head -1); python tools/rocprof_summary.py $db | grep "sweep_mark_hash\|hash_build" | cut -c1-110
-done
+rm -rf $O/kt; timeout 900 rocprofv3 --kernel-trace --stats -d $O/kt -o kt -- python bench.py --workload flight --keyframes 3 --streams 1 --gang 2 --periods 30 --no-parity --no-cpu-baseline > /dev/null 2>> $O/err.txt
+db=$(find $O/kt -name "*.db" | head -1); python tools/rocprof_summary.py $db | grep "sweep_mark_hash\|hash_build\|mpc_solve" | cut -c1-110
 rm -rf $O/kt; tail -2 $O/err.txt
