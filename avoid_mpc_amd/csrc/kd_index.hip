@@ -688,9 +688,18 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
     float4 *out = recs + (size_t)row * cap;
     for (int i = tid; i < nb; i += kSweepBuildThreads) hist[i] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += kSweepBuildThreads) {
-        const float x = xs[i], y = ys[i], z = zs[i];
-        if (amk::finite3(x, y, z)) atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h), nb)], 1);
+    constexpr int U = 4;   // points per thread and trip: their loads fly together (a block's passes are two chains of dependent trips)
+    for (int i0 = tid; i0 < n; i0 += U * kSweepBuildThreads) {
+        float x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * kSweepBuildThreads, n - 1);
+            x[u] = xs[i]; y[u] = ys[i]; z[u] = zs[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + u * kSweepBuildThreads < n && amk::finite3(x[u], y[u], z[u]))
+                atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_h), sweep_cell(y[u], inv_h), sweep_cell(z[u], inv_h), nb)], 1);
     }
     __syncthreads();
     // exclusive scan of the nb counts: nb / kSweepBuildThreads consecutive buckets per thread (nb >= 1024 = the block)
@@ -711,11 +720,20 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
     }
     if (tid == kSweepBuildThreads - 1) tab[nb] = run;   // = the points with finite coordinates
     __syncthreads();
-    for (int i = tid; i < n; i += kSweepBuildThreads) {
-        const float x = xs[i], y = ys[i], z = zs[i];
-        if (amk::finite3(x, y, z)) {
-            const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x, inv_h), sweep_cell(y, inv_h), sweep_cell(z, inv_h), nb)], 1);
-            out[pos] = make_float4(x, y, z, __int_as_float(i));   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
+    for (int i0 = tid; i0 < n; i0 += U * kSweepBuildThreads) {
+        float x[U], y[U], z[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = min(i0 + u * kSweepBuildThreads, n - 1);
+            x[u] = xs[i]; y[u] = ys[i]; z[u] = zs[i];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * kSweepBuildThreads;
+            if (i < n && amk::finite3(x[u], y[u], z[u])) {
+                const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_h), sweep_cell(y[u], inv_h), sweep_cell(z[u], inv_h), nb)], 1);
+                out[pos] = make_float4(x[u], y[u], z[u], __int_as_float(i));   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
+            }
         }
     }
 }
