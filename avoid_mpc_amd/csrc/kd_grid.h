@@ -11,6 +11,7 @@
 // to everything not yet visited.  That is the same branch-and-bound argument as nanoflann's
 // searchLevel (mindist <= worstDist, :1780-1790), applied to rings instead of half-spaces.
 #pragma once
+#include <cfloat>
 #include <type_traits>
 #include "kd_device.h"
 
@@ -731,6 +732,10 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
     // sqrt(d) <= th is decided without the square root except in a band of relative width 2e-15 around th^2 (the correctly rounded
     // sqrt and the rounded square differ from the real ones by < 2.3e-16 relative: outside the band both tests agree)
     const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+    // the query as floats: exact when it IS a float (the sweep's queries are records); otherwise the screen is off
+    const float qxf = (float)qx, qyf = (float)qy, qzf = (float)qz;
+    const bool q_is_float = (double)qxf == qx && (double)qyf == qy && (double)qzf == qz;
+    const float t2f = q_is_float ? (float)(t2 * (1.0 + 1e-5)) * (1.0f + 1e-6f) : __builtin_inff();
     // rows (iy, iz) of the cube, the query's OWN row first: that is where a point within th most likely lies, and the first one ends the walk
     const int ny = hi[1] - lo[1] + 1, nrows = ny * (hi[2] - lo[2] + 1);
     const int own = (cell_of(q[2], b[2], inv_h, g[2]) - lo[2]) * ny + (cell_of(q[1], b[1], inv_h, g[1]) - lo[1]);
@@ -759,6 +764,16 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
                         float4 p[kSweepRecs];
 #pragma unroll
                         for (int e = 0; e < kSweepRecs; ++e) p[e] = gs.pt[min(pos + e, last)];
+                        // fp32 screen (both points are floats; the fp32 squared distance is within 3e-7 relative of the real one): a
+                        // step none of whose records comes within t2 (1 + 1e-5) cannot pass the exact test -- fp64 arithmetic, at a
+                        // quarter of the fp32 rate, was what bounded the sweep (profiles/r05_sweep_target.txt)
+                        float m32 = FLT_MAX;
+#pragma unroll
+                        for (int e = 0; e < kSweepRecs; ++e) {
+                            const float dx = qxf - p[e].x, dy = qyf - p[e].y, dz = qzf - p[e].z;
+                            m32 = fminf(m32, dx * dx + dy * dy + dz * dz);
+                        }
+                        if (!(m32 <= t2f)) continue;
                         double d = sq_dist(qx, qy, qz, p[0].x, p[0].y, p[0].z);
 #pragma unroll
                         for (int e = 1; e < kSweepRecs; ++e) d = fmin(d, sq_dist(qx, qy, qz, p[e].x, p[e].y, p[e].z));
