@@ -1,3 +1,5 @@
+# (history: AMK_SWEEP_VARIANT / AMK_SWEEP_TARGET=1 meant the persistent-lane kernel / the one-tile target when this ran; both are patches now
+#  -- tools/experiments/patches/r05_sweep_persistent_lanes.patch -- and AMK_SWEEP_TARGET=1 is the fine hashed grid, the default)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/r05kfAp; mkdir -p $O; : > $O/err.txt
 for tg in 1 0; do

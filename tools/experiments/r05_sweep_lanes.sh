@@ -1,3 +1,5 @@
+# (history: AMK_SWEEP_VARIANT selected the persistent-lane kernel when this ran; it is a patch now -- tools/experiments/patches/
+#  r05_sweep_persistent_lanes.patch -- and the variable is ignored; AMK_SWEEP_TARGET=0 still selects the walk over the frame's own index)
 # the pool's sweep: target = the current frame's own index (0) or its fine hashed grid (1); flags (tests), sensor-like flights of both
 # regimes, single-stream kernel time of regime A
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
