@@ -410,6 +410,12 @@ def flight_main(args):
              "unsafe_periods": int((fl[..., 0] == 0).sum()), "capped_solves": int((fl[..., 2] > 0).sum()),
              "min_clearance_median_m": round(float(np.median(cmin)), 3), "flights_inside_drone_radius": int((cmin < prm.radius).sum()),
              "flights_through_a_cylinder": int((cmin < 0).sum()), "x_final_mean_m": round(float(pos[:, :, -1, 0].mean()), 2)}
+    if kf:   # what the maps hold at the end of the flights (a map that stands empty would make the sweep and the merges free)
+        ms = [pl.kfmap_state(i) for i in range(nslots)]
+        nk = np.concatenate([m["n_keyframes"] for m in ms]); nq = np.concatenate([m["n_query_frames"] for m in ms])
+        stats["keyframes_at_end_mean_max"] = [round(float(nk.mean()), 2), int(nk.max())]
+        stats["query_frames_at_end_mean_max"] = [round(float(nq.mean()), 2), int(nq.max())]
+        stats["outliers_of_the_last_sweep_mean"] = round(float(np.concatenate([m["last_outliers"] for m in ms]).mean()), 1)
     parity = None
     if not args.no_cpu_baseline and not args.no_parity:
         # the same flights on the CPU oracle: a sample of batch 0, on the frames the GPU saw

@@ -50,3 +50,22 @@ def test_bench_flight_line():
     assert f["flights"] == 4 * 32 and f["solves_per_step"] >= 1.0 and f["ipm_iters_per_step"] < f["ipm_iters_first_period"] * 2
     p = d["parity"]["flights_vs_cpu_oracle"]
     assert p["ok"] and p["dpos_max_while_flags_agree_m"] <= 1e-6, p
+
+
+def test_bench_flight_line_with_the_keyframe_map():
+    """bench.py --workload flight --config yaml --keyframes 100, small shape: the reference's own configuration (3072-point frames of a
+    forward-looking sensor, N = 30, K = 3, max_frame_count 100) with the keyframe map in every slot; the map must actually hold
+    keyframes (frames that reach behind the vehicle would empty it every other period: DESIGN.md section 15, row 6), and the
+    timed run's own flights agree with the CPU oracle's map and step."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "flight", "--config", "yaml", "--keyframes", "100",
+                        "--streams", "2", "--gang", "2", "--scenes", "16", "--periods", "30", "--warmup", "2"], capture_output=True,
+                       text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] > 0 and d["config"]["points"] == 3072 and d["config"]["horizon"] == 30 and d["config"]["K"] == 3
+    assert d["flight"]["flights"] == 4 * 16 and d["steps"] == 4 * 30
+    assert d["flight"]["keyframes_at_end_mean_max"][0] >= 2.0 and d["flight"]["outliers_of_the_last_sweep_mean"] > 0, d["flight"]
+    p = d["parity"]["flights_vs_cpu_oracle"]
+    assert p["ok"] and p["dpos_max_while_flags_agree_m"] <= 1e-6, p
