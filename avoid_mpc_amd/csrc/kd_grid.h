@@ -765,8 +765,8 @@ __device__ __forceinline__ int grid_outlier_thread(const GridScene &gs, double q
 #pragma unroll
                         for (int e = 0; e < kSweepRecs; ++e) p[e] = gs.pt[min(pos + e, last)];
                         // fp32 screen (both points are floats; the fp32 squared distance is within 3e-7 relative of the real one): a
-                        // step none of whose records comes within t2 (1 + 1e-5) cannot pass the exact test -- fp64 arithmetic, at a
-                        // quarter of the fp32 rate, was what bounded the sweep (profiles/r05_sweep_target.txt)
+                        // step none of whose records comes within t2 (1 + 1e-5) cannot pass the exact test -- the candidates' fp64
+                        // distances (11 VALU instructions each) were what bounded the sweep (profiles/r05_sweep_target.txt)
                         float m32 = FLT_MAX;
 #pragma unroll
                         for (int e = 0; e < kSweepRecs; ++e) {

@@ -739,8 +739,8 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
 }
 
 // kSweepStepH records against one query.  The counters of the first version said what bounds this kernel: 3 000 VALU instructions per
-// wavefront, nearly all fp64 (11 per candidate: three conversions, the differences, the squares, the sum) at a quarter of the fp32
-// rate -- the arithmetic, not the loads (TA 66 % busy, 81 % of L2 requests hit).  So the candidates are screened in fp32 first: both
+// wavefront -- the VALU pipes ~90 % busy, most of it the candidates' fp64 distances (11 instructions each: three conversions, the
+// differences, the squares, the sum) -- not the loads (TA 66 % busy, 81 % of L2 requests hit).  So the candidates are screened in fp32 first: both
 // points ARE floats, the fp32 squared distance is within 3e-7 relative of the real one, and a candidate above t2 (1 + 1e-5) cannot pass
 // the exact test; only the few below it get the fp64 distance and the exact test (same bits as before: same flags).
 __device__ __forceinline__ bool sweep_step_hits(const float4 &q, const float4 (&pr)[4], float t2f, double qx, double qy, double qz, double th,
