@@ -667,6 +667,8 @@ __device__ __forceinline__ int sweep_bucket(long long ix, long long iy, long lon
 }
 // buckets of a pool's sweep grids: a power of two, about two per point, between 1024 and kSweepBuckets
 static int sweep_buckets(int max_points) {
+    static const int forced = [] { const char *e = getenv("AMK_SWEEP_NB"); return e ? atoi(e) : 0; }();   // (experiments: a power of two in [1024, 16384])
+    if (forced >= 1024 && forced <= kSweepBuckets && (forced & (forced - 1)) == 0) return forced;
     int nb = 1024;
     while (nb < kSweepBuckets && nb < 2 * max_points) nb *= 2;
     return nb;
@@ -760,7 +762,7 @@ __device__ __forceinline__ bool sweep_step_hits(const float4 &q, const float4 (&
 
 // one thread per keyframe record (record order): the <= 8 cells of its cube, its own cell first; their table entries fetched together,
 // then kSweepStepH records of a run per step.  A query whose cube would span more than two cells along an axis (coordinates so large
-// that the rounding allowance exceeds the cell) takes the walk over the frame's own index instead.
+// that the rounding allowance exceeds the cell) reads every point of the grid instead.
 constexpr int kSweepStepH = 4;   // (= the array bound of sweep_step_hits)
 __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
                                                                  const float4 *__restrict__ trecs, const int *__restrict__ table,
@@ -788,7 +790,15 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs c
         const long long ly = sweep_cell(qy - rr, inv_h), hy = sweep_cell(qy + rr, inv_h);
         const long long lz = sweep_cell(qz - rr, inv_h), hz = sweep_cell(qz + rr, inv_h);
         if (hx - lx > 1 || hy - ly > 1 || hz - lz > 1) {
-            f = (unsigned char)amk::grid_outlier_thread(cur.scene(sc), qx, qy, qz, th);
+            // coordinates so large that the rounding allowance exceeds a cell: every point of the grid is a candidate (a plain loop --
+            // the walk over the frame's own index, inlined here, cost this kernel 10 registers = one wavefront per SIMD: 1.72 -> 1.83 ms)
+            const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+            f = 1;
+            for (int j = 0; f && j < tab[nb]; ++j) {
+                const float4 p = pts[j];
+                const double d = amk::sq_dist(qx, qy, qz, p.x, p.y, p.z);
+                if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;
+            }
         } else {
             const long long ox = sweep_cell(qx, inv_h), oy = sweep_cell(qy, inv_h), oz = sweep_cell(qz, inv_h);   // own cell: within [l, h]
             const int nx = (int)(hx - lx) + 1, ny = (int)(hy - ly) + 1, nz = (int)(hz - lz) + 1, nc = nx * ny * nz;
