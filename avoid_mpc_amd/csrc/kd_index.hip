@@ -764,7 +764,7 @@ __device__ __forceinline__ bool sweep_step_hits(const float4 &q, const float4 (&
 // then kSweepStepH records of a run per step.  A query whose cube would span more than two cells along an axis (coordinates so large
 // that the rounding allowance exceeds the cell) reads every point of the grid instead.
 constexpr int kSweepStepH = 4;   // (= the array bound of sweep_step_hits)
-__global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(amk::GridPtrs cur, const int *__restrict__ cur_sizes,
+__global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__restrict__ cur_sizes,
                                                                  const float4 *__restrict__ trecs, const int *__restrict__ table,
                                                                  double inv_h, int nb, const float4 *__restrict__ KGP, int kcap,
                                                                  const int *__restrict__ ksizes, double th,
@@ -908,7 +908,7 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
         hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (nb + kSweepBuildThreads / 64),
                            stream, pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, inv_h, nb, pool->sw_gpt.p, pool->sw_cs.p,
                            d_kf_list, d_cur_list);
-        hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
+        hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, pool->size.p,
                            pool->sw_gpt.p, pool->sw_cs.p, inv_h, nb, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p,
                            d_kf_list, d_cur_list);
     }
