@@ -10,6 +10,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libavoid_mpc_amd.so")
 
 AMK_OK, AMK_ERR_INVALID_ARG, AMK_ERR_HIP, AMK_ERR_NO_DEVICE, AMK_ERR_UNSUPPORTED, AMK_ERR_TIMEOUT = 0, 1, 2, 3, 4, 5   # include/avoid_mpc_amd.h
+AMK_TIES_LOWEST_INDEX, AMK_TIES_NANOFLANN = 0, 1
+AMK_EXACT_OFF, AMK_EXACT_IN_USE, AMK_EXACT_GAVE_UP, AMK_EXACT_TOO_DEEP = -1, 0, 1, 2   # amk_kd_exact_status
 AMK_MAX_K = 64
 AMK_MAX_QUERIES = 64
 AMK_MAX_HORIZON = 32
@@ -27,11 +29,11 @@ PLUGIN_SYMBOLS = [f for f in PLUGIN_FUNCTIONS] + [f + "_" + h for f in PLUGIN_FU
 SYMBOLS = [
     "amk_version", "amk_status_string", "amk_last_hip_error", "amk_device_count",
     "amk_kd_create", "amk_kd_destroy", "amk_kd_build", "amk_kd_build_pair", "amk_kd_sizes", "amk_kd_search",
-    "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_set_tie_order", "amk_kd_keyframe_sweep",
+    "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_set_tie_order", "amk_kd_exact_status", "amk_kd_exact_status_host", "amk_kd_keyframe_sweep",
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
     "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
-    "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_reset", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
+    "amk_kfmap_pool_bytes", "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_reset", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
     "amk_kfmap_update", "amk_kfmap_step", "amk_kfmap_state_host",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_solve_budget", "amk_mpc_set_precision", "amk_mpc_solve",
     "amk_mpc_get_warm_start", "amk_mpc_set_warm_start", "amk_mpc_reset_warm_start",
@@ -139,6 +141,8 @@ def load():
         "amk_kd_search": (i, [vp, vp, i, i, vp, vp, vp, vp, vp]),
         "amk_kd_tie_flags": (i, [vp, vp, i, i, i, vp, vp]),
         "amk_kd_set_tie_order": (i, [vp, i]),
+        "amk_kd_exact_status": (i, [vp, vp, vp]),
+        "amk_kd_exact_status_host": (i, [vp, vp]),
         "amk_kd_keyframe_sweep": (i, [vp, vp, d, i, vp, vp, vp]),
         "amk_kd_keyframe_sweep_host": (i, [vp, vp, d, i, vp, vp]),
         "amk_kd_points_host": (i, [vp, vp, vp]),
@@ -191,6 +195,7 @@ def load():
         "amk_pipeline_query": (i, [vp, i]),
         "amk_pipeline_drain": (i, [vp]),
         "amk_pipeline_outputs": (i, [vp, i, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]),
+        "amk_kfmap_pool_bytes": (i, [i, i, i, i, C.POINTER(C.c_longlong)]),
         "amk_kfmap_create": (i, [i, i, i, C.POINTER(KfmapParams), C.POINTER(vp)]),
         "amk_kfmap_destroy": (i, [vp]),
         "amk_kfmap_reset": (i, [vp, i, i, vp]),

@@ -895,13 +895,11 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
             AMK_HIP(pool->sw_gpt.alloc((size_t)n_rows * pool->cap));
             AMK_HIP(pool->sw_cs.alloc((size_t)n_rows * (nb + 1)));
             pool->sw_rows = n_rows;
-            static bool attr_set = false;
-            if (!attr_set) {
-                AMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kd_sweep_hash_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64))));
-                attr_set = true;
-            }
         }
+        // > 64 KB of dynamic LDS needs the attribute; it is per device and the call is cheap, so it is made before every launch
+        // (a process-wide flag would leave a second device, or a second thread's first launch, without it)
+        AMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kd_sweep_hash_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)(sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64))));
         static const double factor = [] { const char *e = getenv("AMK_SWEEP_CELL"); const double v = e ? atof(e) : 2.5; return v >= 2.1 ? v : 2.5; }();
         const double cell = fmax(factor * th_dist, 1e-3);   // edge of a cell: the cube [q - th, q + th] touches <= 2 cells per axis
         const double inv_h = 1.0 / cell;
@@ -1143,6 +1141,51 @@ int amk__kd_exact_trace(amk_kd *kd, unsigned *h, int n) {
     return AMK_OK;
 }
 #endif
+
+// depth of every scene's reference-shaped tree: children are created after their parent (ids grow downwards), so one pass in
+// id order carries the depths; one lane per scene, the build's list scratch (sa) holds depth[node] -- a diagnostic call
+static __global__ __launch_bounds__(64) void kd_exact_status_kernel(int S, const int *__restrict__ n_nodes, const int *__restrict__ feat,
+                                                             const int *__restrict__ child, unsigned *__restrict__ scratch,
+                                                             int max_nodes, int cap, int *__restrict__ status) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s >= S) return;
+    const int nn = n_nodes[s];
+    if (nn < 0) { status[s] = AMK_EXACT_GAVE_UP; return; }
+    const int *f = feat + (size_t)s * max_nodes, *c = child + (size_t)s * max_nodes;
+    unsigned *d = scratch + (size_t)s * cap;
+    unsigned deepest = 0;
+    if (nn > 0) d[0] = 0;
+    for (int id = 0; id < nn; ++id) {
+        const unsigned dep = d[id];
+        if (f[id] >= 0) { d[c[id]] = dep + 1; d[c[id] + 1] = dep + 1; }   // an internal node: the traversal pushes one frame here
+        else deepest = dep > deepest ? dep : deepest;                      // a leaf at depth dep is reached with dep frames on the stack
+    }
+    status[s] = deepest > (unsigned)amk::kExactMaxDepth ? AMK_EXACT_TOO_DEEP : AMK_EXACT_IN_USE;
+}
+
+// Which index answers a handle's searches, per scene (header).  Stream-ordered.
+int amk_kd_exact_status(amk_kd *kd, int *d_status, void *stream) {
+    if (!kd || !d_status) return AMK_ERR_INVALID_ARG;
+    if (!kd->tie_order || !kd->ex_valid || !kd->ex_nn.p) {   // the bucketed index answers everything: not a fallback
+        AMK_HIP(hipMemsetAsync(d_status, 0xff, sizeof(int) * kd->n_scenes, (hipStream_t)stream));   // AMK_EXACT_OFF == -1
+        return AMK_OK;
+    }
+    hipLaunchKernelGGL(kd_exact_status_kernel, dim3((kd->n_scenes + 63) / 64), dim3(64), 0, (hipStream_t)stream, kd->n_scenes,
+                       kd->ex_nn.p, kd->ex_feat.p, kd->ex_child.p, kd->ex_sa.p, kd->ex_max_nodes, kd->cap, d_status);
+    AMK_HIP(hipGetLastError());
+    return AMK_OK;
+}
+
+int amk_kd_exact_status_host(amk_kd *kd, int *h_status) {   // synchronises
+    if (!kd || !h_status) return AMK_ERR_INVALID_ARG;
+    amk::DevBuf<int> d;
+    AMK_HIP(d.alloc(kd->n_scenes));
+    const int st = amk_kd_exact_status(kd, d.p, nullptr);
+    if (st != AMK_OK) return st;
+    AMK_HIP(hipDeviceSynchronize());
+    AMK_HIP(hipMemcpy(h_status, d.p, sizeof(int) * kd->n_scenes, hipMemcpyDeviceToHost));
+    return AMK_OK;
+}
 
 int amk_kd_set_tie_order(amk_kd *kd, int mode) {
     if (!kd) return AMK_ERR_INVALID_ARG;

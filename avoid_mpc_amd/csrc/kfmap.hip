@@ -22,6 +22,7 @@
 #include "kd_grid.h"
 #include "mpc_handle.h"
 
+#include <cstdio>
 #include <vector>
 
 namespace amk {
@@ -65,7 +66,8 @@ __global__ __launch_bounds__(256) void kf_init_kernel(int S, int P, int *__restr
 __global__ __launch_bounds__(256) void kf_alloc_kernel(int S, int P, int first, int n, const int *__restrict__ counts,
                                                        const double *__restrict__ Twc_in, int *__restrict__ cur_slot,
                                                        const int *__restrict__ kf_n, const int *__restrict__ kf_slots,
-                                                       int *__restrict__ need, double *__restrict__ Twc, int *__restrict__ out_scene) {
+                                                       int *__restrict__ need, double *__restrict__ Twc, int *__restrict__ out_scene,
+                                                       int *__restrict__ fmap) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int s = first + i;
@@ -87,6 +89,8 @@ __global__ __launch_bounds__(256) void kf_alloc_kernel(int S, int P, int first, 
     }
     cur_slot[s] = slot;           // (slot < P: the deque holds at most P - 1 slots)
     out_scene[i] = slot * S + s;
+    fmap[s] = slot * S + s;       // SetCurPtCloud -> UpdateQueryVector (:53-58): the query vector's first frame is the new one at once
+                                  // (the keyframe rows do not change here: the deque is the worker's, amk_kfmap_update)
     need[s] = 1;                  // mbNeedProcessPtCloud = true (:51)
     for (int e = 0; e < 16; ++e) Twc[(size_t)s * 16 + e] = Twc_in[(size_t)i * 16 + e];   // mCurFrame.Twc = mat4Twb * mParamTbc (:50)
 }
@@ -183,6 +187,26 @@ __global__ __launch_bounds__(256) void kf_insert_kernel(int S, int P, int F, con
 
 extern "C" {
 
+// Device bytes the map's pools will hold once the first sweep has run (the formula of the header): per pool scene the bucket
+// records (16 B per point of capacity), the tile directories, and for the obstacle pool the index-ordered planes (12 B) and the
+// sweep's outlier flags (1 B); per SCENE (sweep row) the hashed grid of the current frame (16 B per point + bucket starts).
+int amk_kfmap_pool_bytes(int n_scenes, int max_points, int max_edge_points, int max_frame_count, long long *bytes_out) {
+    if (!bytes_out || n_scenes <= 0 || max_points <= 0 || max_edge_points <= 0 || max_frame_count < 1) return AMK_ERR_INVALID_ARG;
+    const long long P = max_frame_count + 2, S = n_scenes, F = max_frame_count + 1;
+    auto cap = [](int mp) { return (long long)amk::round_up(mp, 256) + 1024; };
+    auto index_bytes = [&](int mp) {   // amk_kd_create
+        return 16 * cap(mp) + 4ll * amk::grid_tiles(mp) * (amk::kGridMaxCells + 2) + 8 * amk::kGridParamDoubles + 24 + 8;
+    };
+    long long b = P * S * (index_bytes(max_points) + index_bytes(max_edge_points));
+    b += P * S * (12 + 1) * cap(max_points);                                      // x / y / z planes + flags (kd_sweep_mapped)
+    int nb = 1024;
+    while (nb < 16384 && nb < 2 * max_points) nb *= 2;
+    b += S * (16 * cap(max_points) + 4ll * (nb + 1));                             // the sweep's grid of the current frame
+    b += S * (4 * (8 + P + F) + 8 * 16);                                          // the deques, lists and Twc
+    *bytes_out = b;
+    return AMK_OK;
+}
+
 int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const amk_kfmap_params *prm, amk_kfmap **out) {
     if (!out || !prm || n_scenes <= 0 || max_points <= 0 || max_edge_points <= 0 || prm->keyframe_th_count < 1 ||
         !(prm->keyframe_th_dist >= 0.0))
@@ -190,6 +214,18 @@ int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const am
     *out = nullptr;
     if (prm->max_frame_count < 1 || prm->max_frame_count + 1 > AMK_MAX_MAP_FRAMES) return AMK_ERR_UNSUPPORTED;
     if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
+    {   // the pools are allocated eagerly at full capacity: say what they need before the allocator fails half-way with a bare
+        // out-of-memory (max_frame_count = 100 with 512 scenes x 50 k points is ~ 80 GB per map)
+        long long need = 0;
+        size_t free_b = 0, total_b = 0;
+        if (amk_kfmap_pool_bytes(n_scenes, max_points, max_edge_points, prm->max_frame_count, &need) == AMK_OK &&
+            hipMemGetInfo(&free_b, &total_b) == hipSuccess && (unsigned long long)need > (unsigned long long)free_b) {
+            fprintf(stderr, "amk_kfmap_create: the pools of %d scenes x (max_frame_count %d + 2) slots x (%d + %d) points need %.2f GiB, "
+                            "%.2f GiB are free on the device (amk_kfmap_pool_bytes)\n", n_scenes, prm->max_frame_count, max_points,
+                    max_edge_points, need / 1073741824.0, free_b / 1073741824.0);
+            return AMK_ERR_UNSUPPORTED;
+        }
+    }
     amk_kfmap *m = new amk_kfmap();
     m->S = n_scenes; m->P = prm->max_frame_count + 2; m->F = prm->max_frame_count + 1;
     m->prm = *prm;
@@ -262,7 +298,7 @@ int amk_kfmap_add_vertex(amk_kfmap *m, int first_scene, int n_scenes, const floa
         return AMK_ERR_INVALID_ARG;
     hipStream_t stream = (hipStream_t)stream_;
     hipLaunchKernelGGL(kf_alloc_kernel, dim3((n_scenes + 255) / 256), dim3(256), 0, stream, m->S, m->P, first_scene, n_scenes, d_counts,
-                       d_Twc, m->cur_slot.p, m->kf_n.p, m->kf_slots.p, m->need.p, m->Twc.p, m->out_scene.p + first_scene);
+                       d_Twc, m->cur_slot.p, m->kf_n.p, m->kf_slots.p, m->need.p, m->Twc.p, m->out_scene.p + first_scene, m->fmap.p);
     AMK_HIP(hipGetLastError());
     return amk::kd_build_mapped(m->obs, m->edge, n_scenes, d_xyz, d_counts, d_edge_xyz, d_edge_counts, point_stride,
                                 m->out_scene.p + first_scene, stream);

@@ -545,7 +545,16 @@ int amk_pipeline_submit(amk_pipeline *p, const amk_pipeline_frame *f, int *ticke
     const int si = p->next, ns = (int)p->slots.size();
     auto &s = p->slots[si];
     if (f->n_keyframes < 0 || f->n_keyframes > AMK_MAX_FRAMES - 1) return AMK_ERR_INVALID_ARG;
-    if (s.map && (f->n_keyframes > 0 || (!f->d_depth && !f->d_Twc_cur))) return AMK_ERR_INVALID_ARG;   // the slot's own map: no caller keyframes; cloud frames bring mCurFrame.Twc
+    // the slot's own map: no caller keyframes; cloud frames bring mCurFrame.Twc AND the camera model -- the reference always runs
+    // PtIsInFrame (FrameKDMap.cpp:339-345); without a camera every reference point would count as inside the current frame and
+    // the keyframes would never be merged
+    if (s.map && (f->n_keyframes > 0 || (!f->d_depth && (!f->d_Twc_cur || !f->camera)))) return AMK_ERR_INVALID_ARG;
+    if (s.map && !s.open.empty()) {   // the map step takes ONE camera model per launch (position 0's): a gang must agree on it
+        const amk_pipeline::Staged &o = s.open[0];
+        if ((o.depth != nullptr) != (f->d_depth != nullptr)) return AMK_ERR_INVALID_ARG;
+        if (f->d_depth && (o.depth_rows != f->depth_rows || o.depth_cols != f->depth_cols)) return AMK_ERR_INVALID_ARG;
+        if (!f->d_depth && std::memcmp(&o.camera, f->camera, sizeof(amk_frame_camera)) != 0) return AMK_ERR_INVALID_ARG;
+    }
     if (f->n_keyframes > 0) {
         if (p->gang != 1) return AMK_ERR_UNSUPPORTED;   // keyframe handles hold n_scenes scenes, a gang's handles gang x n_scenes
         if (!f->kf_obstacle || !f->kf_edge) return AMK_ERR_INVALID_ARG;

@@ -45,6 +45,13 @@ class KdBatch:
         """capi.AMK_TIES_LOWEST_INDEX (default) or capi.AMK_TIES_NANOFLANN; takes effect at the next build."""
         capi.check(self.lib.amk_kd_set_tie_order(self.h, int(mode)), "amk_kd_set_tie_order")
 
+    def exact_status(self, stream=None):
+        """amk_kd_exact_status: int32 device tensor [S] -- -1 mode off / 0 the reference-shaped tree answers / 1 its build gave up /
+        2 deeper than the traversal stack (1, 2: the bucketed index answers)."""
+        st = torch.empty(self.S, dtype=torch.int32, device="cuda")
+        capi.check(self.lib.amk_kd_exact_status(self.h, capi.dptr(st), capi.stream_ptr(stream)), "amk_kd_exact_status")
+        return st
+
     def build(self, xyz, counts=None, stream=None):
         """InitializeNew: xyz float32 device tensor [S, max_points, 3|4]; counts int32 [S] or None."""
         assert xyz.dtype == torch.float32 and xyz.dim() == 3 and xyz.shape[0] == self.S

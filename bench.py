@@ -22,7 +22,9 @@ Besides the contract's fields the JSON line carries
   parity      |u - u*|_inf and (J - J*)/J* of the GPU solve on the committed fixtures of the three BASELINE sizes
               (tests/golden/mpc_parity_golden.npz: converged optima, SURVEY.md section 8(d) gate) and the check of one
               in-flight slot's controls / flags of the timed workload against the CPU oracle (same scenes);
-  roofline    dominant kernel (mpc_solve_kernel): not an HBM-bound kernel -- see roofline_solve_issue and DESIGN.md;
+  roofline    SURVEY 8(d)'s ruler: frac = frac_hbm_8d = steps/s x algorithmic bytes per scene-step / 8 TB/s (the whole step), and beside
+              it frac_valu_issue + dominant_kernel: what the dominant kernel (mpc_solve_kernel, a serial interior-point solve per
+              wavefront, not HBM-bound) fills of the chip's VALU issue slots; roofline_hbm = that kernel's own bytes / launch duration;
   roofline_kd_build   the HBM-bound kernel of the step.
 """
 import argparse
@@ -835,7 +837,11 @@ def main():
         issue = prof.get("issue")
         valu_per_solve = issue["valu_instructions_per_wave_solve"] if issue else None
         solves_per_s = value * solves
-        valu_frac_timed = (solves_per_s * valu_per_solve * 4 / (N_CU * N_SIMD * CLOCK_GHZ * 1e9)) if valu_per_solve else None
+        # issue cycles one VALU instruction of this kernel holds a SIMD for, MEASURED (SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU of the
+        # committed profile: 4.27, the fp64 share of the mix; a wave64 fp32 instruction would be 4 on paper, an fp64 FMA 4+)
+        valu_cpi = (issue["frac_of_wave_time_issuing_valu"] * issue["wave_cycles_per_wave"] / valu_per_solve) if valu_per_solve else None
+        valu_frac_timed = (solves_per_s * valu_per_solve * valu_cpi / (N_CU * N_SIMD * CLOCK_GHZ * 1e9)) if valu_per_solve else None
+        hbm_8d_gbs = value / max(world, 1) * step_bytes / 1e9      # per GPU: SURVEY 8(d)'s bytes per scene-step x this GPU's steps/s
         hbm = lambda nbytes, us: None if not us else round(nbytes / (us * 1e-6) / 1e9, 2)
         frac = lambda gbs: None if gbs is None else round(gbs / HBM_PEAK_GBS, 6)
         fracm = lambda gbs: None if gbs is None or not hbm_measured else round(gbs / hbm_measured, 6)   # against the measured copy rate
@@ -883,19 +889,34 @@ def main():
                        "rccl": rccl_info if collective else "no process group (single GPU, plain run): RCCL not used",
                        "multi_gpu_measured": "no N > 1 line has been measured by this project (no multi-GPU node was available to it "
                                              "in any round); per-rank files: gpurun_out/bench_ranks/"},
-            "roofline": {"bound": "valu-issue (dependent fp64 / LDS latency at 2 waves per SIMD; neither HBM nor MFMA)",
+            "roofline": {"bound": "hbm",
+                         "what": "SURVEY 8(d)'s ruler for the WHOLE step: algorithmic bytes per scene-step (every input read once, every "
+                                 "output written once) x steps/s of this GPU, against the vendor's HBM peak.  The path is not HBM-bound: its "
+                                 "dominant kernel is a serial interior-point solve per wavefront (frac_valu_issue, dominant_kernel below)",
+                         "alg_bytes_per_scene_step": step_bytes,
+                         "achieved": round(hbm_8d_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(hbm_8d_gbs / HBM_PEAK_GBS, 5), "frac_hbm_8d": round(hbm_8d_gbs / HBM_PEAK_GBS, 5),
+                         "frac_of_measured_copy": fracm(hbm_8d_gbs),
+                         "frac_valu_issue": None if valu_frac_timed is None else round(valu_frac_timed, 4),
+                         "valu_issue_cycles_per_instruction_measured": None if valu_cpi is None else round(valu_cpi, 3),
                          "kernel": f"mpc_solve_kernel<{N}>",
-                         "achieved": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),
-                         "peak": round(N_CU * N_SIMD * CLOCK_GHZ, 1), "unit": "G VALU issue cycles/s (1024 SIMDs x 2.4 GHz)",
-                         "frac": None if valu_frac_timed is None else round(valu_frac_timed, 4),
-                         "frac_at_saturation_solves_only": issue.get("valu_issue_util_at_saturation") if issue else None,
-                         "lds_array_frac_at_saturation": issue.get("lds_array_util_at_saturation (conflict level of the lone wave)") if issue else None,
-                         "valu_instructions_per_wave_solve": valu_per_solve, "solves_per_s_timed_region": round(solves_per_s, 1),
-                         "traffic": traffic, "hbm": roof_solve_hbm,
-                         "note": "frac = (solves/s of the timed region) x (VALU instructions per wave-solve, SQ_INSTS_VALU of the "
-                                 "committed profile) x 4 issue cycles / (1024 SIMDs x 2.4 GHz): the share of the chip's VALU issue "
-                                 "slots the dominant kernel fills while the builds and searches of the other steps share the CUs; "
-                                 "frac_at_saturation_solves_only is the same quantity with nothing but solves resident "
+                         "traffic": traffic,
+                         "dominant_kernel": {
+                             "kernel": f"mpc_solve_kernel<{N}>", "bound": "valu-issue / dependent fp64 + LDS latency at 2 waves per SIMD (neither HBM nor MFMA)",
+                             "hbm_alg_bytes_per_launch": alg_launch, "avg_launch_us": solve_us,
+                             "hbm_achieved_gbs": hbm(alg_launch, solve_us), "hbm_frac": frac(hbm(alg_launch, solve_us)),
+                             "hbm_traffic_per_launch": traffic,
+                             "valu_issue_achieved_gcycles_per_s": None if valu_frac_timed is None else round(valu_frac_timed * N_CU * N_SIMD * CLOCK_GHZ, 1),
+                             "valu_issue_peak_gcycles_per_s": round(N_CU * N_SIMD * CLOCK_GHZ, 1),
+                             "frac_valu_issue": None if valu_frac_timed is None else round(valu_frac_timed, 4),
+                             "frac_valu_issue_at_saturation_solves_only": issue.get("valu_issue_util_at_saturation") if issue else None,
+                             "lds_array_frac_at_saturation": issue.get("lds_array_util_at_saturation (conflict level of the lone wave)") if issue else None,
+                             "valu_instructions_per_wave_solve": valu_per_solve, "solves_per_s_timed_region": round(solves_per_s, 1)},
+                         "note": "frac = frac_hbm_8d = steps/s x alg_bytes_per_scene_step / 8 TB/s.  frac_valu_issue = (solves/s of the timed "
+                                 "region) x (VALU instructions per wave-solve, SQ_INSTS_VALU of the committed profile) x (measured issue cycles "
+                                 "per VALU instruction, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) / (1024 SIMDs x 2.4 GHz): the share of the chip's "
+                                 "VALU issue slots the dominant kernel fills while the builds and searches of the other steps share the CUs; "
+                                 "frac_valu_issue_at_saturation_solves_only is the same quantity with nothing but solves resident "
                                  "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (230 VGPRs and 17.8 KB of LDS "
                                  "per scene) cannot cover ~32-cycle dependent fp64 issue and LDS round trips "
                                  f"(profiles/{PROFILE_TAG}_pmc_solve_issue.md, DESIGN.md section 5)"},

@@ -109,6 +109,21 @@ int amk_kd_tie_flags(amk_kd *kd, const double *d_queries, int query_stride, int 
 #define AMK_TIES_LOWEST_INDEX 0
 #define AMK_TIES_NANOFLANN 1
 int amk_kd_set_tie_order(amk_kd *kd, int mode);
+/* Whether AMK_TIES_NANOFLANN holds for a scene: d_status[s] (device, [n_scenes], stream-ordered after the build it describes)
+ *   AMK_EXACT_OFF      (-1) the mode is off, or no build has run since it was switched on: the bucketed index answers (by design)
+ *   AMK_EXACT_IN_USE   ( 0) the reference-shaped tree answers every search of the scene: nanoflann's index lists, ties included
+ *   AMK_EXACT_GAVE_UP  ( 1) the build gave the tree up (node capacity cap / 2 + 64, its ring of open nodes, or its watchdog):
+ *                           the bucketed index answers -- same distances, equal distances in cloud-index order
+ *   AMK_EXACT_TOO_DEEP ( 2) the tree exists but is deeper than the traversal stack (48 levels): queries that would descend past
+ *                           it are answered by the bucketed index, the others by the tree
+ * A caller that NEEDS the reference's index lists checks this after the build; 1 and 2 are pathological data (never seen on
+ * depth-derived or synthetic clouds; tests force them with a shrunken ring and a geometric point sequence).              */
+#define AMK_EXACT_OFF (-1)
+#define AMK_EXACT_IN_USE 0
+#define AMK_EXACT_GAVE_UP 1
+#define AMK_EXACT_TOO_DEEP 2
+int amk_kd_exact_status(amk_kd *kd, int *d_status, void *stream);
+int amk_kd_exact_status_host(amk_kd *kd, int *h_status);   /* the same into host memory; synchronises the device */
 
 /* Keyframe sweep of FrameKDMap::KeyframeThreadWorker (AM/src/FrameKDMap.cpp:462-485), for every scene:
  * for each point of `keyframe` the nearest-neighbour distance in `current` (SearchForNearest(pt, 1));
@@ -381,8 +396,11 @@ typedef struct amk_pipeline_config {
                             /* mVecQueryVector = [current, keyframes ...] (the reference's default regime: FrameKDMap.cpp:29-32, */
                             /* 64-74).  The scene at position g of slot s must be the same robot every period (as in TASK mode).*/
                             /* PtIsInFrame: for depth frames the camera is amk_pipeline_config.depth's, down-scaled (:21-24,     */
-                            /* 106-107); for cloud frames amk_pipeline_frame.camera + d_Twc_cur (required then: mCurFrame.Twc    */
-                            /* also feeds DroneBehindPts).  keyframes.Tbc is ignored: depth.Tbc is used.  0: single-frame map.   */
+                            /* 106-107); for cloud frames amk_pipeline_frame.camera + d_Twc_cur (BOTH required then, else         */
+                            /* AMK_ERR_INVALID_ARG: mCurFrame.Twc also feeds DroneBehindPts, and without a camera no keyframe    */
+                            /* would ever be merged).  The frames of one gang must agree on depth-vs-cloud, the depth image      */
+                            /* size and the camera (AMK_ERR_INVALID_ARG): the map step takes one camera model per launch.        */
+                            /* keyframes.Tbc is ignored: depth.Tbc is used.  0: single-frame map.                                */
                             /* A TASK frame that brings d_ref_path_init (a robot that starts over) also resets its scenes' map.   */
 } amk_pipeline_config;
 typedef struct amk_pipeline_frame {
@@ -482,6 +500,17 @@ int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x
  * two pool indices, its current frame is built into a slot no keyframe holds, the deque is a list of slot numbers.
  * amk_pipeline runs the three calls inside a TASK-mode slot when amk_pipeline_config.keyframes.max_frame_count > 0
  * (any gang).  Twb = Twc * Tbc^-1 of DroneBehindPts uses the rigid inverse of Tbc.                                          */
+/* Memory.  The pools are allocated at creation, at full capacity: with cap(p) = round_up(p, 256) + 1024 points per pool scene
+ *   bytes ~ (max_frame_count + 2) x n_scenes x [ 16 cap(max_points) + 16 cap(max_edge_points) + 13 cap(max_points) + directories ]
+ *           + n_scenes x 16 cap(max_points)                                                         (amk_kfmap_pool_bytes)
+ * i.e. ~ 45 B per obstacle point per slot: the reference's max_frame_count = 100 at its own 3072-point frames is 15 MB per robot,
+ * at 50 k-point frames 240 MB per robot.  A flight holds ~ 6 frames; slots a scene never uses are still reserved.
+ * amk_kfmap_create compares the figure with the device's free memory first and returns AMK_ERR_UNSUPPORTED (message with both
+ * numbers on stderr) instead of failing half-way through the allocations with AMK_ERR_HIP.
+ * Call order.  add_vertex -> update -> step per control period is what amk_pipeline issues.  add_vertex alone already points the
+ * query vector's first frame at the new trees (SetCurPtCloud -> UpdateQueryVector, FrameKDMap.cpp:53-58); the keyframe rows of the
+ * query vector are the worker's (update).                                                                                    */
+int amk_kfmap_pool_bytes(int n_scenes, int max_points, int max_edge_points, int max_frame_count, long long *bytes_out);
 int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const amk_kfmap_params *prm, amk_kfmap **out);
 int amk_kfmap_destroy(amk_kfmap *map);
 /* scenes [first_scene, first_scene + n_scenes) start over: no current frame, no keyframe, Twc = identity (stream-ordered) */

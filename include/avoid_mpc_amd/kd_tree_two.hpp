@@ -65,6 +65,15 @@ public:
         if (kd_) amk_throw(amk_kd_set_tie_order(kd_, tie_order_), "amk_kd_set_tie_order");
     }
 
+    // Not in the reference: whether SetNanoflannTieOrder(true) holds for the cloud the tree currently indexes --
+    // AMK_EXACT_IN_USE (0): searches follow nanoflann's own tree; AMK_EXACT_GAVE_UP (1) / AMK_EXACT_TOO_DEEP (2): pathological
+    // data, the bucketed index answers (same distances, equal distances in index order); AMK_EXACT_OFF (-1): mode off / no build
+    int NanoflannTieOrderStatus() const {
+        int st = AMK_EXACT_OFF;
+        if (kd_) amk_throw(amk_kd_exact_status_host(kd_, &st), "amk_kd_exact_status_host");
+        return st;
+    }
+
     template <class CloudPtr>
     void Initialize(CloudPtr const &xyz_cloud_new, bool clear) {  // kd_tree_two.h:88-106
         if (clear) cloud.pts.clear();

@@ -486,6 +486,8 @@ def test_exact_build_gives_up_cleanly_when_the_ring_of_open_nodes_is_full(torch_
             kd.build(torch.from_numpy(cl).cuda())
             nn = np.zeros(len(cl), np.int32)
             assert lib.amk__kd_exact_nodes(kd.h, nn.ctypes.data_as(C.c_void_p)) == 0     # synchronises: the build ended
+            status = kd.exact_status().cpu().numpy()                                      # the public account of the same fact
+            assert np.array_equal(status, np.where(nn < 0, capi.AMK_EXACT_GAVE_UP, capi.AMK_EXACT_IN_USE)), (cap, nn, status)
             r = kd.search(torch.from_numpy(np.stack([qs] * len(cl))).cuda(), 8)
             torch.cuda.synchronize()
             idx, d2 = r["indices"].cpu().numpy(), r["sqdist"].cpu().numpy()
@@ -503,3 +505,34 @@ def test_exact_build_gives_up_cleanly_when_the_ring_of_open_nodes_is_full(torch_
     finally:
         lib.amk__exact_set_queue_cap(0)
     assert gave_up > 0, "a 2-entry ring must overflow on 50 k points: the give-up path was not exercised"
+
+
+def test_exact_status_tells_when_the_reference_tie_order_does_not_hold(torch_cuda, oracle):
+    """amk_kd_exact_status: AMK_TIES_NANOFLANN used to degrade silently.  Off / before a build: -1; an ordinary
+    cloud: 0; a geometric point sequence (x_i = 2^-i: planeSplit's mid-range cut peels one point per level, the tree is ~n levels
+    deep, beyond the 48-frame traversal stack): 2, and every answer still carries the right distances (bucketed fallback)."""
+    torch = torch_cuda
+    from avoid_mpc_amd import capi
+    from avoid_mpc_amd.host import KdBatch
+    n = 120
+    geo = np.zeros((n, 3), np.float32); geo[:, 0] = 2.0 ** -np.arange(n, dtype=np.float64)
+    ordinary = synth.make_cloud(n, 5)[0]
+    cl = np.stack([geo, ordinary])
+    kd = KdBatch(2, n)
+    assert (kd.exact_status().cpu().numpy() == capi.AMK_EXACT_OFF).all()
+    kd.set_tie_order(capi.AMK_TIES_NANOFLANN)
+    assert (kd.exact_status().cpu().numpy() == capi.AMK_EXACT_OFF).all()          # no build since the switch: the bucketed index answers
+    kd.build(torch.from_numpy(cl).cuda())
+    st = kd.exact_status().cpu().numpy()
+    assert st.tolist() == [capi.AMK_EXACT_TOO_DEEP, capi.AMK_EXACT_IN_USE], st
+    qs = np.array([[0.0, 0.0, 0.0], [1e-30, 0.0, 0.0], [0.3, 0.1, 0.0], [2.0, 0.0, 0.0]])
+    r = kd.search(torch.from_numpy(np.stack([qs, qs])).cuda(), 5)
+    torch.cuda.synchronize()
+    for s in range(2):
+        t = _oracle.kd_oracle(cl[s])
+        for i, q in enumerate(qs):
+            ia, da = t.bruteforce(q, 5)
+            assert np.array_equal(r["sqdist"][s, i].cpu().numpy().view(np.int64), da.view(np.int64)), (s, i)
+    h = np.zeros(2, np.int32)
+    assert capi.load().amk_kd_exact_status_host(kd.h, h.ctypes.data) == 0 and h.tolist() == st.tolist()
+    kd.close()
