@@ -946,8 +946,10 @@ def main():
             "hbm_peak_vendor_gbs": HBM_PEAK_GBS,
             "hbm_peak_measured_gbs": None if not hbm_measured else round(hbm_measured, 1),
             "hbm_peak_measured_how": "float4 device copy of 1 GiB (amk__hbm_copy_probe, csrc/probe.hip): bytes read + bytes written "
-                                     "over the copy's duration, best of 18 launch shapes (2 / 4 / 8 loads in flight per thread, plain / "
-                                     "non-temporal, 8 / 16 / 32 blocks per CU), 10 repetitions each, HIP events; every HBM fraction of "
+                                     "over the copy's duration, best of 20 launch shapes -- 18 persistent ones (2 / 4 / 8 loads in flight per "
+                                     "thread, plain / non-temporal, 8 / 16 / 32 blocks per CU) and one 16-byte element per thread on a grid as large "
+                                     "as the data, plain / non-temporal stores (the shape that reaches the guide's 6.29 TB/s: "
+                                     f"profiles/r06_hbm_probe_shapes.txt) -- 10 repetitions each, HIP events; every HBM fraction of "
                                      "this line is given against the vendor peak (frac) and against this figure (frac_of_measured_copy)",
             "kernels_single_stream": lone,
             "parity": parity,

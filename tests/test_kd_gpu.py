@@ -509,30 +509,39 @@ def test_exact_build_gives_up_cleanly_when_the_ring_of_open_nodes_is_full(torch_
 
 def test_exact_status_tells_when_the_reference_tie_order_does_not_hold(torch_cuda, oracle):
     """amk_kd_exact_status: AMK_TIES_NANOFLANN used to degrade silently.  Off / before a build: -1; an ordinary
-    cloud: 0; a geometric point sequence (x_i = 2^-i: planeSplit's mid-range cut peels one point per level, the tree is ~n levels
-    deep, beyond the 48-frame traversal stack): 2, and every answer still carries the right distances (bucketed fallback)."""
+    cloud: 0; a geometric point sequence in front of a tight cluster (x_i = 2^-i, i < 100, then 1000 points within 2^-110 of the
+    origin: planeSplit's mid-range cut peels a point or two per level while the cluster stays one big node, so the tree is > 48
+    levels deep above an ordinary subtree): 2; a bare geometric sequence (the deep part lies inside one of the build's subtree
+    windows, whose own stack it exceeds): 1.  In every case the answers carry the right distances (bucketed fallback)."""
     torch = torch_cuda
     from avoid_mpc_amd import capi
     from avoid_mpc_amd.host import KdBatch
-    n = 120
-    geo = np.zeros((n, 3), np.float32); geo[:, 0] = 2.0 ** -np.arange(n, dtype=np.float64)
+    n = 1100
+    rng = np.random.default_rng(3)
+    deep = np.zeros((n, 3), np.float32)
+    deep[:100, 0] = 2.0 ** -np.arange(100, dtype=np.float64)
+    deep[100:] = (rng.uniform(0.0, 1.0, (n - 100, 3)) * 2.0 ** -110).astype(np.float32)
     ordinary = synth.make_cloud(n, 5)[0]
-    cl = np.stack([geo, ordinary])
-    kd = KdBatch(2, n)
+    geo = np.full((n, 3), np.nan, np.float32); geo[:120] = 0.0; geo[:120, 0] = 2.0 ** -np.arange(120, dtype=np.float64)   # 120 points, NaN-x padding
+    cl = np.stack([deep, ordinary, geo])
+    kd = KdBatch(3, n)
     assert (kd.exact_status().cpu().numpy() == capi.AMK_EXACT_OFF).all()
     kd.set_tie_order(capi.AMK_TIES_NANOFLANN)
     assert (kd.exact_status().cpu().numpy() == capi.AMK_EXACT_OFF).all()          # no build since the switch: the bucketed index answers
     kd.build(torch.from_numpy(cl).cuda())
     st = kd.exact_status().cpu().numpy()
-    assert st.tolist() == [capi.AMK_EXACT_TOO_DEEP, capi.AMK_EXACT_IN_USE], st
+    print("exact status of (deep top, ordinary, bare geometric):", st.tolist())
+    assert st[1] == capi.AMK_EXACT_IN_USE and st[0] in (capi.AMK_EXACT_TOO_DEEP, capi.AMK_EXACT_GAVE_UP) and st[2] in (capi.AMK_EXACT_TOO_DEEP, capi.AMK_EXACT_GAVE_UP), st
+    assert capi.AMK_EXACT_TOO_DEEP in st.tolist(), st                              # the depth account is exercised, not only the give-up flag
     qs = np.array([[0.0, 0.0, 0.0], [1e-30, 0.0, 0.0], [0.3, 0.1, 0.0], [2.0, 0.0, 0.0]])
-    r = kd.search(torch.from_numpy(np.stack([qs, qs])).cuda(), 5)
+    r = kd.search(torch.from_numpy(np.stack([qs] * 3)).cuda(), 5)
     torch.cuda.synchronize()
-    for s in range(2):
-        t = _oracle.kd_oracle(cl[s])
+    for s_ in range(3):
+        c = cl[s_][~np.isnan(cl[s_][:, 0])]
+        t = _oracle.kd_oracle(c)
         for i, q in enumerate(qs):
             ia, da = t.bruteforce(q, 5)
-            assert np.array_equal(r["sqdist"][s, i].cpu().numpy().view(np.int64), da.view(np.int64)), (s, i)
-    h = np.zeros(2, np.int32)
+            assert np.array_equal(r["sqdist"][s_, i].cpu().numpy().view(np.int64), da.view(np.int64)), (s_, i)
+    h = np.zeros(3, np.int32)
     assert capi.load().amk_kd_exact_status_host(kd.h, h.ctypes.data) == 0 and h.tolist() == st.tolist()
     kd.close()
