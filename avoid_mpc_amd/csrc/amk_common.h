@@ -114,9 +114,13 @@ struct amk_kd {
     amk::DevBuf<int> sweep_cnt;       // [S][2]   {outliers, rebuilt}
     // the keyframe map's pool only (kd_sweep_mapped): the sweep's target, per sweep ROW -- the current frame's points once more, sorted
     // into a fine hashed grid (cells of 2.5 th), rebuilt before every sweep
-    amk::DevBuf<float4> sw_gpt;       // [rows][cap]               records, bucket by bucket
-    amk::DevBuf<int> sw_cs;           // [rows][buckets + 1] bucket starts; the last entry = points with finite coordinates
-    int sw_rows = 0;
+    // Two generations (this sweep's and the one before: a row's newest keyframe is usually the frame it swept against last period,
+    // and its points are then taken in that grid's order -- the lanes of a wavefront ask for the same few buckets)
+    amk::DevBuf<float4> sw_gpt;       // [2][rows][cap]         records, bucket by bucket
+    amk::DevBuf<int> sw_cs;           // [2][rows][buckets + 1] bucket starts; the last entry = points with finite coordinates
+    amk::DevBuf<int> sw_src;          // [2 + 1][rows]          pool scene the row's grid was built from, -1: none (row 2: always -1)
+    int sw_rows = 0, sw_flip = 0;
+    double sw_inv_h = 0.0;            // the lattice of the grids held (1 / cell edge)
     // staging for the *_host conveniences: a private stream and one pinned host block, so that a single-query
     // SearchForNearest costs one small H2D copy, one launch, one D2H copy and a wait on THIS stream only (a device-wide
     // synchronisation would stall every other stream of the process: a ROS node calls this ~100 times per control period)

@@ -488,6 +488,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
 // tools/experiments/patches/r05_sweep_persistent_lanes.patch, profiles/r05_sweep_target.txt.)
 static int g_sweep_target = [] { const char *e = getenv("AMK_SWEEP_TARGET"); return e ? atoi(e) : 1; }();   // 1: the pool sweeps against a fine hashed grid of the current frame (below); 0: against the frame's own index (A/B, tests)
 extern "C" void amk__sweep_set_target(int v) { g_sweep_target = v; }
+static int g_sweep_order = [] { const char *e = getenv("AMK_SWEEP_ORDER"); return e ? atoi(e) : 1; }();   // 1: keyframe points in the order of last sweep's grid where it is theirs; 0: always in record order (A/B)
 
 // one block per scene: count the outliers; with >= th_count of them compact the keyframe's planes in place
 // (order preserved: the write cursor never passes the read cursor) and refresh size / bbox / max|coordinate|
@@ -656,14 +657,29 @@ __global__ __launch_bounds__(amk::kGridBuildThreads) void kd_grid_build_list_ker
 constexpr int kSweepBuckets = 16384;   // at most: 64 KB of LDS histogram per build block; a pool of small frames takes fewer (sweep_buckets)
 constexpr int kSweepBuildThreads = 1024;
 
-__device__ __forceinline__ long long sweep_cell(double p, double inv_h) {
-    double c = floor(p * inv_h);
-    c = c < -1e15 ? -1e15 : (c > 1e15 ? 1e15 : c);   // monotone, and a long long for every float
-    return (long long)c;
+// Cell of a coordinate: 32-bit, from fp32 arithmetic -- mul, floor, clamp, convert (the fp64 / 64-bit version of round 5 cost ~12 VALU
+// instructions per coordinate and ~40 per hash, in kernels that are bound by their VALU instructions).  What the sweep needs of it is
+// MONOTONICITY, which every step keeps (round-to-nearest, floor, clamp): a point p with q - rr <= p <= q + rr then has
+// cell(q - rr) <= cell(p) <= cell(q + rr), whatever the rounding did to the cell boundaries.
+__device__ __forceinline__ int sweep_cell(float p, float inv_hf) {
+    return (int)fminf(fmaxf(floorf(p * inv_hf), -5.0e8f), 5.0e8f);
 }
-__device__ __forceinline__ int sweep_bucket(long long ix, long long iy, long long iz, int nb) {
-    const unsigned long long h = (unsigned long long)ix * 73856093ull ^ (unsigned long long)iy * 19349663ull ^ (unsigned long long)iz * 83492791ull;
-    return (int)((h ^ (h >> 17)) & (unsigned long long)(nb - 1));
+__device__ __forceinline__ int sweep_cell(double p, float inv_hf) { return sweep_cell((float)p, inv_hf); }
+// Bucket of a cell.  Cells are hashed BLOCK-wise: a block of 4 x 4 x 4 cells (10 th = 1 m at th 0.1) owns 64 CONSECUTIVE buckets, the hash
+// only picks which run of 64 (nb / 64 runs).  Neighbouring cells therefore share a run unless they straddle a block face: queries taken in
+// grid order (kd_sweep_mapped's two generations) find their <= 8 cells' table entries and records near each other (mark kernel 1.56 ->
+// 1.47 ms per 512 x 50 k sweep against the cell-wise hash).  Cells per bucket are what a cell-wise hash gives (cells / nb on average).
+// (A workgroup per run with the run's records staged in LDS was built on top of this and is SLOWER, 1.94 ms: the kernel is bound by its
+// VALU instructions and their divergence, not by its gathers -- tools/experiments/patches/r06_sweep_block_lds.patch, profiles/r06_sweep.txt.)
+constexpr int kSweepBlockCells = 64;   // 4 x 4 x 4
+__device__ __forceinline__ int sweep_block(int ix, int iy, int iz, int nb) {
+    unsigned h = (unsigned)(ix >> 2) * 73856093u ^ (unsigned)(iy >> 2) * 19349663u ^ (unsigned)(iz >> 2) * 83492791u;
+    h ^= h >> 15;
+    return (int)(h & (unsigned)(nb / kSweepBlockCells - 1));
+}
+__device__ __forceinline__ int sweep_local(int ix, int iy, int iz) { return (ix & 3) | ((iy & 3) << 2) | ((iz & 3) << 4); }
+__device__ __forceinline__ int sweep_bucket(int ix, int iy, int iz, int nb) {
+    return sweep_block(ix, iy, iz, nb) * kSweepBlockCells + sweep_local(ix, iy, iz);
 }
 // buckets of a pool's sweep grids: a power of two, about two per point, between 1024 and kSweepBuckets
 static int sweep_buckets(int max_points) {
@@ -674,17 +690,30 @@ static int sweep_buckets(int max_points) {
     return nb;
 }
 
-// one block per sweep row: counting sort of the current frame's points by bucket (LDS histogram, block scan, LDS cursors)
+// one block per sweep row: counting sort of the current frame's points by bucket (LDS histogram, block scan, LDS cursors).  The points are
+// read from the frame's OWN bucketed records (kd_build's output: coarse-cell order, ~1 m cells), not from the index-ordered planes: the 64
+// points of a wave-instruction then lie in one or two blocks of fine cells and their 16-byte records are scattered into a few KB instead of
+// all over the row's 800 KB (round 6: the scatter, not the arithmetic, is what this kernel's time is).
 __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel(
-    const float *__restrict__ X, const float *__restrict__ Y, const float *__restrict__ Z, int cap, const int *__restrict__ sizes,
+    const float4 *__restrict__ GP, int cap, const int *__restrict__ sizes,
     double inv_h, int nb, float4 *__restrict__ recs, int *__restrict__ table, const int *__restrict__ kf_list,
-    const int *__restrict__ cur_list) {
+    const int *__restrict__ cur_list, int *__restrict__ src, const int *__restrict__ src_prev, unsigned char *__restrict__ flags) {
     extern __shared__ int hist[];   // [nb] + [kSweepBuildThreads / 64] wave sums
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    if (kf_list[row] < 0) return;   // (block-uniform)
+    const float inv_hf = (float)inv_h;
+    const int kf = kf_list[row];
+    if (kf < 0) {   // (block-uniform) no sweep in this row: whatever grid this generation held for it is not the next sweep's keyframe
+        if (tid == 0) src[row] = -1;
+        return;
+    }
     const int sc = cur_list[row];
+    if (tid == 0) src[row] = sc;
+    // the keyframe is the frame this row swept against last time: the mark kernel takes its points from that grid, which leaves out the
+    // points with a non-finite coordinate -- their flag is 0 (no outlier: within th of nothing, but SearchForNearest gives them no result)
+    if (src_prev[row] == kf)
+        for (int i = tid; i < sizes[kf]; i += kSweepBuildThreads) flags[(size_t)kf * cap + i] = 0;
     const int n = sizes[sc];
-    const float *xs = X + (size_t)sc * cap, *ys = Y + (size_t)sc * cap, *zs = Z + (size_t)sc * cap;
+    const float4 *in = GP + (size_t)sc * cap;   // the frame's own records: coarse-cell order (see above)
     int *wsum = hist + nb;
     int *tab = table + (size_t)row * (nb + 1);
     float4 *out = recs + (size_t)row * cap;
@@ -693,15 +722,16 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
     constexpr int U = 4;   // points per thread and trip: their loads fly together (a block's passes are two chains of dependent trips)
     for (int i0 = tid; i0 < n; i0 += U * kSweepBuildThreads) {
         float x[U], y[U], z[U];
+        int id[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * kSweepBuildThreads, n - 1);
-            x[u] = xs[i]; y[u] = ys[i]; z[u] = zs[i];
+            const float4 r = in[min(i0 + u * kSweepBuildThreads, n - 1)];
+            x[u] = r.x; y[u] = r.y; z[u] = r.z; id[u] = __float_as_int(r.w);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
             if (i0 + u * kSweepBuildThreads < n && amk::finite3(x[u], y[u], z[u]))
-                atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_h), sweep_cell(y[u], inv_h), sweep_cell(z[u], inv_h), nb)], 1);
+                atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_hf), sweep_cell(y[u], inv_hf), sweep_cell(z[u], inv_hf), nb)], 1);
     }
     __syncthreads();
     // exclusive scan of the nb counts: nb / kSweepBuildThreads consecutive buckets per thread (nb >= 1024 = the block)
@@ -724,17 +754,22 @@ __global__ __launch_bounds__(kSweepBuildThreads) void kd_sweep_hash_build_kernel
     __syncthreads();
     for (int i0 = tid; i0 < n; i0 += U * kSweepBuildThreads) {
         float x[U], y[U], z[U];
+        int id[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = min(i0 + u * kSweepBuildThreads, n - 1);
-            x[u] = xs[i]; y[u] = ys[i]; z[u] = zs[i];
+            const float4 r = in[min(i0 + u * kSweepBuildThreads, n - 1)];
+            x[u] = r.x; y[u] = r.y; z[u] = r.z; id[u] = __float_as_int(r.w);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int i = i0 + u * kSweepBuildThreads;
             if (i < n && amk::finite3(x[u], y[u], z[u])) {
-                const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_h), sweep_cell(y[u], inv_h), sweep_cell(z[u], inv_h), nb)], 1);
-                out[pos] = make_float4(x[u], y[u], z[u], __int_as_float(i));   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
+                const int pos = atomicAdd(&hist[sweep_bucket(sweep_cell(x[u], inv_hf), sweep_cell(y[u], inv_hf), sweep_cell(z[u], inv_hf), nb)], 1);
+#ifndef AMK_DIAG_NOSTORE   // (diagnostics: without the scatter the kernel takes 169 of its 458 us)
+                out[pos] = make_float4(x[u], y[u], z[u], __int_as_float(id[u]));
+#else
+                if (pos == -12345) out[0] = make_float4(x[u], y[u], z[u], 0.f);
+#endif   // (order inside a bucket: whatever the atomics gave -- the sweep asks "any", not "which")
             }
         }
     }
@@ -769,81 +804,108 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
                                                                  double inv_h, int nb, const float4 *__restrict__ KGP, int kcap,
                                                                  const int *__restrict__ ksizes, double th,
                                                                  unsigned char *__restrict__ flags, const int *__restrict__ kf_list,
-                                                                 const int *__restrict__ cur_list) {
+                                                                 const int *__restrict__ cur_list, const float4 *__restrict__ prev_recs,
+                                                                 const int *__restrict__ prev_table, const int *__restrict__ src_prev) {
     const int row = blockIdx.y;
     const int s = kf_list[row];
     if (s < 0) return;
     const int sc = cur_list[row];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ksizes[s]) return;
-    const float4 rec = KGP[(size_t)s * kcap + i];
+    // the keyframe's points: in the order of the grid it was sorted into when it was the current frame (the sweep before this one, same
+    // row) -- the lanes of a wavefront then ask for the same few buckets and runs -- else in its own records' order
+    const bool ordered = src_prev[row] == s;   // (row-uniform)
+    const bool live = i < (ordered ? prev_table[(size_t)row * (nb + 1) + nb] : ksizes[s]);
+    // Two phases per workgroup.  A: every thread scans its query's OWN cell (half the inliers end there).  B: the queries that are still open
+    // are compacted into LDS and taken by the first threads of the block, one each, for the other <= 7 cells of their cubes.  One query per
+    // thread throughout made nearly every wavefront run at its slowest lane's pace (an outlier scans all 8 cells: a real pair of frames with
+    // 14 % outliers cost 90 % of an all-outlier pair); after the compaction the wavefronts of phase B are full of open queries and the others
+    // have retired.  Same cells, same screen, same exact test: same flags.
+    __shared__ float4 open_q[256];
+    __shared__ int n_open;
+    if (threadIdx.x == 0) n_open = 0;
+    __syncthreads();
     const int *tab = table + (size_t)row * (nb + 1);
     const float4 *pts = trecs + (size_t)row * kcap;
-    unsigned char f = 0;
-    const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
-    // SearchForNearest(pt, 1) yields a result only for a tree of more than one point (kd_tree_two.h:119-124), and an outlier needs a
-    // nearest point at all: a point with finite coordinates
-    if (cur_sizes[sc] > 1 && tab[nb] > 0 && qx == qx && qy == qy && qz == qz) {
-        const double h = 1.0 / inv_h;
-        const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);   // (rounding allowance, as grid_outlier_thread's)
-        const long long lx = sweep_cell(qx - rr, inv_h), hx = sweep_cell(qx + rr, inv_h);
-        const long long ly = sweep_cell(qy - rr, inv_h), hy = sweep_cell(qy + rr, inv_h);
-        const long long lz = sweep_cell(qz - rr, inv_h), hz = sweep_cell(qz + rr, inv_h);
-        if (hx - lx > 1 || hy - ly > 1 || hz - lz > 1) {
-            // coordinates so large that the rounding allowance exceeds a cell: every point of the grid is a candidate (a plain loop --
-            // the walk over the frame's own index, inlined here, cost this kernel 10 registers = one wavefront per SIMD: 1.72 -> 1.83 ms)
-            const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+    const double h = 1.0 / inv_h;
+    const float inv_hf = (float)inv_h;
+    const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
+    const float t2f = (float)(t2 * (1.0 + 1e-5)) * (1.0f + 1e-6f);   // fp32 screen: above it no candidate can pass the exact test
+    const bool usable = cur_sizes[sc] > 1 && tab[nb] > 0;   // SearchForNearest(pt, 1) yields a result only for a tree of more than one point
+                                                            // (kd_tree_two.h:119-124), and an outlier needs a nearest point at all
+    if (live) {
+        const float4 rec = ordered ? prev_recs[(size_t)row * kcap + i] : KGP[(size_t)s * kcap + i];
+        unsigned char f = 0;
+        bool open = false;
+        const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
+        if (usable && qx == qx && qy == qy && qz == qz) {
+            const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);   // (rounding allowance, as grid_outlier_thread's)
+            const int lx = sweep_cell(qx - rr, inv_hf), hx = sweep_cell(qx + rr, inv_hf);
+            const int ly = sweep_cell(qy - rr, inv_hf), hy = sweep_cell(qy + rr, inv_hf);
+            const int lz = sweep_cell(qz - rr, inv_hf), hz = sweep_cell(qz + rr, inv_hf);
             f = 1;
-            for (int j = 0; f && j < tab[nb]; ++j) {
-                const float4 p = pts[j];
-                const double d = amk::sq_dist(qx, qy, qz, p.x, p.y, p.z);
-                if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;
-            }
-        } else {
-            const long long ox = sweep_cell(qx, inv_h), oy = sweep_cell(qy, inv_h), oz = sweep_cell(qz, inv_h);   // own cell: within [l, h]
-            const int nx = (int)(hx - lx) + 1, ny = (int)(hy - ly) + 1, nz = (int)(hz - lz) + 1, nc = nx * ny * nz;
-            const double t2 = th * th, t2lo = t2 * (1.0 - 1e-15), t2hi = t2 * (1.0 + 1e-15);
-            const float t2f = (float)(t2 * (1.0 + 1e-5)) * (1.0f + 1e-6f);   // fp32 screen: above it no candidate can pass the exact test
-            int s0[8], s1[8];
-            f = 1;
-            {   // the query's own cell first, on its own: half the inliers end here and never ask for the other seven buckets
+            if (hx - lx > 1 || hy - ly > 1 || hz - lz > 1) {
+                // coordinates so large that the rounding allowance exceeds a cell: every point of the grid is a candidate (a plain loop)
+                for (int j = 0; f && j < tab[nb]; ++j) {
+                    const float4 p = pts[j];
+                    const double d = amk::sq_dist(qx, qy, qz, p.x, p.y, p.z);
+                    if (d <= t2lo || (d <= t2hi && sqrt(d) <= th)) f = 0;
+                }
+            } else {
+                const int ox = sweep_cell(rec.x, inv_hf), oy = sweep_cell(rec.y, inv_hf), oz = sweep_cell(rec.z, inv_hf);   // own cell: within [l, h]
                 const int b = sweep_bucket(ox, oy, oz, nb);
-                s0[0] = tab[b];
-                s1[0] = tab[b + 1];
-                for (int pos = s0[0]; f && pos < s1[0]; pos += kSweepStepH) {
-                    const int last = s1[0] - 1;
+                const int s0 = tab[b], s1 = tab[b + 1];
+                for (int pos = s0; f && pos < s1; pos += kSweepStepH) {
+                    const int last = s1 - 1;
                     float4 pr[kSweepStepH];
 #pragma unroll
                     for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
                     if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
                 }
-            }
-            if (f) {
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {   // cell k: bit set = the OTHER cell of that axis
-                s0[k] = s1[k] = 0;
-                if (k < nc) {
-                    const int kx = k % nx, ky = (k / nx) % ny, kz = k / (nx * ny);
-                    const long long cx = kx ? lx + hx - ox : ox, cy = ky ? ly + hy - oy : oy, cz = kz ? lz + hz - oz : oz;
-                    const int b = sweep_bucket(cx, cy, cz, nb);
-                    s0[k] = tab[b];
-                    s1[k] = tab[b + 1];
-                }
-            }
-#pragma unroll
-            for (int k = 1; k < 8; ++k) {
-                for (int pos = s0[k]; f && pos < s1[k]; pos += kSweepStepH) {
-                    const int last = s1[k] - 1;
-                    float4 pr[kSweepStepH];
-#pragma unroll
-                    for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
-                    if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
-                }
-            }
+                open = f && (hx != lx || hy != ly || hz != lz);
             }
         }
+        if (open) open_q[atomicAdd(&n_open, 1)] = rec;
+        else flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
     }
-    flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
+    __syncthreads();
+#ifdef AMK_SWEEP_SKIPB
+    if (false) {
+#else
+    if ((int)threadIdx.x < n_open) {
+#endif
+        const float4 rec = open_q[threadIdx.x];
+        const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
+        const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);
+        const int lx = sweep_cell(qx - rr, inv_hf), hx = sweep_cell(qx + rr, inv_hf);
+        const int ly = sweep_cell(qy - rr, inv_hf), hy = sweep_cell(qy + rr, inv_hf);
+        const int lz = sweep_cell(qz - rr, inv_hf), hz = sweep_cell(qz + rr, inv_hf);
+        const int ox = sweep_cell(rec.x, inv_hf), oy = sweep_cell(rec.y, inv_hf), oz = sweep_cell(rec.z, inv_hf);
+        const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1, nc = nx * ny * nz;
+        int s0[8], s1[8];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {   // cell k: bit set = the OTHER cell of that axis; the table entries fetched together
+            s0[k] = s1[k] = 0;
+            if (k < nc) {
+                const int kx = k % nx, ky = (k / nx) % ny, kz = k / (nx * ny);
+                const int cx = kx ? lx + hx - ox : ox, cy = ky ? ly + hy - oy : oy, cz = kz ? lz + hz - oz : oz;
+                const int b = sweep_bucket(cx, cy, cz, nb);
+                s0[k] = tab[b];
+                s1[k] = tab[b + 1];
+            }
+        }
+        unsigned char f = 1;
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            for (int pos = s0[k]; f && pos < s1[k]; pos += kSweepStepH) {
+                const int last = s1[k] - 1;
+                float4 pr[kSweepStepH];
+#pragma unroll
+                for (int e = 0; e < kSweepStepH; ++e) pr[e] = pts[min(pos + e, last)];
+                if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
+            }
+        }
+        flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
+    }
 }
 
 namespace amk {
@@ -892,23 +954,37 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
         const int nb = sweep_buckets(pool->max_points);
         if (pool->sw_rows < n_rows) {
             if (pool->sw_rows > 0) AMK_HIP(hipDeviceSynchronize());   // (growing: earlier sweeps may still read the old arrays)
-            AMK_HIP(pool->sw_gpt.alloc((size_t)n_rows * pool->cap));
-            AMK_HIP(pool->sw_cs.alloc((size_t)n_rows * (nb + 1)));
+            AMK_HIP(pool->sw_gpt.alloc((size_t)2 * n_rows * pool->cap));
+            AMK_HIP(pool->sw_cs.alloc((size_t)2 * n_rows * (nb + 1)));
+            AMK_HIP(pool->sw_src.alloc((size_t)3 * n_rows));   // (a third row of -1s: "no grid", what the A/B switch hands the mark kernel)
+            AMK_HIP(hipMemset(pool->sw_src.p, 0xff, sizeof(int) * 3 * (size_t)n_rows));   // -1: no grid yet
             pool->sw_rows = n_rows;
         }
         // > 64 KB of dynamic LDS needs the attribute; it is per device and the call is cheap, so it is made before every launch
         // (a process-wide flag would leave a second device, or a second thread's first launch, without it)
         AMK_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kd_sweep_hash_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)(sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64))));
+                                    (int)(sizeof(int) * (kSweepBuckets + kSweepBuildThreads / 64)) + 65536));
         static const double factor = [] { const char *e = getenv("AMK_SWEEP_CELL"); const double v = e ? atof(e) : 2.5; return v >= 2.1 ? v : 2.5; }();
         const double cell = fmax(factor * th_dist, 1e-3);   // edge of a cell: the cube [q - th, q + th] touches <= 2 cells per axis
         const double inv_h = 1.0 / cell;
-        hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (nb + kSweepBuildThreads / 64),
-                           stream, pool->x.p, pool->y.p, pool->z.p, pool->cap, pool->size.p, inv_h, nb, pool->sw_gpt.p, pool->sw_cs.p,
-                           d_kf_list, d_cur_list);
+        // generations alternate per call; a call with another row count than the one the arrays were sized for is refused (rows are the
+        // map's scenes)
+        if (n_rows != pool->sw_rows) return AMK_ERR_INVALID_ARG;
+        if (pool->sw_inv_h != inv_h) {   // another lattice than the last call's: the previous generation's grids are not this one's cells
+            if (pool->sw_inv_h != 0.0) AMK_HIP(hipMemsetAsync(pool->sw_src.p, 0xff, sizeof(int) * 2 * (size_t)n_rows, stream));
+            pool->sw_inv_h = inv_h;
+        }
+        const int g = pool->sw_flip ^= 1;
+        float4 *recs_g = pool->sw_gpt.p + (size_t)g * n_rows * pool->cap, *recs_p = pool->sw_gpt.p + (size_t)(g ^ 1) * n_rows * pool->cap;
+        int *tab_g = pool->sw_cs.p + (size_t)g * n_rows * (nb + 1), *tab_p = pool->sw_cs.p + (size_t)(g ^ 1) * n_rows * (nb + 1);
+        int *src_g = pool->sw_src.p + (size_t)g * n_rows, *src_p = pool->sw_src.p + (size_t)(g ^ 1) * n_rows;
+        static const int extra_lds = [] { const char *e = getenv("AMK_SWEEP_BUILD_EXTRA_LDS"); return e ? atoi(e) : 0; }();   // (experiments: blocks per CU)
+        hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (nb + kSweepBuildThreads / 64) + extra_lds,
+                           stream, pool->gpt.p, pool->cap, pool->size.p, inv_h, nb, recs_g, tab_g, d_kf_list, d_cur_list,
+                           src_g, src_p, pool->flags.p);
         hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, pool->size.p,
-                           pool->sw_gpt.p, pool->sw_cs.p, inv_h, nb, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p,
-                           d_kf_list, d_cur_list);
+                           recs_g, tab_g, inv_h, nb, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list, d_cur_list,
+                           recs_p, tab_p, g_sweep_order ? src_p : pool->sw_src.p + (size_t)2 * n_rows);
     }
     else if (pool->max_points > 0)
         hipLaunchKernelGGL(kd_sweep_mark_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, cur, pool->size.p,
