@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 # amk_common.h KernelClass: what the library's HIP-event timing (amk__timing_*) can bracket
 KCLASS = [None, "step_knn_grid_kernel", "step_scan_kernel (cross-check mode only)", "step_plan_pack_kernel", None,
           "mpc_solve_kernel", "step_begin_kernel", "kd_build_kernel"]
-PROFILE_TAG = "r05"
+PROFILE_TAG = "r06"
 N_CU, N_SIMD, CLOCK_GHZ = 256, 4, 2.4   # MI355X: /opt/skills/guides/MI355X_MICROARCH.md
 
 
