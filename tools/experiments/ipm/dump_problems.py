@@ -31,6 +31,7 @@ def main(S=128, n=50000, T=0.66, K=8, seed=100000, out="scratch/ipm/problems_c2.
             iters.append(int(info[1])); tot += int(info[1])
         assert tot == int(r["flags"][3]), (tot, r["flags"])
         kd.close(); ke.close(); mpc.close(); m2.close()
+    os.makedirs(os.path.dirname(os.path.abspath(out)), exist_ok=True)
     np.savez_compressed(out, ref=np.array(refs), w0=np.array(w0s), pas=np.array(passes), scene=np.array(scene_of),
                         iters=np.array(iters), T=T, K=K)
     it = np.array(iters); pa = np.array(passes)

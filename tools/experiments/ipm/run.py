@@ -7,8 +7,10 @@ import numpy as np
 from avoid_mpc_amd import synth
 from tests import _oracle
 
-def build():
-    src = os.path.join(ROOT, "tools/experiments/ipm/proto.c"); so = os.path.join(ROOT, "scratch/ipm/libproto.so")
+def build(out_dir=None):
+    out_dir = out_dir or os.path.join(ROOT, "scratch/ipm")
+    os.makedirs(out_dir, exist_ok=True)
+    src = os.path.join(ROOT, "tools/experiments/ipm/proto.c"); so = os.path.join(out_dir, "libproto.so")
     subprocess.check_call(["gcc", "-O2", "-march=x86-64-v3", "-ffp-contract=off", "-fPIC", "-shared", "-o", so, src, "-lm"])
     return C.CDLL(so)
 
@@ -18,8 +20,8 @@ class ProtoOpts(C.Structure):
 _f64p = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS"); _i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 class Bench:
-    def __init__(self, path=os.path.join(ROOT, "scratch/ipm/problems_c2.npz")):
-        self.lib = build()
+    def __init__(self, path=os.path.join(ROOT, "scratch/ipm/problems_c2.npz"), out_dir=None):
+        self.lib = build(out_dir)
         self.lib.proto_solve.restype = C.c_int
         self.lib.proto_solve.argtypes = [_f64p, _f64p, _f64p, _f64p, C.c_int, C.c_int, C.c_double, C.POINTER(_oracle.MpcoOpts),
                                          C.POINTER(ProtoOpts), _f64p, _i32p, _f64p]
