@@ -32,7 +32,7 @@ SYMBOLS = [
     "amk_kd_build_host", "amk_kd_search_host", "amk_kd_tie_flags", "amk_kd_set_tie_order", "amk_kd_exact_status", "amk_kd_exact_status_host", "amk_kd_keyframe_sweep",
     "amk_kd_keyframe_sweep_host", "amk_kd_points_host",
     "amk_mpc_create", "amk_mpc_destroy", "amk_mpc_horizon", "amk_mpc_nx", "amk_mpc_ref_len",
-    "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drone_radius",
+    "amk_mpc_setup_weights", "amk_mpc_setup_tau", "amk_mpc_setup_gains", "amk_mpc_set_drag_coefficient", "amk_mpc_set_drone_radius",
     "amk_kfmap_pool_bytes", "amk_kfmap_create", "amk_kfmap_destroy", "amk_kfmap_reset", "amk_kfmap_scenes", "amk_kfmap_frames", "amk_kfmap_twc", "amk_kfmap_add_vertex",
     "amk_kfmap_update", "amk_kfmap_step", "amk_kfmap_state_host",
     "amk_mpc_set_drone_accel_limits", "amk_mpc_set_solver_options", "amk_mpc_set_solve_budget", "amk_mpc_set_precision", "amk_mpc_solve",
@@ -156,6 +156,7 @@ def load():
         "amk_mpc_setup_weights": (i, [vp, vp]),
         "amk_mpc_setup_tau": (i, [vp, vp]),
         "amk_mpc_setup_gains": (i, [vp, vp]),
+        "amk_mpc_set_drag_coefficient": (i, [vp, d, d, d]),
         "amk_mpc_set_drone_radius": (i, [vp, d]),
         "amk_mpc_set_drone_accel_limits": (i, [vp, d, d, d, d]),
         "amk_mpc_set_solver_options": (i, [vp, d, i]),

@@ -293,26 +293,26 @@ inline Dual operator+(Dual a, Dual b) { return {a.v + b.v, a.d + b.d}; }
 inline Dual operator-(Dual a, Dual b) { return {a.v - b.v, a.d - b.d}; }
 inline Dual operator*(Dual a, Dual b) { return {a.v * b.v, a.d * b.v + a.v * b.d}; }
 inline Dual operator*(double a, Dual b) { return {a * b.v, a * b.d}; }
-void ode_dual(const Dual *x, const Dual *u, const Dual *tau, Dual *xd) {  // mpc_obstacle_casadi.py:106-122
+void ode_dual(const Dual *x, const Dual *u, const Dual *tau, const double *drag, Dual *xd) {  // mpc_obstacle_casadi.py:95-122
     xd[0] = x[4]; xd[1] = x[5]; xd[2] = x[6];
     xd[3] = u[3];
-    xd[4] = x[7]; xd[5] = x[8]; xd[6] = x[9];
+    xd[4] = x[7] - drag[0] * x[4]; xd[5] = x[8] - drag[1] * x[5]; xd[6] = x[9] - drag[2] * x[6];   // (amk_mpc_set_drag_coefficient)
     xd[7] = (u[0] - x[7]) * tau[0];
     xd[8] = (u[1] - x[8]) * tau[1];
     xd[9] = (u[2] - Dual{9.81, 0.0} - x[9]) * tau[2];
 }
-void rk4_dual(const Dual *x, const Dual *u, const Dual *tau, double dt, Dual *xn) {  // :338-357
+void rk4_dual(const Dual *x, const Dual *u, const Dual *tau, const double *drag, double dt, Dual *xn) {  // :338-357
     const double DT = dt / 4;
     Dual X[SD], k1[SD], k2[SD], k3[SD], k4[SD], t[SD];
     for (int i = 0; i < SD; ++i) X[i] = x[i];
     for (int m = 0; m < 4; ++m) {
-        ode_dual(X, u, tau, k1);
+        ode_dual(X, u, tau, drag, k1);
         for (int i = 0; i < SD; ++i) { k1[i] = DT * k1[i]; t[i] = X[i] + 0.5 * k1[i]; }
-        ode_dual(t, u, tau, k2);
+        ode_dual(t, u, tau, drag, k2);
         for (int i = 0; i < SD; ++i) { k2[i] = DT * k2[i]; t[i] = X[i] + 0.5 * k2[i]; }
-        ode_dual(t, u, tau, k3);
+        ode_dual(t, u, tau, drag, k3);
         for (int i = 0; i < SD; ++i) { k3[i] = DT * k3[i]; t[i] = X[i] + k3[i]; }
-        ode_dual(t, u, tau, k4);
+        ode_dual(t, u, tau, drag, k4);
         for (int i = 0; i < SD; ++i) { k4[i] = DT * k4[i]; X[i] = X[i] + (1.0 / 6) * (k1[i] + 2.0 * k2[i] + 2.0 * k3[i] + k4[i]); }
     }
     for (int i = 0; i < SD; ++i) xn[i] = X[i];
@@ -325,17 +325,17 @@ void dynamics_dtau(const amk_mpc *m, double *out /* [3][150] */) {
         for (int i = 0; i < SD; ++i) z10[i] = {0.0, 0.0};
         for (int i = 0; i < UD; ++i) z4[i] = {0.0, 0.0};
         double *dA = out + a * 150, *dB = dA + 100, *dc = dA + 140;
-        rk4_dual(z10, z4, tau, m->dt, c);
+        rk4_dual(z10, z4, tau, m->drag, m->dt, c);
         for (int i = 0; i < SD; ++i) dc[i] = c[i].d;
         for (int j = 0; j < SD; ++j) {
             for (int i = 0; i < SD; ++i) e[i] = {i == j ? 1.0 : 0.0, 0.0};
-            rk4_dual(e, z4, tau, m->dt, f);
+            rk4_dual(e, z4, tau, m->drag, m->dt, f);
             for (int i = 0; i < SD; ++i) dA[i * SD + j] = f[i].d - c[i].d;
         }
         for (int j = 0; j < UD; ++j) {
             Dual e4[UD];
             for (int i = 0; i < UD; ++i) e4[i] = {i == j ? 1.0 : 0.0, 0.0};
-            rk4_dual(z10, e4, tau, m->dt, f);
+            rk4_dual(z10, e4, tau, m->drag, m->dt, f);
             for (int i = 0; i < SD; ++i) dB[i * UD + j] = f[i].d - c[i].d;
         }
     }

@@ -10,6 +10,7 @@ struct amk_mpc {
     int run_scenes = 0;       // internal (amk_pipeline, a gang that is not full): launches cover scenes [0, run_scenes); 0 = all S
     int launch_scenes() const { return run_scenes > 0 && run_scenes < S ? run_scenes : S; }
     double h_prm[amk::PRM_LEN];
+    double drag[3] = {0.0, 0.0, 0.0};   // amk_mpc_set_drag_coefficient: v' = a - drag .* v (host-side: only A, B, c see it)
     amk::SolveOpts opt;
     size_t lds_bytes = 0;     // fp64 scratchpad; the fp32 kernels take half
     int precision = 64;       // arithmetic of the solve: 64 (default) or 32 (amk_mpc_set_precision)

@@ -18,28 +18,30 @@ namespace {
 // ---- host-side model: RK4 x 4 of the quadrotor ODE (mpc_obstacle_casadi.py:106-122, 338-357) probed for
 // its affine form F(x,u) = A x + B u + c (exactly affine with the drag term off, the repo default
 // mpc_parameters.yaml:4).
-void ode_host(const double *x, const double *u, const double *tau, double *xd) {
+// Drag (mpc_obstacle_casadi.py:95-105, yaml use_drag_coefficient): `rotmat * diag(k, k, k) * rotmat.T * v` read as matrix products is
+// k v whatever the attitude (R (k I) R' = k I) -- linear in the state, so F stays affine with the same sparsity (amk_mpc_set_drag_coefficient).
+void ode_host(const double *x, const double *u, const double *tau, const double *drag, double *xd) {
     xd[0] = x[4]; xd[1] = x[5]; xd[2] = x[6];
     xd[3] = u[3];
-    xd[4] = x[7]; xd[5] = x[8]; xd[6] = x[9];
+    xd[4] = x[7] - drag[0] * x[4]; xd[5] = x[8] - drag[1] * x[5]; xd[6] = x[9] - drag[2] * x[6];
     xd[7] = (u[0] - x[7]) * tau[0];
     xd[8] = (u[1] - x[8]) * tau[1];
     xd[9] = (u[2] - kGz - x[9]) * tau[2];
 }
 
-void rk4_host(const double *x, const double *u, const double *tau, double dt, double *xn) {
+void rk4_host(const double *x, const double *u, const double *tau, const double *drag, double dt, double *xn) {
     const int M = 4;
     const double DT = dt / M;
     double X[SD], k1[SD], k2[SD], k3[SD], k4[SD], t[SD];
     std::memcpy(X, x, sizeof X);
     for (int m = 0; m < M; ++m) {
-        ode_host(X, u, tau, k1);
+        ode_host(X, u, tau, drag, k1);
         for (int i = 0; i < SD; ++i) { k1[i] *= DT; t[i] = X[i] + 0.5 * k1[i]; }
-        ode_host(t, u, tau, k2);
+        ode_host(t, u, tau, drag, k2);
         for (int i = 0; i < SD; ++i) { k2[i] *= DT; t[i] = X[i] + 0.5 * k2[i]; }
-        ode_host(t, u, tau, k3);
+        ode_host(t, u, tau, drag, k3);
         for (int i = 0; i < SD; ++i) { k3[i] *= DT; t[i] = X[i] + k3[i]; }
-        ode_host(t, u, tau, k4);
+        ode_host(t, u, tau, drag, k4);
         for (int i = 0; i < SD; ++i) { k4[i] *= DT; X[i] = X[i] + (k1[i] + 2 * k2[i] + 2 * k3[i] + k4[i]) / 6; }
     }
     std::memcpy(xn, X, sizeof X);
@@ -49,17 +51,17 @@ void refresh_dynamics(amk_mpc *m) {
     double *A = m->h_prm + PRM_A, *B = m->h_prm + PRM_B, *c = m->h_prm + PRM_C;
     const double *tau = m->h_prm + PRM_TAU;
     double z10[SD] = {0}, z4[UD] = {0}, e10[SD], e4[UD], f[SD];
-    rk4_host(z10, z4, tau, m->dt, c);
+    rk4_host(z10, z4, tau, m->drag, m->dt, c);
     for (int j = 0; j < SD; ++j) {
         std::memset(e10, 0, sizeof e10);
         e10[j] = 1.0;
-        rk4_host(e10, z4, tau, m->dt, f);
+        rk4_host(e10, z4, tau, m->drag, m->dt, f);
         for (int i = 0; i < SD; ++i) A[i * SD + j] = f[i] - c[i];
     }
     for (int j = 0; j < UD; ++j) {
         std::memset(e4, 0, sizeof e4);
         e4[j] = 1.0;
-        rk4_host(z10, e4, tau, m->dt, f);
+        rk4_host(z10, e4, tau, m->drag, m->dt, f);
         for (int i = 0; i < SD; ++i) B[i * UD + j] = f[i] - c[i];
     }
 }
@@ -454,6 +456,15 @@ int amk_mpc_setup_weights(amk_mpc *m, const double *w) {
 int amk_mpc_setup_tau(amk_mpc *m, const double *tau) {
     if (!m || !tau) return AMK_ERR_INVALID_ARG;
     std::memcpy(m->h_prm + PRM_TAU, tau, sizeof(double) * 4);
+    refresh_dynamics(m);
+    return upload_params(m);
+}
+// The reference's use_drag_coefficient switch in the one reading under which it is well defined (see ode_host): v' = a - k .* v.
+// Changes A (the v <- v and p <- v entries) and nothing of its sparsity; the Riccati plan is rebuilt from the new values.
+int amk_mpc_set_drag_coefficient(amk_mpc *m, double kx, double ky, double kz) {
+    if (!m || !(kx >= 0.0 && ky >= 0.0 && kz >= 0.0) || !(kx < 1e3 && ky < 1e3 && kz < 1e3)) return AMK_ERR_INVALID_ARG;
+    m->drag[0] = kx; m->drag[1] = ky; m->drag[2] = kz;
+    m->ev_dtau_valid = false;   // d(A, B, c)/d tau depends on the drag too
     refresh_dynamics(m);
     return upload_params(m);
 }

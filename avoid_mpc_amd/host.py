@@ -175,6 +175,11 @@ class MpcBatch:
     def SetDroneRadius(self, r):
         capi.check(self.lib.amk_mpc_set_drone_radius(self.h, float(r)), "SetDroneRadius")
 
+    def SetDragCoefficient(self, kx, ky=None, kz=None):
+        """v' = a - k .* v (the generator's use_drag_coefficient switch read as matrix products: include/avoid_mpc_amd.h); one value = isotropic."""
+        ky = kx if ky is None else ky; kz = kx if kz is None else kz
+        capi.check(self.lib.amk_mpc_set_drag_coefficient(self.h, float(kx), float(ky), float(kz)), "SetDragCoefficient")
+
     def SetDroneAccelLimits(self, aMinZ, aMaxZ, aMaxXy, aMaxYawDot):
         capi.check(self.lib.amk_mpc_set_drone_accel_limits(self.h, float(aMinZ), float(aMaxZ), float(aMaxXy),
                                                            float(aMaxYawDot)), "SetDroneAccelLimits")
@@ -196,6 +201,8 @@ class MpcBatch:
         self.SetupWeights(prm.weights); self.SetupTau(prm.tau); self.SetupGains(prm.gain)
         self.SetDroneAccelLimits(prm.a_min_z, prm.a_max_z, prm.a_max_xy, prm.a_max_yaw_dot)
         self.SetDroneRadius(prm.radius)
+        if any(getattr(prm, "drag", (0.0, 0.0, 0.0))):
+            self.SetDragCoefficient(*prm.drag)
 
     def Solve(self, ref_states, faster=False, stream=None, want_traj=True):
         assert ref_states.dtype == torch.float64 and tuple(ref_states.shape) == (self.S, self.ref_len)

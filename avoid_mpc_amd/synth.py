@@ -46,6 +46,7 @@ class MpcParams:
     height: float = 1.5
     safety_distance: float = 0.2
     decay: float = 0.015
+    drag: tuple = (0.0, 0.0, 0.0)         # use_drag_coefficient read as k v (0.033 in the generator); 0 = the yaml's default
 
     @property
     def N(self):

@@ -176,6 +176,12 @@ int amk_mpc_ref_len(const amk_mpc *mpc);   /* 20 + 10 N + 3 K N  (what GetRefSta
 int amk_mpc_setup_weights(amk_mpc *mpc, const double *h_weights25); /* SetupWeights  .cpp:58-60  */
 int amk_mpc_setup_tau(amk_mpc *mpc, const double *h_tau4);          /* SetupTau      .cpp:61-63  */
 int amk_mpc_setup_gains(amk_mpc *mpc, const double *h_gains4);      /* SetupGains    .cpp:67-69  */
+/* The generator's use_drag_coefficient switch (mpc_obstacle_casadi.py:95-105, mpc_parameters.yaml:4; off by default, hard-coded 0.033).
+ * Its expression `rotmat * diag(k, k, k) * rotmat.T * (vx, vy, vz)`, read as the matrix products it describes, is k v whatever the attitude
+ * (R (k I) R' = k I): v' = a - k .* v, linear in the state, so the RK4 map stays affine with the same sparsity and the solver is unchanged
+ * -- only A differs.  (As written, with CasADi's element-wise `*`, a 3 x 3 times a 3 x 1 is a dimension error; the reference cannot have
+ * exercised it, and it cannot be checked here: CasADi is absent.)  One coefficient per world axis, >= 0; 0, 0, 0 = the reference's default. */
+int amk_mpc_set_drag_coefficient(amk_mpc *mpc, double kx, double ky, double kz);
 int amk_mpc_set_drone_radius(amk_mpc *mpc, double radius);          /* SetDroneRadius .cpp:64-66 */
 int amk_mpc_set_drone_accel_limits(amk_mpc *mpc, double aMinZ, double aMaxZ, double aMaxXy,
                                    double aMaxYawDot);              /* .cpp:70-92                */

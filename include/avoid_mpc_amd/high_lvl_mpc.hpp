@@ -32,7 +32,7 @@ public:
         if (this != &o) {
             if (mpc_) amk_mpc_destroy(mpc_);
             mT = o.mT; mDt = o.mDt; mN = o.mN; mK = o.mK; mSoPath = o.mSoPath;
-            mDroneRadius = o.mDroneRadius; mTau = o.mTau; mGains = o.mGains; mWeights = o.mWeights;
+            mDroneRadius = o.mDroneRadius; for (int i = 0; i < 3; ++i) mDrag[i] = o.mDrag[i]; mTau = o.mTau; mGains = o.mGains; mWeights = o.mWeights;
             mLimits = o.mLimits; mHaveLimits = o.mHaveLimits; mpc_ = o.mpc_;
             o.mpc_ = nullptr;
         }
@@ -43,6 +43,9 @@ public:
     void SetupTau(const std::vector<double> &tau) { mTau = tau; if (mpc_) Push(); }
     void SetupGains(const std::vector<double> &gains) { mGains = gains; if (mpc_) Push(); }
     void SetDroneRadius(const double droneRadius) { mDroneRadius = droneRadius; if (mpc_) Push(); }
+    // Not in the reference's class (the generator bakes it into the plugin: use_drag_coefficient, mpc_obstacle_casadi.py:95-105):
+    // v' = a - k .* v, the switch's expression read as matrix products (amk_mpc_set_drag_coefficient); {0, 0, 0} = off, the yaml's default
+    void SetDragCoefficient(double kx, double ky, double kz) { mDrag[0] = kx; mDrag[1] = ky; mDrag[2] = kz; if (mpc_) Push(); }
     void SetDroneAccelLimits(const double aMinZ, const double aMaxZ, const double aMaxXy, const double aMaxYawDot) {
         mLimits = {aMinZ, aMaxZ, aMaxXy, aMaxYawDot};
         mHaveLimits = true;
@@ -88,6 +91,7 @@ private:
         amk_mpc_setup_tau(mpc_, mTau.data());
         amk_mpc_setup_gains(mpc_, mGains.data());
         amk_mpc_set_drone_radius(mpc_, mDroneRadius);
+        amk_mpc_set_drag_coefficient(mpc_, mDrag[0], mDrag[1], mDrag[2]);
         if (mHaveLimits) amk_mpc_set_drone_accel_limits(mpc_, mLimits[0], mLimits[1], mLimits[2], mLimits[3]);
         amk_mpc_set_precision(mpc_, mPrecision);
     }
@@ -95,6 +99,7 @@ private:
     int mN = 0, mK = -1, mPrecision = 64;
     std::string mSoPath;
     double mDroneRadius = 0;
+    double mDrag[3] = {0.0, 0.0, 0.0};
     std::vector<double> mTau, mGains, mWeights, mLimits;
     bool mHaveLimits = false;
     amk_mpc *mpc_ = nullptr;

@@ -59,11 +59,14 @@ def split_p(P, N, K):
 # ----------------------------------------------------------------------------------------------
 # dynamics  (mpc_obstacle_casadi.py:106-122 ode, :338-357 RK4 x 4)
 # ----------------------------------------------------------------------------------------------
+DRAG = np.zeros(3)   # v' = a - DRAG * v (mpc_obstacle_casadi.py:95-105 read as matrix products: R (k I) R' v = k v; see mpc_oracle.c)
+
+
 def ode(x, u, tau):
     return np.array([
         x[4], x[5], x[6],
         u[3],
-        x[7], x[8], x[9],
+        x[7] - DRAG[0] * x[4], x[8] - DRAG[1] * x[5], x[9] - DRAG[2] * x[6],
         (u[0] - x[7]) * tau[0],
         (u[1] - x[8]) * tau[1],
         (u[2] - GZ - x[9]) * tau[2],

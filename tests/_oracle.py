@@ -164,6 +164,7 @@ def _decl_mpc(lib):
     lib.mpco_set_drone_radius.argtypes = [vp, d]
     lib.mpco_set_drone_accel_limits.argtypes = [vp, d, d, d, d]
     lib.mpco_set_solver_options.argtypes = [vp, d, i]
+    lib.mpco_set_drag.argtypes = [_f64p]
     lib.mpco_warm_start.restype = C.POINTER(C.c_double); lib.mpco_warm_start.argtypes = [vp]
     lib.mpco_last_info.restype = C.POINTER(C.c_int); lib.mpco_last_info.argtypes = [vp]
     lib.mpco_last_stats.restype = C.POINTER(C.c_double); lib.mpco_last_stats.argtypes = [vp]
@@ -173,6 +174,29 @@ def _decl_mpc(lib):
         lib.stepo_run.argtypes = [vp, vp, vp, i, d, d, d, i, _f64p, d, _f64p, _f64p, _f64p, _i32p, vp]
         lib.stepo_cur_state_quad.argtypes = [_f64p, _f64p, _f64p, d, d, i, _f64p]
         lib.stepo_get_init_path.argtypes = [_f64p, i, d, d, d, d, d]
+
+
+class oracle_drag:
+    """`with oracle_drag(k):` -- the oracle's dynamics with v' = a - k .* v (oracle/mpc_oracle.c: the use_drag_coefficient switch read
+    as matrix products) in the C restatement AND the numpy twin; restored to the default (off) on exit."""
+
+    def __init__(self, k):
+        self.k = np.ascontiguousarray(np.broadcast_to(np.asarray(k, np.float64), (3,)).copy())
+
+    @staticmethod
+    def _twins():   # the numpy twin is imported as `mpc_oracle_np` (oracle/ on sys.path) by the tests: every loaded instance
+        import sys
+        return [m for n, m in sys.modules.items() if n.split(".")[-1] == "mpc_oracle_np" and hasattr(m, "DRAG")]
+
+    def __enter__(self):
+        load_oracle().mpco_set_drag(self.k)
+        for m in self._twins(): m.DRAG[:] = self.k
+        return self
+
+    def __exit__(self, *exc):
+        load_oracle().mpco_set_drag(np.zeros(3))
+        for m in self._twins(): m.DRAG[:] = 0.0
+        return False
 
 
 MPC_DEFAULT_MAX_ITER = 100   # oracle/mpc_oracle.c MPCO_DEFAULT_MAX_ITER == the product's default (amk_mpc_create)

@@ -52,6 +52,38 @@ def test_dynamics_are_affine_with_the_documented_structure(oracle):
     assert np.allclose(f, M.rk4_step(x, u, tau, DT), atol=1e-15)
 
 
+def test_drag_read_as_matrix_products_is_linear_and_keeps_the_structure(oracle):
+    """The generator's use_drag_coefficient switch (mpc_obstacle_casadi.py:95-105): `rotmat * diag(k, k, k) * rotmat.T * v` as matrix
+    products is k v for EVERY rotation (R (k I) R' = k I) -- checked here on random attitudes with the generator's own acc2rotmat
+    (:253-264) -- so v' = a - k v: the RK4 map stays exactly affine, with the sparsity of the drag-free one (19 / 10 / 3 non-zeros),
+    and C == numpy.  (With CasADi's element-wise `*` the expression is a dimension error; nothing here can check that reading.)"""
+    rng = np.random.default_rng(3)
+    for _ in range(20):   # acc2rotmat restated: zb = acc / |acc|, yb = zb x (cos yaw, sin yaw, 0) normalised, xb = yb x zb
+        acc = rng.normal(size=3) + np.array([0.0, 0.0, 9.81]); yaw = rng.uniform(-3, 3); v = rng.normal(size=3)
+        zb = acc / np.linalg.norm(acc); yb = np.cross(zb, [np.cos(yaw), np.sin(yaw), 0.0]); yb /= np.linalg.norm(yb); xb = np.cross(yb, zb)
+        R = np.stack([xb, yb, zb], axis=1)
+        assert np.allclose(R @ np.diag([0.033] * 3) @ R.T @ v, 0.033 * v, atol=1e-15)
+    tau = np.array(synth.DEFAULT_TAU)
+    A0 = np.zeros(100); B0 = np.zeros(40); c0 = np.zeros(10)
+    oracle.mpco_affine(tau, DT, A0, B0, c0)
+    with _oracle.oracle_drag(0.033):
+        A = np.zeros(100); B = np.zeros(40); c = np.zeros(10)
+        oracle.mpco_affine(tau, DT, A, B, c)
+        An, Bn, cn = M.affine_dynamics(tau, DT)
+        assert np.allclose(A.reshape(10, 10), An, atol=1e-15) and np.allclose(B.reshape(10, 4), Bn, atol=1e-15) and np.allclose(c, cn, atol=1e-15)
+        assert np.array_equal(A != 0, A0 != 0) and np.array_equal(B != 0, B0 != 0) and np.array_equal(c != 0, c0 != 0)
+        A2, B2 = A.reshape(10, 10), B.reshape(10, 4)
+        assert abs(A2[4, 4] - np.exp(-0.033 * DT)) < 1e-9 and A2[4, 4] < 1.0 == A0.reshape(10, 10)[4, 4]   # v <- v: e^{-k dt} (RK4 of a linear ODE)
+        x, u = rng.normal(size=10), rng.normal(size=4)
+        f = np.zeros(10); oracle.mpco_rk4_step(x, u, tau, DT, f)
+        assert np.allclose(f, A2 @ x + B2 @ u + c, atol=1e-13) and np.allclose(f, M.rk4_step(x, u, tau, DT), atol=1e-15)
+        P = G["smoke.P"]; w = _rand_w(rng)
+        cg = np.zeros(10 + 10 * N); oracle.mpco_nlp_g(w, P, N, K, DT, cg)
+        assert np.abs(cg - M.nlp_g(w, P, N, K, DT)).max() < 1e-13
+    A1 = np.zeros(100); oracle.mpco_affine(tau, DT, A1, B0, c0)
+    assert np.array_equal(A1, A0)                      # the switch is off again
+
+
 def test_c_equals_numpy_on_values_and_derivatives(oracle):
     P = G["smoke.P"]
     rng = np.random.default_rng(1)

@@ -222,6 +222,8 @@ int proto_solve(const double *P, const double *w0, const double *lbu, const doub
     int status = 1, n_reg = 0, ls_fail = 0, it, n_ls = 0;
     double(*rbp)[UD] = w->rb, (*Rbp)[UD] = w->Rb;
     double mu_s = 0.0; double gU_true[MAXN][UD];
+    double prev_delta = 0.0;
+    int spec_n = 0, spec_hit = 0, spec_waste = 0, spec_more = 0, nospec_n = 0, nospec_fail = 0;
     for (it = 0; it < opt.max_iter; ++it) {
         mu_s = 0.0;
         if (po->diag)
@@ -250,12 +252,18 @@ int proto_solve(const double *P, const double *w0, const double *lbu, const doub
                 Rbp[k][i] = w->Rd[k][i] + w->zl[k][i] / sl + w->zu[k][i] / su;
             }
         double delta = 0.0;
+        int tries = 0;
+        const int spec = prev_delta > 0.0;   /* census for a speculative double sweep (delta = 0 and delta_last / 3 in one pass) */
         while (!riccati(w, (const double(*)[UD])rbp, (const double(*)[UD])Rbp, delta)) {
             if (delta == 0.0) delta = (delta_last == 0.0) ? 1.0 : dmax(1e-20, delta_last / 3.0);
             else delta *= (delta_last == 0.0) ? 100.0 : 8.0;
             ++n_reg;
+            ++tries;
             if (delta > 1e40) break;
         }
+        prev_delta = delta;
+        if (spec) { ++spec_n; if (tries == 0) ++spec_waste; else if (tries == 1) ++spec_hit; else ++spec_more; }
+        else { ++nospec_n; nospec_fail += tries; }
         if (delta > 1e40) { status = 2; break; }
         if (delta > 0.0) delta_last = delta;
         double a_pr = 1.0, a_du = 1.0, dphi = 0.0;
@@ -325,7 +333,8 @@ int proto_solve(const double *P, const double *w0, const double *lbu, const doub
         memcpy(UK(w_out, k), w->U[k], sizeof(double) * UD);
     }
     memcpy(XK(w_out, N), w->X[N], sizeof(double) * SD);
-    if (info) { info[0] = status; info[1] = it; info[2] = n_reg; info[3] = ls_fail; info[4] = n_ls; }
+    if (info) { info[0] = status; info[1] = it; info[2] = n_reg; info[3] = ls_fail; info[4] = n_ls; info[5] = spec_n; info[6] = spec_hit; info[7] = spec_waste; }
+    if (stats) { (void)spec_more; (void)nospec_n; (void)nospec_fail; }
     if (stats) { stats[0] = J; stats[1] = err[0]; stats[2] = mu; stats[3] = delta_last; }
     free(w);
     return status;
