@@ -215,7 +215,7 @@ int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const am
     if (prm->max_frame_count < 1 || prm->max_frame_count + 1 > AMK_MAX_MAP_FRAMES) return AMK_ERR_UNSUPPORTED;
     if (amk_device_count() <= 0) return AMK_ERR_NO_DEVICE;
     {   // the pools are allocated eagerly at full capacity: say what they need before the allocator fails half-way with a bare
-        // out-of-memory (max_frame_count = 100 with 512 scenes x 50 k points is ~ 80 GB per map)
+        // out-of-memory (max_frame_count = 100 with 512 scenes x 50 k points is 86 GB per map)
         long long need = 0;
         size_t free_b = 0, total_b = 0;
         if (amk_kfmap_pool_bytes(n_scenes, max_points, max_edge_points, prm->max_frame_count, &need) == AMK_OK &&

@@ -509,8 +509,8 @@ int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x
 /* Memory.  The pools are allocated at creation, at full capacity: with cap(p) = round_up(p, 256) + 1024 points per pool scene
  *   bytes ~ (max_frame_count + 2) x n_scenes x [ 16 cap(max_points) + 16 cap(max_edge_points) + 13 cap(max_points) + directories ]
  *           + n_scenes x 16 cap(max_points)                                                         (amk_kfmap_pool_bytes)
- * i.e. ~ 45 B per obstacle point per slot: the reference's max_frame_count = 100 at its own 3072-point frames is 15 MB per robot,
- * at 50 k-point frames 240 MB per robot.  A flight holds ~ 6 frames; slots a scene never uses are still reserved.
+ * i.e. ~ 30 B per obstacle point per slot + the edge pool: the reference's max_frame_count = 100 at its own 3072-point frames is 20 MB per
+ * robot, at 50 k-point frames 170 MB per robot.  A flight holds ~ 6 frames; slots a scene never uses are still reserved.
  * amk_kfmap_create compares the figure with the device's free memory first and returns AMK_ERR_UNSUPPORTED (message with both
  * numbers on stderr) instead of failing half-way through the allocations with AMK_ERR_HIP.
  * Call order.  add_vertex -> update -> step per control period is what amk_pipeline issues.  add_vertex alone already points the

@@ -61,6 +61,24 @@ def test_no_cpu_fallback(lib):
     assert lib.amk_shard_scene_range(2, 3, 8, C.byref(first), C.byref(count)) == 0 and (first.value, count.value) == (6, 2)
 
 
+def test_kfmap_pool_bytes_is_host_arithmetic(lib):
+    """amk_kfmap_pool_bytes: what a map's pools reserve -- ~30 B per obstacle point and slot + the edge pool, (max_frame_count + 2) slots per
+    scene; no device needed."""
+    import ctypes as C
+    b = C.c_longlong()
+    assert lib.amk_kfmap_pool_bytes(1, 3072, 3072, 100, C.byref(b)) == 0
+    per_robot_yaml = b.value
+    assert 10e6 < per_robot_yaml < 40e6                                   # the yaml's map: tens of MB per robot
+    assert lib.amk_kfmap_pool_bytes(512, 50000, 5000, 100, C.byref(b)) == 0
+    assert 70e9 < b.value < 110e9                                         # the advisor's example (86 GB): two pipeline slots of it already exceed half a 288 GB device
+    assert lib.amk_kfmap_pool_bytes(512, 50000, 5000, 3, C.byref(b)) == 0 and 4e9 < b.value < 9e9
+    small = C.c_longlong(); assert lib.amk_kfmap_pool_bytes(256, 50000, 5000, 3, C.byref(small)) == 0
+    assert abs(b.value - 2 * small.value) < 1e-3 * b.value                # linear in the scenes
+    assert lib.amk_kfmap_pool_bytes(0, 100, 100, 3, C.byref(b)) == capi.AMK_ERR_INVALID_ARG
+    assert lib.amk_kfmap_pool_bytes(4, 100, 100, 0, C.byref(b)) == capi.AMK_ERR_INVALID_ARG
+    assert lib.amk_kfmap_pool_bytes(4, 100, 100, 3, None) == capi.AMK_ERR_INVALID_ARG
+
+
 def test_product_never_touches_the_oracle():
     bad = []
     for dirpath, _, files in os.walk(os.path.join(ROOT, "avoid_mpc_amd")):

@@ -130,6 +130,10 @@ def test_argument_errors(torch_cuda):
     assert lib.amk_kfmap_create(4, 100, 100, C.byref(capi.KfmapParams(0, 10, 0.1, 0.1, Tbc)), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED
     assert lib.amk_kfmap_create(4, 100, 100, C.byref(capi.KfmapParams(101, 10, 0.1, 0.1, Tbc)), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED
     assert lib.amk_kfmap_create(4, 100, 100, C.byref(capi.KfmapParams(3, 0, 0.1, 0.1, Tbc)), C.byref(h)) == capi.AMK_ERR_INVALID_ARG
+    # a map whose pools cannot fit is refused up front, with the figure: 4096 robots x 102 slots x 200 k points ~ 4 TB
+    need = C.c_longlong()
+    assert lib.amk_kfmap_pool_bytes(4096, 200000, 20000, 100, C.byref(need)) == 0 and need.value > 1e12
+    assert lib.amk_kfmap_create(4096, 200000, 20000, C.byref(capi.KfmapParams(100, 10, 0.1, 0.1, Tbc)), C.byref(h)) == capi.AMK_ERR_UNSUPPORTED and not h.value
     assert lib.amk_kfmap_create(4, 100, 100, C.byref(ok), C.byref(h)) == 0 and h.value
     assert lib.amk_kfmap_frames(h) == 4 and lib.amk_kfmap_scenes(h) == 4
     assert lib.amk_kfmap_add_vertex(h, 2, 3, None, None, None, None, 3, None, None) == capi.AMK_ERR_INVALID_ARG
