@@ -136,7 +136,18 @@ __device__ __forceinline__ real collide_term(const real p[3], const real v[3], c
         ir = c_ir;
         if (!(ir > RL(0.0))) { y1 = -RL(1.0); y2 = -RL(1.0); return RL(0.0); }  // dormant at the iterate
     } else {
-        const real rho = sqrt(d0 * d0 + d1 * d1 + d2 * d2);
+        // Exact-zero pre-test (round 6): the reference's naive softplus log(1 + exp(x)) is exactly 0 once exp(x) < 2^-53, i.e. x < -36.74, i.e.
+        // beyond 1.148 m of clearance.  A squared-distance test with a margin (x < -37: clearance > 1.15625 m) decides that without the
+        // sqrt -> exp -> log chain; a term inside the margin takes the chain and its own `c > 0` test as before, so the result is the same
+        // bits either way.  A round whose lanes are ALL beyond it (sparse worlds, the 1e4 padding of short neighbour lists) skips the
+        // chain altogether; on the bench's dense scenes 150 of 152 terms are live and this is two instructions per term.
+        const real rr2 = d0 * d0 + d1 * d1 + d2 * d2;
+        const real far = radius + (AMK_REAL_F32 ? RL(0.6) : RL(1.15625));   // (fp32: exp(x) < 2^-24 at x < -16.7: clearance 0.52 m)
+        if (rr2 > far * far * (RL(1.0) + RL(1e-6))) {
+            if (MODE == 1) c_ir = RL(0.0);
+            return RL(0.0);
+        }
+        const real rho = sqrt(rr2);
         const real x = -RL(32.0) * (rho - radius);
         ex = real_exp(x);
         g = real_log(RL(1.0) + ex);  // naive softplus, mpc_obstacle_casadi.py:250-251
