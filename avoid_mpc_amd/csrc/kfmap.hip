@@ -189,7 +189,7 @@ extern "C" {
 
 // Device bytes the map's pools will hold once the first sweep has run (the formula of the header): per pool scene the bucket
 // records (16 B per point of capacity), the tile directories, and for the obstacle pool the index-ordered planes (12 B) and the
-// sweep's outlier flags (1 B); per SCENE (sweep row) the hashed grid of the current frame (16 B per point + bucket starts).
+// sweep's outlier flags (1 B); per SCENE (sweep row) two generations of the hashed grid of the current frame (16 B per point + bucket starts each).
 int amk_kfmap_pool_bytes(int n_scenes, int max_points, int max_edge_points, int max_frame_count, long long *bytes_out) {
     if (!bytes_out || n_scenes <= 0 || max_points <= 0 || max_edge_points <= 0 || max_frame_count < 1) return AMK_ERR_INVALID_ARG;
     const long long P = max_frame_count + 2, S = n_scenes, F = max_frame_count + 1;
@@ -201,7 +201,7 @@ int amk_kfmap_pool_bytes(int n_scenes, int max_points, int max_edge_points, int 
     b += P * S * (12 + 1) * cap(max_points);                                      // x / y / z planes + flags (kd_sweep_mapped)
     int nb = 1024;
     while (nb < 16384 && nb < 2 * max_points) nb *= 2;
-    b += S * (16 * cap(max_points) + 4ll * (nb + 1));                             // the sweep's grid of the current frame
+    b += 2 * S * (16 * cap(max_points) + 4ll * (nb + 1)) + 12 * S;                // the sweep's grids of the current frame: two generations per row (kd_sweep_mapped)
     b += S * (4 * (8 + P + F) + 8 * 16);                                          // the deques, lists and Twc
     *bytes_out = b;
     return AMK_OK;

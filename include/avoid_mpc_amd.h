@@ -508,7 +508,7 @@ int amk_pipeline_outputs(amk_pipeline *p, int ticket, double **d_u, double **d_x
  * (any gang).  Twb = Twc * Tbc^-1 of DroneBehindPts uses the rigid inverse of Tbc.                                          */
 /* Memory.  The pools are allocated at creation, at full capacity: with cap(p) = round_up(p, 256) + 1024 points per pool scene
  *   bytes ~ (max_frame_count + 2) x n_scenes x [ 16 cap(max_points) + 16 cap(max_edge_points) + 13 cap(max_points) + directories ]
- *           + n_scenes x 16 cap(max_points)                                                         (amk_kfmap_pool_bytes)
+ *           + n_scenes x 2 x 16 cap(max_points)   (the sweep's grids: two generations per scene)    (amk_kfmap_pool_bytes)
  * i.e. ~ 30 B per obstacle point per slot + the edge pool: the reference's max_frame_count = 100 at its own 3072-point frames is 20 MB per
  * robot, at 50 k-point frames 170 MB per robot.  A flight holds ~ 6 frames; slots a scene never uses are still reserved.
  * amk_kfmap_create compares the figure with the device's free memory first and returns AMK_ERR_UNSUPPORTED (message with both
