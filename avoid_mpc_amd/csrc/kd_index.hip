@@ -514,8 +514,14 @@ __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
     __shared__ float wave_max[kCompactThreads / kWave];
     __shared__ float wave_bb[6][kCompactThreads / kWave];
     __shared__ int total_sh;
+    // Four consecutive elements per thread and trip (round 6: one element per trip was 98 trips of dependent loads and two barriers each at
+    // 50 k points: 183 us per 512-row launch).  The rows start at multiples of 256 elements and are NaN- / zero-padded to cap >= n + 1024,
+    // so the 4-byte flag words and 16-byte coordinate vectors are aligned and may overhang n.
     int cnt = 0;
-    for (int i = tid; i < n; i += kCompactThreads) cnt += fl[i];
+    for (int i = 4 * tid; i < n; i += 4 * kCompactThreads) {
+        const uchar4 f4 = *reinterpret_cast<const uchar4 *>(fl + i);
+        cnt += (f4.x != 0) + ((i + 1 < n) & (f4.y != 0)) + ((i + 2 < n) & (f4.z != 0)) + ((i + 3 < n) & (f4.w != 0));
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off);
     if (lane == 0) wave_tot[w] = cnt;
@@ -536,18 +542,23 @@ __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
     if (!rebuilt) return;
     float amax = 0.f, bmn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, bmx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
     int base = 0;
-    for (int c0 = 0; c0 < n; c0 += kCompactThreads) {
-        const int i = c0 + tid;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        bool valid = false;
+    for (int c0 = 0; c0 < n; c0 += 4 * kCompactThreads) {
+        const int i = c0 + 4 * tid;
+        float px[4] = {0.f, 0.f, 0.f, 0.f}, py[4] = {0.f, 0.f, 0.f, 0.f}, pz[4] = {0.f, 0.f, 0.f, 0.f};
+        bool valid[4] = {false, false, false, false};
         if (i < n) {
-            px = xs[i]; py = ys[i]; pz = zs[i];
-            valid = fl[i] != 0;
+            const float4 x4 = *reinterpret_cast<const float4 *>(xs + i), y4 = *reinterpret_cast<const float4 *>(ys + i),
+                         z4 = *reinterpret_cast<const float4 *>(zs + i);
+            const uchar4 f4 = *reinterpret_cast<const uchar4 *>(fl + i);
+            px[0] = x4.x; px[1] = x4.y; px[2] = x4.z; px[3] = x4.w;
+            py[0] = y4.x; py[1] = y4.y; py[2] = y4.z; py[3] = y4.w;
+            pz[0] = z4.x; pz[1] = z4.y; pz[2] = z4.z; pz[3] = z4.w;
+            valid[0] = f4.x != 0; valid[1] = i + 1 < n && f4.y != 0; valid[2] = i + 2 < n && f4.z != 0; valid[3] = i + 3 < n && f4.w != 0;
         }
-        const unsigned long long m = __ballot(valid);
-        const int prefix = __popcll(m & ((1ull << lane) - 1ull));
-        __syncthreads();  // every read of this chunk is done before anybody writes (in-place)
-        if (lane == 0) wave_tot[w] = __popcll(m);
+        const int mine = (int)valid[0] + (int)valid[1] + (int)valid[2] + (int)valid[3];
+        const int incl = amk::wave_incl_scan_i32(mine);
+        __syncthreads();  // every read of this chunk is done before anybody writes (in-place; the write cursor never passes the chunk's start)
+        if (lane == 63) wave_tot[w] = incl;
         __syncthreads();
         int woff = 0, tot = 0;
 #pragma unroll
@@ -556,16 +567,19 @@ __global__ __launch_bounds__(kCompactThreads) void kd_sweep_compact_kernel(
             woff += (j < w) ? t : 0;
             tot += t;
         }
-        if (valid) {
-            const int o = base + woff + prefix;
-            xs[o] = px; ys[o] = py; zs[o] = pz;
-            amax = fmaxf(amax, fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz))));
-            if (amk::finite3(px, py, pz)) {
-                bmn[0] = fminf(bmn[0], px); bmx[0] = fmaxf(bmx[0], px);
-                bmn[1] = fminf(bmn[1], py); bmx[1] = fmaxf(bmx[1], py);
-                bmn[2] = fminf(bmn[2], pz); bmx[2] = fmaxf(bmx[2], pz);
+        int o = base + woff + incl - mine;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (valid[e]) {
+                xs[o] = px[e]; ys[o] = py[e]; zs[o] = pz[e];
+                ++o;
+                amax = fmaxf(amax, fmaxf(fabsf(px[e]), fmaxf(fabsf(py[e]), fabsf(pz[e]))));
+                if (amk::finite3(px[e], py[e], pz[e])) {
+                    bmn[0] = fminf(bmn[0], px[e]); bmx[0] = fmaxf(bmx[0], px[e]);
+                    bmn[1] = fminf(bmn[1], py[e]); bmx[1] = fmaxf(bmx[1], py[e]);
+                    bmn[2] = fminf(bmn[2], pz[e]); bmx[2] = fmaxf(bmx[2], pz[e]);
+                }
             }
-        }
         base += tot;
         __syncthreads();
     }
@@ -821,6 +835,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
     // 14 % outliers cost 90 % of an all-outlier pair); after the compaction the wavefronts of phase B are full of open queries and the others
     // have retired.  Same cells, same screen, same exact test: same flags.
     __shared__ float4 open_q[256];
+    __shared__ int4 open_c[256];   // the open query's own cell and, per axis, which other cell its cube reaches (bits 0-2: has one, 3-5: it is the next one up)
     __shared__ int n_open;
     if (threadIdx.x == 0) n_open = 0;
     __syncthreads();
@@ -836,6 +851,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
         const float4 rec = ordered ? prev_recs[(size_t)row * kcap + i] : KGP[(size_t)s * kcap + i];
         unsigned char f = 0;
         bool open = false;
+        int4 oc = make_int4(0, 0, 0, 0);
         const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
         if (usable && qx == qx && qy == qy && qz == qz) {
             const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);   // (rounding allowance, as grid_outlier_thread's)
@@ -862,9 +878,10 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
                     if (sweep_step_hits(rec, pr, t2f, qx, qy, qz, th, t2lo, t2hi)) f = 0;
                 }
                 open = f && (hx != lx || hy != ly || hz != lz);
+                oc = make_int4(ox, oy, oz, (hx != lx ? 1 : 0) | (hy != ly ? 2 : 0) | (hz != lz ? 4 : 0) | (ox == lx ? 8 : 0) | (oy == ly ? 16 : 0) | (oz == lz ? 32 : 0));
             }
         }
-        if (open) open_q[atomicAdd(&n_open, 1)] = rec;
+        if (open) { const int slot = atomicAdd(&n_open, 1); open_q[slot] = rec; open_c[slot] = oc; }
         else flags[(size_t)s * kcap + __float_as_int(rec.w)] = f;
     }
     __syncthreads();
@@ -874,23 +891,22 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
     if ((int)threadIdx.x < n_open) {
 #endif
         const float4 rec = open_q[threadIdx.x];
+        const int4 oc = open_c[threadIdx.x];
         const double qx = (double)rec.x, qy = (double)rec.y, qz = (double)rec.z;
-        const double rr = th + 1e-9 * h + 1e-12 * (fabs(qx) + fabs(qy) + fabs(qz) + th);
-        const int lx = sweep_cell(qx - rr, inv_hf), hx = sweep_cell(qx + rr, inv_hf);
-        const int ly = sweep_cell(qy - rr, inv_hf), hy = sweep_cell(qy + rr, inv_hf);
-        const int lz = sweep_cell(qz - rr, inv_hf), hz = sweep_cell(qz + rr, inv_hf);
-        const int ox = sweep_cell(rec.x, inv_hf), oy = sweep_cell(rec.y, inv_hf), oz = sweep_cell(rec.z, inv_hf);
-        const int nx = hx - lx + 1, ny = hy - ly + 1, nz = hz - lz + 1, nc = nx * ny * nz;
+        // the other cell of an axis: the next one up or down (phase A's cube [l, h] with h - l <= 1 around the own cell)
+        const int ax = oc.x + ((oc.w & 8) ? 1 : -1), ay = oc.y + ((oc.w & 16) ? 1 : -1), az = oc.z + ((oc.w & 32) ? 1 : -1);
+        const int mask = oc.w & 7;
         int s0[8], s1[8];
+        // cells that share a FACE with the own cell first (one bit), then edges, then the corner: an inlier's neighbour is most often there
+        constexpr int kOrder[8] = {0, 1, 2, 4, 3, 5, 6, 7};
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {   // cell k: bit set = the OTHER cell of that axis; the table entries fetched together
-            s0[k] = s1[k] = 0;
-            if (k < nc) {
-                const int kx = k % nx, ky = (k / nx) % ny, kz = k / (nx * ny);
-                const int cx = kx ? lx + hx - ox : ox, cy = ky ? ly + hy - oy : oy, cz = kz ? lz + hz - oz : oz;
-                const int b = sweep_bucket(cx, cy, cz, nb);
-                s0[k] = tab[b];
-                s1[k] = tab[b + 1];
+        for (int j = 1; j < 8; ++j) {   // bit a of kk set = the OTHER cell of axis a; the table entries fetched together
+            const int kk = kOrder[j];
+            s0[j] = s1[j] = 0;
+            if ((kk & ~mask) == 0) {
+                const int b = sweep_bucket((kk & 1) ? ax : oc.x, (kk & 2) ? ay : oc.y, (kk & 4) ? az : oc.z, nb);
+                s0[j] = tab[b];
+                s1[j] = tab[b + 1];
             }
         }
         unsigned char f = 1;
