@@ -470,9 +470,15 @@ __device__ __forceinline__ double grid_wave_min_f64(double v) {
 // round were measured slower: the BASELINE clouds are dense enough that ring r + 1 is rarely needed).  Once k
 // candidates are known, a ring only visits the cells that the ball of the current k-th distance reaches: a row
 // (iy, iz) is skipped when its slab is farther than that, and its run of cells is clipped to the ball's x extent.
+#ifdef AMK_KNN_COUNT   // diagnostics build: queries, item batches, candidate batches, insertions, candidates (tools/experiments/knn_counts.py)
+__device__ unsigned long long g_knn_cnt[8];
+#endif
 __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double qy, double qz, int k, double &ld,
                                          int &li, int &lpos, GridWaveLds *ws) {
     const int lane = threadIdx.x & 63;
+#ifdef AMK_KNN_COUNT
+    unsigned c_items = 0, c_batches = 0, c_ins = 0, c_cand = 0, c_rings = 0;
+#endif
     const double b[3] = {gs.gp[0], gs.gp[1], gs.gp[2]};
     const double h = gs.gp[3], inv_h = gs.gp[4];
     const int g[3] = {(int)gs.gp[5], (int)gs.gp[6], (int)gs.gp[7]};
@@ -545,6 +551,9 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     }
                 }
             }
+#ifdef AMK_KNN_COUNT
+            ++c_items;
+#endif
             if (__ballot(lA + lB > 0) == 0) continue;  // nothing but empty buckets in these rows
             // flatten the <= 128 ranges into one index space so that every lane gets a point
             const int incl = wave_incl_scan_i32(lA + lB);
@@ -574,7 +583,13 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             double d, dn;
             int ic, icn, ip, ipn;
             fetch(lane, d, ic, ip);
+#ifdef AMK_KNN_COUNT
+            c_cand += total;
+#endif
             for (int t0 = 0; t0 < total; t0 += 64) {
+#ifdef AMK_KNN_COUNT
+                ++c_batches;
+#endif
                 if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn, ipn);  // next batch in flight while this one is merged
                 // candidates that beat (or tie) the current k-th best enter BEST FIRST: the k nearest of a batch tighten tau as
                 // fast as it can be tightened, so a batch costs about as many insertions as it has entries that end up in the
@@ -595,6 +610,9 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     // rank of the candidate in (distance, index) order among the kept entries
                     const bool lt = (lane < k) && (ld < dc || (ld == dc && li < icc));
                     const int pos = __popcll(__ballot(lt));
+#ifdef AMK_KNN_COUNT
+                    ++c_ins;
+#endif
                     if (pos < k && dc < DBL_MAX) {
                         const double up_d = wave_shr1_f64(ld);
                         const int up_i = wave_shr1_i32(li), up_p = wave_shr1_i32(lpos);
@@ -633,7 +651,16 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
         if (r >= rmax) break;
         rp = r;
         r = r + 1;
+#ifdef AMK_KNN_COUNT
+        ++c_rings;
+#endif
     }
+#ifdef AMK_KNN_COUNT
+    if (lane == 0) {
+        atomicAdd(&g_knn_cnt[0], 1ull); atomicAdd(&g_knn_cnt[1], (unsigned long long)c_items); atomicAdd(&g_knn_cnt[2], (unsigned long long)c_batches);
+        atomicAdd(&g_knn_cnt[3], (unsigned long long)c_ins); atomicAdd(&g_knn_cnt[4], (unsigned long long)c_cand); atomicAdd(&g_knn_cnt[5], (unsigned long long)c_rings);
+    }
+#endif
 }
 
 // 1-NN squared distance of q, one THREAD per query (the n-queries-on-n-points keyframe sweep,

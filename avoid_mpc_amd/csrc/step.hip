@@ -452,3 +452,12 @@ extern "C" int amk_step_batch_host(amk_kd *obstacle, amk_kd *edge, amk_mpc *mpc,
     AMK_HIP(hipMemcpy(h_flags, mpc->sh_flags.p, sizeof(int) * S * 4, hipMemcpyDeviceToHost));
     return AMK_OK;
 }
+
+#ifdef AMK_KNN_COUNT
+extern "C" int amk__knn_counters(unsigned long long *h8, int reset) {   // diagnostics build only: step.hip's copy of grid_knn's counters
+    if (hipDeviceSynchronize() != hipSuccess) return AMK_ERR_HIP;
+    if (hipMemcpyFromSymbol(h8, HIP_SYMBOL(amk::g_knn_cnt), sizeof(unsigned long long) * 8) != hipSuccess) return AMK_ERR_HIP;
+    if (reset) { unsigned long long z[8] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(amk::g_knn_cnt), z, sizeof z) != hipSuccess) return AMK_ERR_HIP; }
+    return AMK_OK;
+}
+#endif
