@@ -228,6 +228,7 @@ def load():
     }
     sig["amk__kd_set_mode"] = (i, [vp, i])  # internal: 0 bucketed index, 1 streaming scan
     sig["amk__sweep_set_target"] = (None, [i])  # internal (tests, A/B): the pool's sweep against 1 a fine hashed grid of the current frame (default), 0 the frame's own index
+    sig["amk__sweep_set_order"] = (None, [i])   # internal (tests, A/B): 1 keyframe points in last sweep's grid order where it is theirs (default), 0 record order
     for name, (res, args) in sig.items():
         fn = getattr(lib, name, None)
         if fn is None:

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_kernel(amk::GridPtrs cur, c
 static int g_sweep_target = [] { const char *e = getenv("AMK_SWEEP_TARGET"); return e ? atoi(e) : 1; }();   // 1: the pool sweeps against a fine hashed grid of the current frame (below); 0: against the frame's own index (A/B, tests)
 extern "C" void amk__sweep_set_target(int v) { g_sweep_target = v; }
 static int g_sweep_order = [] { const char *e = getenv("AMK_SWEEP_ORDER"); return e ? atoi(e) : 1; }();   // 1: keyframe points in the order of last sweep's grid where it is theirs; 0: always in record order (A/B)
+extern "C" void amk__sweep_set_order(int v) { g_sweep_order = v; }
 
 // one block per scene: count the outliers; with >= th_count of them compact the keyframe's planes in place
 // (order preserved: the write cursor never passes the read cursor) and refresh size / bbox / max|coordinate|

@@ -64,3 +64,39 @@ def test_sweep_matches_oracle(tie_order):
             assert np.array_equal(res["indices"][s, q, :cnt].cpu().numpy(), ia)
             assert np.array_equal(res["sqdist"][s, q, :cnt].cpu().numpy(), da)
     assert reb[4] == 0 and outl[4] == 0 and reb[5] == 0 and reb[0] == 1
+
+
+def test_sweep_and_rebuild_at_ragged_sizes():
+    """The compaction kernel takes four consecutive elements per thread and trip (round 6): keyframes of 1 ... 4099 points -- below one
+    vector, not a multiple of four, around the 2048-element trip -- with every third point an outlier, rebuilt
+    from their outliers in order (th_count 1): outlier counts, rebuilt flags, sizes and the answers of the rebuilt keyframe == oracle."""
+    import torch
+    from avoid_mpc_amd.host import KdBatch
+    sizes = [1, 2, 3, 4, 5, 7, 13, 255, 256, 257, 1023, 1025, 2047, 2048, 2049, 4099]
+    S = len(sizes)
+    rng = np.random.default_rng(9)
+    cur = synth.make_cloud(6000, 911)[0]
+    nk = max(sizes)
+    kb = np.zeros((S, nk, 3), np.float32); kn = np.array(sizes, np.int32)
+    ks = []
+    for s, n in enumerate(sizes):
+        k = cur[rng.integers(0, len(cur), n)].copy() + rng.normal(0, 0.005, (n, 3)).astype(np.float32)   # inliers: next to a current point
+        k[::3, 0] -= 9.0                                                                                   # every third point: far away
+        kb[s, :n] = k; ks.append(k)
+    kd_k, kd_c = KdBatch(S, nk), KdBatch(S, len(cur))
+    kd_k.build(torch.from_numpy(kb).cuda(), torch.from_numpy(kn).cuda())
+    kd_c.build(torch.from_numpy(np.repeat(cur[None], S, 0).copy()).cuda())
+    outl, reb = kd_k.keyframe_sweep(kd_c, 0.1, 1)
+    torch.cuda.synchronize()
+    outl, reb, got = outl.cpu().numpy(), reb.cpu().numpy(), kd_k.sizes()
+    qs = np.stack([rng.uniform(-9, 20, (S, 6)), rng.uniform(-6, 6, (S, 6)), rng.uniform(0, 4, (S, 6))], -1)
+    res = kd_k.search(torch.from_numpy(qs).cuda(), 3)
+    torch.cuda.synchronize()
+    tc = _oracle.kd_oracle(cur)
+    for s, k in enumerate(ks):
+        tk = _oracle.kd_oracle(k)
+        r, n_out = tk.keyframe_sweep(tc, 0.1, 1)
+        assert outl[s] == n_out and reb[s] == r and got[s] == tk.size(), (sizes[s], outl[s], n_out, reb[s], r, got[s], tk.size())
+        for q in range(6):
+            ia, da, _ = tk.search(qs[s, q], 3)
+            assert np.array_equal(res["sqdist"][s, q].cpu().numpy()[:len(da)].view(np.int64), da.view(np.int64)), (sizes[s], q)

@@ -38,16 +38,20 @@ def _scripted_frames(seed, prm, periods, world_kw):
     return world, xs
 
 
-@pytest.mark.parametrize("max_frames,th_count,wide,target", [(3, 10, 0, 1), (6, 10, 1, 1), (12, 40, 0, 0), (100, 10, 0, 1)])
-def test_map_follows_the_reference_list(max_frames, th_count, wide, target, torch_cuda):
+@pytest.mark.parametrize("max_frames,th_count,wide,target,order", [(3, 10, 0, 1, 1), (6, 10, 1, 1, 1), (12, 40, 0, 0, 1), (100, 10, 0, 1, 1),
+                                                                   (6, 10, 0, 1, 0), (6, 1300, 0, 1, 1)])
+def test_map_follows_the_reference_list(max_frames, th_count, wide, target, order, torch_cuda):
     """(wide = 1: the merge of maps with more than 1024 (frame, neighbour) candidates -- candidates re-read every round -- forced
     on a small map; max_frames = 100: the yaml's own max_frame_count, mpc_parameters.yaml:73; target = 0: the sweep against the
-    current frame's own index instead of its fine hashed grid, the default)"""
+    current frame's own index instead of its fine hashed grid, the default; order = 0: the hashed sweep with the keyframe's points always in
+    record order -- round 6's default, 1, takes them in the order of last sweep's grid whenever the keyframe IS last sweep's frame; th_count 1300:
+    only some sweeps rebuild, so the newest keyframe stays for several periods and the rows alternate between the two orders)"""
     torch = torch_cuda
     from avoid_mpc_amd import capi
     from avoid_mpc_amd.host import KfMap, MpcBatch
     capi.load().amk__frames_force_wide(int(wide))
     capi.load().amk__sweep_set_target(int(target))
+    capi.load().amk__sweep_set_order(int(order))
     prm, _ = _flight.make_prm("C1")
     c = _flight.DEPTH_CAM
     S, P = 6, 36
@@ -65,6 +69,7 @@ def test_map_follows_the_reference_list(max_frames, th_count, wide, target, torc
     gcam = capi.FrameCamera(*cam[:5], int(cam[5]), int(cam[6]))
     dev = torch.device("cuda")
     seen_pop = seen_keep = seen_multi = False
+    sweeps_rebuilt = sweeps_kept = 0
     for t in range(P):
         clouds = np.zeros((S, cap, 3), np.float32); edges = np.zeros((S, cap, 3), np.float32)
         cn = np.zeros(S, np.int32); en = np.zeros(S, np.int32); Twc = np.zeros((S, 4, 4))
@@ -97,6 +102,8 @@ def test_map_follows_the_reference_list(max_frames, th_count, wide, target, torc
             assert list(st["frame_sizes"][s][:len(sizes)]) == sizes, (t, s, st["frame_sizes"][s], sizes)
             assert (st["frame_sizes"][s][len(sizes):] == -1).all()
             assert st["last_outliers"][s] == max(omaps[s].last_outliers, 0), (t, s)
+            if omaps[s].last_outliers > 0:
+                sweeps_rebuilt += int(omaps[s].last_outliers >= th_count); sweeps_kept += int(omaps[s].last_outliers < th_count)
             seen_multi = seen_multi or len(sizes) >= 3
         if t > 0:
             seen_pop = seen_pop or (st["n_keyframes"] < prev_nk).any() or (st["n_keyframes"] == prev_nk).any()
@@ -112,11 +119,15 @@ def test_map_follows_the_reference_list(max_frames, th_count, wide, target, torc
             if np.array_equal(gf[s], r["flags"]):
                 assert np.abs(gu[s] - r["u"]).max() <= 1e-6 and np.abs(gr[s] - refs[s]).max() <= 1e-6, (t, s)
     assert seen_multi, "the scripted flight never had three query frames: the test did not exercise the merge"
+    if th_count >= 100:   # the mixed case: both kinds of sweep happened (a keyframe that stays is swept in record order, a fresh one in grid order)
+        assert sweeps_rebuilt > 0 and sweeps_kept > 0, (sweeps_rebuilt, sweeps_kept)
+    print(f"sweeps that rebuilt their keyframe {sweeps_rebuilt}, that kept it {sweeps_kept}")
     nk_final = [len(m.kfs) for m in omaps]
     print(f"max_frame_count {max_frames}: keyframes at the end {nk_final}, query frames {[len(m.frames()) for m in omaps]}")
     gmap.close()
     capi.load().amk__frames_force_wide(0)
     capi.load().amk__sweep_set_target(1)
+    capi.load().amk__sweep_set_order(1)
 
 
 def test_argument_errors(torch_cuda):
