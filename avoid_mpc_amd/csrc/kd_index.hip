@@ -814,7 +814,11 @@ __device__ __forceinline__ bool sweep_step_hits(const float4 &q, const float4 (&
 // then kSweepStepH records of a run per step.  A query whose cube would span more than two cells along an axis (coordinates so large
 // that the rounding allowance exceeds the cell) reads every point of the grid instead.
 constexpr int kSweepStepH = 4;   // (= the array bound of sweep_step_hits)
-__global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__restrict__ cur_sizes,
+#ifndef AMK_SWEEP_MARK_THREADS
+#define AMK_SWEEP_MARK_THREADS 256
+#endif
+constexpr int kSweepMarkThreads = AMK_SWEEP_MARK_THREADS;
+__global__ __launch_bounds__(kSweepMarkThreads) void kd_sweep_mark_hash_kernel(const int *__restrict__ cur_sizes,
                                                                  const float4 *__restrict__ trecs, const int *__restrict__ table,
                                                                  double inv_h, int nb, const float4 *__restrict__ KGP, int kcap,
                                                                  const int *__restrict__ ksizes, double th,
@@ -835,8 +839,8 @@ __global__ __launch_bounds__(256) void kd_sweep_mark_hash_kernel(const int *__re
     // thread throughout made nearly every wavefront run at its slowest lane's pace (an outlier scans all 8 cells: a real pair of frames with
     // 14 % outliers cost 90 % of an all-outlier pair); after the compaction the wavefronts of phase B are full of open queries and the others
     // have retired.  Same cells, same screen, same exact test: same flags.
-    __shared__ float4 open_q[256];
-    __shared__ int4 open_c[256];   // the open query's own cell and, per axis, which other cell its cube reaches (bits 0-2: has one, 3-5: it is the next one up)
+    __shared__ float4 open_q[kSweepMarkThreads];
+    __shared__ int4 open_c[kSweepMarkThreads];   // the open query's own cell and, per axis, which other cell its cube reaches (bits 0-2: has one, 3-5: it is the next one up)
     __shared__ int n_open;
     if (threadIdx.x == 0) n_open = 0;
     __syncthreads();
@@ -999,7 +1003,7 @@ int kd_sweep_mapped(amk_kd *pool, int n_rows, const int *d_kf_list, const int *d
         hipLaunchKernelGGL(kd_sweep_hash_build_kernel, dim3(n_rows), dim3(kSweepBuildThreads), sizeof(int) * (nb + kSweepBuildThreads / 64) + extra_lds,
                            stream, pool->gpt.p, pool->cap, pool->size.p, inv_h, nb, recs_g, tab_g, d_kf_list, d_cur_list,
                            src_g, src_p, pool->flags.p);
-        hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + 255) / 256, n_rows), dim3(256), 0, stream, pool->size.p,
+        hipLaunchKernelGGL(kd_sweep_mark_hash_kernel, dim3((pool->max_points + kSweepMarkThreads - 1) / kSweepMarkThreads, n_rows), dim3(kSweepMarkThreads), 0, stream, pool->size.p,
                            recs_g, tab_g, inv_h, nb, pool->gpt.p, pool->cap, pool->size.p, th_dist, pool->flags.p, d_kf_list, d_cur_list,
                            recs_p, tab_p, g_sweep_order ? src_p : pool->sw_src.p + (size_t)2 * n_rows);
     }
