@@ -961,6 +961,34 @@ int kd_build_mapped(amk_kd *obs_pool, amk_kd *edge_pool, int n_in, const float *
     return AMK_OK;
 }
 
+// The same for the G frames of a pipeline gang in ONE launch (grid.y = 2 G trees): frame f's scenes are built into the pool scenes
+// d_out_scene[f * frame_scenes + s].  (One add_vertex per gang position was 2 G launches per period: the map's periods at the
+// reference's 3072-point frames are bound by their launch count.)
+int kd_build_mapped_gang(amk_kd *obs_pool, amk_kd *edge_pool, int n_frames, int frame_scenes, const float *const *d_xyz,
+                         const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
+                         const int *d_out_scene, hipStream_t stream) {
+    if (!obs_pool || !edge_pool || n_frames < 1 || n_frames > AMK_PIPELINE_MAX_GANG || frame_scenes < 1 || !d_out_scene || point_stride < 3)
+        return AMK_ERR_INVALID_ARG;
+    const int st = pool_planes(obs_pool);
+    if (st != AMK_OK) return st;
+    BuildArgs2 args{};
+    for (int f = 0; f < n_frames; ++f) {
+        if (!d_xyz[f] || !d_edge_xyz[f]) return AMK_ERR_INVALID_ARG;
+        BuildArgs a = build_args(obs_pool, d_xyz[f], point_stride, (long long)obs_pool->max_points * point_stride, d_counts[f]);
+        BuildArgs b = build_args(edge_pool, d_edge_xyz[f], point_stride, (long long)edge_pool->max_points * point_stride, d_edge_counts[f]);
+        a.out_scene = b.out_scene = d_out_scene + (size_t)f * frame_scenes;
+        a.soa_x = obs_pool->x.p; a.soa_y = obs_pool->y.p; a.soa_z = obs_pool->z.p;
+        args.t[2 * f] = a; args.t[2 * f + 1] = b;
+    }
+    {
+        amk::TimedLaunch tg(amk::KC_GRID, stream);
+        hipLaunchKernelGGL(kd_build_kernel, dim3(frame_scenes, 2 * n_frames), dim3(kCompactThreads), 0, stream, args);
+    }
+    AMK_HIP(hipGetLastError());
+    for (amk_kd *kd : {obs_pool, edge_pool}) { kd->soa_valid = 0; kd->ex_valid = 0; kd->async_pending = 1; }
+    return AMK_OK;
+}
+
 // KeyframeThreadWorker's sweep (FrameKDMap.cpp:463-485) for n_rows scenes of a map: row r sweeps the points of pool scene
 // d_kf_list[r] (the newest keyframe) against pool scene d_cur_list[r] (the current frame); with >= th_count outliers the
 // keyframe's planes are compacted to them in place and its index is rebuilt.  d_outliers / d_rebuilt: [n_rows].

@@ -63,16 +63,12 @@ __global__ __launch_bounds__(256) void kf_init_kernel(int S, int P, int *__restr
 
 // AddVertex, bookkeeping half: which physical slot the scene's new current frame is built into.  The old current slot is
 // reused unless the deque holds it (then the trees live on as a keyframe and the lowest free slot is taken).
-__global__ __launch_bounds__(256) void kf_alloc_kernel(int S, int P, int first, int n, const int *__restrict__ counts,
-                                                       const double *__restrict__ Twc_in, int *__restrict__ cur_slot,
-                                                       const int *__restrict__ kf_n, const int *__restrict__ kf_slots,
-                                                       int *__restrict__ need, double *__restrict__ Twc, int *__restrict__ out_scene,
-                                                       int *__restrict__ fmap) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int s = first + i;
-    if (counts && counts[i] <= 0) {   // ProcessDepth left no obstacle point: AddVertex returns before anything changes (:39-41)
-        out_scene[i] = -1;
+__device__ __forceinline__ void kf_alloc_scene(int S, int P, int s, bool has_frame, const double *__restrict__ Twc_in16,
+                                               int *__restrict__ cur_slot, const int *__restrict__ kf_n, const int *__restrict__ kf_slots,
+                                               int *__restrict__ need, double *__restrict__ Twc, int *__restrict__ out_scene_i,
+                                               int *__restrict__ fmap) {
+    if (!has_frame) {   // ProcessDepth left no obstacle point: AddVertex returns before anything changes (:39-41)
+        *out_scene_i = -1;
         return;
     }
     const int *dq = kf_slots + (size_t)s * P;
@@ -88,11 +84,32 @@ __global__ __launch_bounds__(256) void kf_alloc_kernel(int S, int P, int first, 
         }
     }
     cur_slot[s] = slot;           // (slot < P: the deque holds at most P - 1 slots)
-    out_scene[i] = slot * S + s;
+    *out_scene_i = slot * S + s;
     fmap[s] = slot * S + s;       // SetCurPtCloud -> UpdateQueryVector (:53-58): the query vector's first frame is the new one at once
                                   // (the keyframe rows do not change here: the deque is the worker's, amk_kfmap_update)
     need[s] = 1;                  // mbNeedProcessPtCloud = true (:51)
-    for (int e = 0; e < 16; ++e) Twc[(size_t)s * 16 + e] = Twc_in[(size_t)i * 16 + e];   // mCurFrame.Twc = mat4Twb * mParamTbc (:50)
+    for (int e = 0; e < 16; ++e) Twc[(size_t)s * 16 + e] = Twc_in16[e];   // mCurFrame.Twc = mat4Twb * mParamTbc (:50)
+}
+__global__ __launch_bounds__(256) void kf_alloc_kernel(int S, int P, int first, int n, const int *__restrict__ counts,
+                                                       const double *__restrict__ Twc_in, int *__restrict__ cur_slot,
+                                                       const int *__restrict__ kf_n, const int *__restrict__ kf_slots,
+                                                       int *__restrict__ need, double *__restrict__ Twc, int *__restrict__ out_scene,
+                                                       int *__restrict__ fmap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    kf_alloc_scene(S, P, first + i, !(counts && counts[i] <= 0), Twc_in + (size_t)i * 16, cur_slot, kf_n, kf_slots, need, Twc, out_scene + i, fmap);
+}
+// the same for the G frames of a pipeline gang at once: frame f holds the map's scenes [f * frame_scenes, (f + 1) * frame_scenes)
+struct KfGangIn { const int *counts[AMK_PIPELINE_MAX_GANG]; const double *twc[AMK_PIPELINE_MAX_GANG]; };
+__global__ __launch_bounds__(256) void kf_alloc_gang_kernel(int S, int P, int n_frames, int frame_scenes, KfGangIn in,
+                                                            int *__restrict__ cur_slot, const int *__restrict__ kf_n,
+                                                            const int *__restrict__ kf_slots, int *__restrict__ need,
+                                                            double *__restrict__ Twc, int *__restrict__ out_scene, int *__restrict__ fmap) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_frames * frame_scenes) return;
+    const int f = i / frame_scenes, j = i - f * frame_scenes;
+    const int *counts = in.counts[f];
+    kf_alloc_scene(S, P, i, !(counts && counts[j] <= 0), in.twc[f] + (size_t)j * 16, cur_slot, kf_n, kf_slots, need, Twc, out_scene + i, fmap);
 }
 
 // KeyframeThreadWorker's body up to the sweep (:443-462), one wavefront per scene.
@@ -303,6 +320,31 @@ int amk_kfmap_add_vertex(amk_kfmap *m, int first_scene, int n_scenes, const floa
     return amk::kd_build_mapped(m->obs, m->edge, n_scenes, d_xyz, d_counts, d_edge_xyz, d_edge_counts, point_stride,
                                 m->out_scene.p + first_scene, stream);
 }
+
+}  // extern "C"
+namespace amk {
+// AddVertex for the G frames of a pipeline gang (frame f = the map's scenes [f * frame_scenes, (f + 1) * frame_scenes)): one bookkeeping launch
+// and one build launch for all of them (amk_kfmap_add_vertex per position: 2 G launches)
+int kfmap_add_vertex_gang(amk_kfmap *m, int n_frames, int frame_scenes, const float *const *d_xyz, const int *const *d_counts,
+                          const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride, const double *const *d_Twc,
+                          hipStream_t stream) {
+    if (!m || n_frames < 1 || n_frames > AMK_PIPELINE_MAX_GANG || frame_scenes < 1 || n_frames * frame_scenes > m->S ||
+        (point_stride != 3 && point_stride != 4))
+        return AMK_ERR_INVALID_ARG;
+    KfGangIn in{};
+    for (int f = 0; f < n_frames; ++f) {
+        if (!d_xyz[f] || !d_edge_xyz[f] || !d_Twc[f]) return AMK_ERR_INVALID_ARG;
+        in.counts[f] = d_counts[f]; in.twc[f] = d_Twc[f];
+    }
+    const int n = n_frames * frame_scenes;
+    hipLaunchKernelGGL(kf_alloc_gang_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, m->S, m->P, n_frames, frame_scenes, in, m->cur_slot.p,
+                       m->kf_n.p, m->kf_slots.p, m->need.p, m->Twc.p, m->out_scene.p, m->fmap.p);
+    AMK_HIP(hipGetLastError());
+    return kd_build_mapped_gang(m->obs, m->edge, n_frames, frame_scenes, d_xyz, d_counts, d_edge_xyz, d_edge_counts, point_stride,
+                                m->out_scene.p, stream);
+}
+}  // namespace amk
+extern "C" {
 
 int amk_kfmap_update(amk_kfmap *m, void *stream_) {
     if (!m) return AMK_ERR_INVALID_ARG;

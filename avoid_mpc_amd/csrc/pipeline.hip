@@ -22,6 +22,12 @@
 #include <cstring>
 #include <vector>
 
+namespace amk {
+int kfmap_add_vertex_gang(amk_kfmap *m, int n_frames, int frame_scenes, const float *const *d_xyz, const int *const *d_counts,
+                          const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride, const double *const *d_Twc,
+                          hipStream_t stream);   // kfmap.hip
+}
+
 struct amk_pipeline {
     amk_pipeline_config cfg;
     struct Staged {  // a frame of the open gang
@@ -336,14 +342,15 @@ int launch_gang(amk_pipeline *p, amk_pipeline::Slot &s) {
     const double t_h0 = trace_host ? now_us() : 0.0;
     double t_h1 = 0.0, t_h2 = 0.0;
     if (s.map) {   // ... into the slot's keyframe map: the scenes' own physical slots, mCurFrame.Twc, then KeyframeThreadWorker's body
+        const double *twcs[AMK_PIPELINE_MAX_GANG] = {};
         for (int g = 0; g < filled; ++g) {
             const amk_pipeline::Staged &f = s.open[g];
-            const double *twc = f.depth ? s.Twc.p + (size_t)g * S * 16 : f.Twc_cur;
-            if (!twc) return AMK_ERR_INVALID_ARG;   // (submit() checked)
-
-            rc = amk_kfmap_add_vertex(s.map, g * S, S, cl[g], cc[g], ed[g], ec[g], s.point_stride, twc, st);
-            if (rc != AMK_OK) return rc;
+            twcs[g] = f.depth ? s.Twc.p + (size_t)g * S * 16 : f.Twc_cur;
+            if (!twcs[g]) return AMK_ERR_INVALID_ARG;   // (submit() checked)
         }
+        // AddVertex of every position of the gang: one bookkeeping launch + one build launch (both trees of all frames)
+        rc = amk::kfmap_add_vertex_gang(s.map, filled, S, cl, cc, ed, ec, s.point_stride, twcs, st);
+        if (rc != AMK_OK) return rc;
         if (trace_host) t_h1 = now_us();
         rc = amk_kfmap_update(s.map, st);
         if (trace_host) t_h2 = now_us();
