@@ -79,6 +79,7 @@ int kd_build_gang(amk_kd *obstacle, amk_kd *edge, int n_frames, int frame_scenes
 // kd_index.hip, for the keyframe map (kfmap.hip): builds and sweeps on a POOL handle (scene = physical slot * S + scene)
 int kd_build_mapped(amk_kd *obs_pool, amk_kd *edge_pool, int n_in, const float *d_xyz, const int *d_counts, const float *d_edge_xyz,
                     const int *d_edge_counts, int point_stride, const int *d_out_scene, hipStream_t stream);
+int kd_pool_reserve(amk_kd *pool, int n_rows);
 int kd_build_mapped_gang(amk_kd *obs_pool, amk_kd *edge_pool, int n_frames, int frame_scenes, const float *const *d_xyz,
                          const int *const *d_counts, const float *const *d_edge_xyz, const int *const *d_edge_counts, int point_stride,
                          const int *d_out_scene, hipStream_t stream);

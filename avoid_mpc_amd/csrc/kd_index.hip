@@ -938,6 +938,25 @@ static int pool_planes(amk_kd *kd) {   // the index-ordered planes of a pool han
     return AMK_OK;
 }
 
+// Everything a map's obstacle pool will ever allocate, at once (amk_kfmap_create): the index-ordered planes, the sweep's outlier flags and
+// its two generations of hashed grids -- so that a pool that does not fit fails when the map is CREATED (amk_kfmap_pool_bytes says what it
+// needs), not at some later submit when the first sweep runs.
+int kd_pool_reserve(amk_kd *pool, int n_rows) {
+    if (!pool || n_rows < 1) return AMK_ERR_INVALID_ARG;
+    const int st = pool_planes(pool);
+    if (st != AMK_OK) return st;
+    if (!pool->flags.p) AMK_HIP(pool->flags.alloc((size_t)pool->n_scenes * pool->cap));
+    if (pool->max_points > 0 && pool->sw_rows < n_rows) {
+        const int nb = sweep_buckets(pool->max_points);
+        AMK_HIP(pool->sw_gpt.alloc((size_t)2 * n_rows * pool->cap));
+        AMK_HIP(pool->sw_cs.alloc((size_t)2 * n_rows * (nb + 1)));
+        AMK_HIP(pool->sw_src.alloc((size_t)3 * n_rows));
+        AMK_HIP(hipMemset(pool->sw_src.p, 0xff, sizeof(int) * 3 * (size_t)n_rows));
+        pool->sw_rows = n_rows;
+    }
+    return AMK_OK;
+}
+
 // FrameKDMap::AddVertex's two InitializeNew calls (FrameKDMap.cpp:44-47) for n_in scenes, each into the pool scene
 // d_out_scene[s] (< 0: that scene gets no new frame); the obstacle pool's planes are written along.
 int kd_build_mapped(amk_kd *obs_pool, amk_kd *edge_pool, int n_in, const float *d_xyz, const int *d_counts,

@@ -263,6 +263,7 @@ int amk_kfmap_create(int n_scenes, int max_points, int max_edge_points, const am
     if (pool > 0x3fffffff) st = AMK_ERR_UNSUPPORTED;
     if (st == AMK_OK) st = amk_kd_create((int)pool, max_points, &m->obs);
     if (st == AMK_OK) st = amk_kd_create((int)pool, max_edge_points, &m->edge);
+    if (st == AMK_OK) st = amk::kd_pool_reserve(m->obs, n_scenes);   // planes, flags, the sweep's grids: everything now, so that memory runs out HERE
     hipError_t e = hipSuccess;
     const size_t S = n_scenes;
     if (st == AMK_OK &&

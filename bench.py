@@ -476,7 +476,7 @@ def main():
     ap.add_argument("--config", default=None, choices=("yaml",),
                     help="yaml: the reference's own configuration (AM/config/mpc_parameters.yaml: 640 x 480 / 10 sensor = 3072-point "
                          "frames, T = 1.0 -> N = 30, nearest_point_num = 3; with --workload flight --keyframes 100 its default regime) "
-                         "-- shorthand for --points 3072 --T 1.0 --K 3, 12 slots x 4 frames per launch, 120 periods unless given")
+                         "-- shorthand for --points 3072 --T 1.0 --K 3, 16 slots x 4 frames per launch, 120 periods unless given")
     ap.add_argument("--points", type=int, default=50000)
     ap.add_argument("--T", type=float, default=0.66)
     ap.add_argument("--K", type=int, default=8)
@@ -524,7 +524,7 @@ def main():
     if args.config == "yaml":
         args.points, args.T, args.K = 3072, 1.0, 3
         if args.workload == "flight":
-            if "--streams" not in sys.argv: args.streams = 12
+            if "--streams" not in sys.argv: args.streams = 16
             if "--gang" not in sys.argv: args.gang = 4
             if args.periods == 0 and args.steps == 2048: args.periods = 120
 

@@ -52,9 +52,9 @@ if not PROFILES_ONLY:
                "under_rocprofv3_kernel_trace": last_json(os.path.join(src, "bench_under_rocprof.json")),
                "flight_workload_10x2_same_box": last_json(os.path.join(src, "bench_flight_10x2.json")),
                "flight_workload_keyframes_3_10x2": last_json(os.path.join(src, "bench_flight_keyframes3.json")),
-               "flight_yaml_config_keyframes_100_12x4": last_json(os.path.join(src, "bench_flight_yaml_keyframes100.json")),
-               "flight_yaml_config_keyframes_100_16x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_keyframes100_16x4.json")),
-               "flight_yaml_config_single_frame_12x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_single_frame.json")),
+               "flight_yaml_config_keyframes_100_16x4": last_json(os.path.join(src, "bench_flight_yaml_keyframes100.json")),
+               "flight_yaml_config_keyframes_100_12x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_keyframes100_12x4.json")),
+               "flight_yaml_config_single_frame_16x4_same_box": last_json(os.path.join(src, "bench_flight_yaml_single_frame.json")),
                "solve_budget_16_same_box": last_json(os.path.join(src, "bench_budget16.json")),
                "solve_budget_16_20_steps_same_box": last_json(os.path.join(src, "bench_budget16_20steps.json"))},
               open(os.path.join(dst, "r06_bench.json"), "w"), indent=1)

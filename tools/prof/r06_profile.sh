@@ -44,7 +44,7 @@ python bench.py --workload flight --streams 10 --gang 2 > $OUT/bench_flight_10x2
 python bench.py --workload flight --streams 10 --gang 2 --keyframes 3 > $OUT/bench_flight_keyframes3.json 2>> $OUT/bench.err
 # 8b. the reference's own configuration (3072-point frames, N = 30, K = 3), with its default keyframe map (max_frame_count 100) and without
 python bench.py --workload flight --config yaml --keyframes 100 > $OUT/bench_flight_yaml_keyframes100.json 2>> $OUT/bench.err
-python bench.py --workload flight --config yaml --keyframes 100 --streams 16 --no-cpu-baseline --no-parity > $OUT/bench_flight_yaml_keyframes100_16x4.json 2>> $OUT/bench.err
+python bench.py --workload flight --config yaml --keyframes 100 --streams 12 --no-cpu-baseline --no-parity > $OUT/bench_flight_yaml_keyframes100_12x4.json 2>> $OUT/bench.err
 python bench.py --workload flight --config yaml --no-cpu-baseline --no-parity > $OUT/bench_flight_yaml_single_frame.json 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt_flight_kf3 -o kt -- python bench.py --workload flight --keyframes 3 --streams 1 --gang 2 --no-parity --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
 rocprofv3 --kernel-trace --stats -d $OUT/kt_flight_yaml -o kt -- python bench.py --workload flight --config yaml --keyframes 100 --streams 1 --no-parity --no-cpu-baseline > /dev/null 2>> $OUT/bench.err
