@@ -427,8 +427,9 @@ struct GridPtrs {  // the batch: what a kernel needs to find scene s
 };
 
 struct GridWaveLds {  // per-wavefront scratch: ranges of the rows of the current shell
-    int pre[65];
-    int sA[64], lA[64], sB[64];
+    int4 item[64];   // (first candidate number, length of run A, start of run A, start of run B) of the (row, tile) item of lane o
+    int mark[65];    // slot j of the current 64-candidate window: (window number << 6 | o) of the item whose candidates begin there
+                     // (slot 64: where the lanes with nothing to announce write)
 };
 
 // DPP data movement inside the wavefront (no LDS crossbar, no s_waitcnt): whole-wave shift by one lane and the
@@ -445,6 +446,27 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);
     v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);
     return v;
+}
+
+// inclusive running maximum over the lanes, values >= 0 (the same ladder with v_max)
+__device__ __forceinline__ int wave_incl_scan_max_i32(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));
+    return v;
+}
+
+// minimum over the 64 lanes of non-negative ints (wave-uniform result): one v_min_i32 with a DPP operand per step
+__device__ __forceinline__ int grid_wave_min_i32(int v) {
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true));    // quad_perm:[1,0,3,2]
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true));    // quad_perm:[2,3,0,1]
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true));   // row_mirror
+    return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+               min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // minimum over the 64 lanes (every lane gets it): DPP inside the rows of 16, v_readlane across them
@@ -491,6 +513,8 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
     lpos = 0;
     double tau = DBL_MAX;
     int rmax = 0;
+    int win = 0;           // number of the candidate window being fetched (tags ws->mark)
+    ws->mark[lane] = 0;
 #pragma unroll
     for (int a = 0; a < 3; ++a) rmax = max(rmax, max(c[a], g[a] - 1 - c[a]));
     // rounding slack of the cell boundaries (cell_of is evaluated in fp64 on fp32 coordinates)
@@ -558,22 +582,34 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             // flatten the <= 128 ranges into one index space so that every lane gets a point
             const int incl = wave_incl_scan_i32(lA + lB);
             const int total = __builtin_amdgcn_readlane(incl, 63);
-            ws->pre[lane] = incl - (lA + lB);
-            ws->sA[lane] = sA; ws->lA[lane] = lA; ws->sB[lane] = sB;
-            auto fetch = [&](int t, double &d, int &ic, int &ip) {
+            const int mypre = incl - (lA + lB), mylen = lA + lB;
+            ws->item[lane] = make_int4(mypre, lA, sA, sB);
+            // candidate t of the window [w0, w0 + 64) belongs to the last non-empty item that begins at or before t.  Rounds 1-5
+            // found it by a six-step binary search over LDS (six dependent round trips per batch); now the items that BEGIN inside
+            // the window announce their slot, a running maximum over the lanes carries them forward, and the item that holds w0
+            // comes from a ballot.  Entries of earlier windows are told apart by the window number.
+            auto fetch = [&](int w0, double &d, int &ic, int &ip) {
+                ++win;
+                const int rel = mypre - w0;
+                // every lane stores (the silent ones into the spare slot) and the wave is fenced before it reads: with the store
+                // under a branch the compiler placed the LOAD below inside that branch as well, and only the announcing lanes got
+                // their slot (lanes communicating through LDS without a fence are a data race by the letter of the memory model)
+                ws->mark[(mylen > 0 && rel >= 0 && rel < 64) ? rel : 64] = (win << 6) | lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const unsigned long long before = __ballot(mylen > 0 && mypre <= w0);
+                const int carry = 63 - __clzll((long long)before);   // (w0 < total: some non-empty item holds w0)
+                const int mk = ws->mark[lane];
+                const int o = max(wave_incl_scan_max_i32((mk >> 6) == win ? (mk & 63) + 1 : 0) - 1, carry);
+                const int t = w0 + lane;
                 d = __builtin_nan("");
                 ic = kNoIndex;
                 ip = 0;
                 if (t < total) {
-                    int lo = 0, hi = 64;  // largest o with pre[o] <= t
-#pragma unroll
-                    for (int it = 0; it < 6; ++it) {
-                        const int mid = (lo + hi) >> 1;
-                        if (ws->pre[mid] <= t) lo = mid; else hi = mid;
-                    }
-                    const int u = t - ws->pre[lo];
-                    const int la = ws->lA[lo];
-                    const int pos = u < la ? ws->sA[lo] + u : ws->sB[lo] + (u - la);
+                    const int4 it = ws->item[o];
+                    const int u = t - it.x;
+                    const int pos = u < it.y ? it.z + u : it.w + (u - it.y);
                     const float4 p4 = gs.pt[pos];
                     d = sq_dist(qx, qy, qz, p4.x, p4.y, p4.z);
                     ic = __float_as_int(p4.w);
@@ -582,7 +618,7 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
             };
             double d, dn;
             int ic, icn, ip, ipn;
-            fetch(lane, d, ic, ip);
+            fetch(0, d, ic, ip);
 #ifdef AMK_KNN_COUNT
             c_cand += total;
 #endif
@@ -590,7 +626,7 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
 #ifdef AMK_KNN_COUNT
                 ++c_batches;
 #endif
-                if (t0 + 64 < total) fetch(t0 + 64 + lane, dn, icn, ipn);  // next batch in flight while this one is merged
+                if (t0 + 64 < total) fetch(t0 + 64, dn, icn, ipn);  // next batch in flight while this one is merged
                 // candidates that beat (or tie) the current k-th best enter BEST FIRST: the k nearest of a batch tighten tau as
                 // fast as it can be tightened, so a batch costs about as many insertions as it has entries that end up in the
                 // list (<= k) plus exact ties -- rounds 1-3 offered every lane that passed the ballot at the batch's start in
@@ -600,9 +636,13 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     const unsigned long long m = __ballot(live);
                     if (!m) break;
                     int src = __ffsll((long long)m) - 1;
-                    if (m & (m - 1)) {   // several: the nearest of them (equal distances: any; the insertion ranks by (distance, index))
-                        const double dmin = grid_wave_min_f64(live ? d : DBL_MAX);
-                        src = __ffsll((long long)__ballot(live && d == dmin)) - 1;
+                    if (m & (m - 1)) {   // several: (one of) the nearest of them by the HIGH WORD of the distance -- monotone for
+                        // doubles >= 0, one v_min_i32 per DPP step where the fp64 minimum took three instructions; candidates that
+                        // agree in those 32 bits enter in lane order (any order gives the same list: the insertion ranks by
+                        // (distance, index))
+                        const int hk = live ? __double2hiint(d) : 0x7FFFFFFF;
+                        const int hmin = grid_wave_min_i32(hk);
+                        src = __ffsll((long long)__ballot(hk == hmin)) - 1;
                     }
                     const double dc = readlane_f64(d, src);
                     const int icc = __builtin_amdgcn_readlane(ic, src);
