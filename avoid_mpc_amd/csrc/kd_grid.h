@@ -648,7 +648,8 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     const int icc = __builtin_amdgcn_readlane(ic, src);
                     const int ipc = __builtin_amdgcn_readlane(ip, src);
                     // rank of the candidate in (distance, index) order among the kept entries
-                    const bool lt = (lane < k) && (ld < dc || (ld == dc && li < icc));
+                    // (bitwise, not short-circuit: three compares and two scalar ANDs instead of nested exec-mask regions)
+                    const bool lt = (lane < k) & ((ld < dc) | ((ld == dc) & (li < icc)));
                     const int pos = __popcll(__ballot(lt));
 #ifdef AMK_KNN_COUNT
                     ++c_ins;
@@ -656,15 +657,10 @@ __device__ __forceinline__ void grid_knn(const GridScene &gs, double qx, double 
                     if (pos < k && dc < DBL_MAX) {
                         const double up_d = wave_shr1_f64(ld);
                         const int up_i = wave_shr1_i32(li), up_p = wave_shr1_i32(lpos);
-                        if (lane > pos) {
-                            ld = up_d;
-                            li = up_i;
-                            lpos = up_p;
-                        } else if (lane == pos) {
-                            ld = dc;
-                            li = icc;
-                            lpos = ipc;
-                        }
+                        const bool above = lane > pos, here = lane == pos;   // selects, not branches
+                        ld = here ? dc : (above ? up_d : ld);
+                        li = here ? icc : (above ? up_i : li);
+                        lpos = here ? ipc : (above ? up_p : lpos);
                         tau = readlane_f64(ld, k - 1);
                     }
                     live = live && lane != src && d <= tau;

@@ -226,6 +226,37 @@ def test_degenerate_grids_and_far_queries(torch_cuda, oracle):
                 assert np.array_equal(res["indices"][s, j, :len(ri)], ri) and np.array_equal(res["sqdist"][s, j, :len(ri)], rd), (s, j, k)
 
 
+def test_candidate_windows_across_item_boundaries(torch_cuda, oracle):
+    """grid_knn flattens the bucket ranges of a shell's (row, tile) items into one candidate index space and reads it in
+    windows of 64; a candidate finds its item through the slots the items announce plus a running maximum, the item that
+    holds the window's first candidate through a ballot (csrc/kd_grid.h: fetch).  Clouds that stress that mapping: one cell
+    far denser than a window (an item spans many windows: carry only), runs of exactly 64 / 128 points per bucket (items
+    begin ON the window boundaries), single points scattered over many buckets and tiles (dozens of one-point items per
+    window, most lanes' items empty), and the mix of all three; k up to 16."""
+    rng = np.random.default_rng(77)
+    blob = (np.array([5.0, 0.0, 1.5]) + 1e-3 * rng.standard_normal((2500, 3))).astype(np.float32)
+    sparse = rng.uniform([0, -8, 0], [30, 8, 4], (500, 3)).astype(np.float32)
+    dense_cell = np.concatenate([sparse, blob])[rng.permutation(3000)]
+    # 48 tight clusters of exactly 64 points (+ 8 of 128) on a lattice: every bucket run is a whole number of windows
+    centres = np.stack(np.meshgrid(np.arange(4) * 7.0, np.arange(-2, 2) * 4.0, np.arange(3) * 1.3, indexing="ij"), -1).reshape(-1, 3)
+    lattice = np.concatenate([c + 1e-2 * rng.standard_normal((128 if i < 8 else 64, 3)) for i, c in enumerate(centres)]).astype(np.float32)
+    # 9000 points = three tiles of the one-pass build, uniformly thin: ~3 points per bucket and tile
+    thin = rng.uniform([0, -8, 0], [30, 8, 4], (9000, 3)).astype(np.float32)
+    mix = np.concatenate([thin[:5000], blob[:700], lattice[:1024]])[rng.permutation(6724)]
+    clouds = [dense_cell, lattice, thin, mix]
+    q = np.concatenate([blob[:6].astype(np.float64) + 0.02, centres[:10] + np.array([0.31, 0.17, 0.23]), rng.uniform([0, -8, 0], [30, 8, 4], (16, 3)),
+                        np.array([[5.0, 0.0, 1.5], [40.0, 0.0, 2.0], [-3.0, 9.0, 5.0]])])
+    qs = np.broadcast_to(q, (len(clouds),) + q.shape)
+    for k in (1, 8, 16):
+        res = _gpu_search(torch_cuda, clouds, qs, k)
+        for s, c in enumerate(clouds):
+            tree = _oracle.kd_oracle(c)
+            for j in range(len(q)):
+                ri, rd, _ = tree.search(q[j], k)
+                assert np.array_equal(res["indices"][s, j, :len(ri)], ri), (s, j, k)
+                assert np.array_equal(res["sqdist"][s, j, :len(ri)].view(np.int64), rd.view(np.int64)), (s, j, k)
+
+
 def test_tile_boundaries_of_the_one_pass_build(torch_cuda, oracle):
     """The index build cuts a cloud into tiles of 4096 points (kd_grid.h grid_build_tiles_scene): ragged batch whose sizes
     sit on, before and behind tile and 512-point round boundaries, NaN-x runs across a tile boundary (the cloud indices of
