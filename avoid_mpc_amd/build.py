@@ -46,6 +46,9 @@ def build(force=False, verbose=False, extra_flags=()):
         extra_flags = tuple(extra_flags) + ("-DAMK_SOLVE_TRACE",)
     if os.environ.get("AMK_HIPCC_FLAGS"):  # experiments only (e.g. -DAMK_SOLVE_WAVES=4)
         extra_flags = tuple(extra_flags) + tuple(os.environ["AMK_HIPCC_FLAGS"].split())
+    flags = list(FLAGS)
+    if os.environ.get("AMK_SCHED_STRATEGY"):  # experiments only: another machine-scheduler strategy than max-ilp
+        flags[-1] = "-amdgpu-sched-strategy=" + os.environ["AMK_SCHED_STRATEGY"]
     os.makedirs(OBJ, exist_ok=True)
     dep_mtime = max(os.path.getmtime(h) for h in _deps())
     objs, relink = [], force or not os.path.exists(LIB)
@@ -54,7 +57,7 @@ def build(force=False, verbose=False, extra_flags=()):
         objs.append(obj)
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), dep_mtime)
         if stale:
-            cmd = [hipcc(), *FLAGS, *extra_flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
+            cmd = [hipcc(), *flags, *extra_flags, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)

@@ -3,8 +3,8 @@
 cd $GRAFT_REPO_ROOT
 rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|power" | head -4
 echo "--- under load"
-( for i in 1 2 3 4 5 6; do python tools/experiments/solve_rate.py > /dev/null 2>&1; done ) &
+( AMK_REPS=12000 python tools/experiments/solve_rate.py 2>/dev/null | grep solve-only ) &
 BG=$!
-sleep 25
+sleep 12
 for i in 1 2 3 4 5 6; do rocm-smi --showclocks --showpower 2>/dev/null | grep -i "sclk\|Socket Power\|power (W)" | head -3; sleep 2; done
 wait $BG

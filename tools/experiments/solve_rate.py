@@ -29,7 +29,7 @@ def run(fn, reps):
         for i in range(NS): fn(i)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / (reps * NS)
-t = run(solve, 8)
+t = run(solve, int(os.environ.get('AMK_REPS', '8')))
 info = outs[0][1].cpu().numpy()
 print('N %d K %d: solve-only %.1f us per 256-scene launch -> %.2f solves/us; iterations mean %.1f, status>0: %d; resident solve blocks per CU %d'
       % (prm.N, prm.K, t * 1e6, S / (t * 1e6), info[:, 1].mean() if info.shape[1] > 1 else -1, int((info[:, 0] > 0).sum()), lib.amk__solve_occupancy(mpcs[0].h)))

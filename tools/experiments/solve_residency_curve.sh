@@ -6,5 +6,5 @@
 cd $GRAFT_REPO_ROOT
 for n in 8 7 6 5 4 3 2 1; do
   lds=$(python -c "print(int(163840 / ($n + 0.5)) // 256 * 256)")
-  echo "cap $n per CU (lds request $lds): $(AMK_SOLVE_LDS_MIN_RT=$lds python tools/experiments/solve_rate.py 2>/dev/null | grep solve-only)"
+  echo "cap $n per CU (lds request $lds): $(AMK_REPS=${AMK_REPS:-256} AMK_SOLVE_LDS_MIN_RT=$lds python tools/experiments/solve_rate.py 2>/dev/null | grep solve-only)"
 done
