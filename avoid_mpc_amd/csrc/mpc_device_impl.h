@@ -304,7 +304,7 @@ template <bool DERIV, bool EXACT = false>
 __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, const real *Xs,
                            const real *Us, real mu, real kappa_sigma, real maj, double *ybuf, real *acc,
                            long long *tclk = nullptr) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x; asm volatile("" : "+v"(lane));   // (opaque per phase: nothing derived from the lane is carried between the phases)
     const real *prm = sm + L.prm;
     const real lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
     real Jloc = RL(0.0), cmax = RL(0.0), cdev = RL(0.0);
@@ -413,7 +413,7 @@ __device__ __forceinline__ real evaluate(real *sm, const LdsMap &L, const SceneI
 // Newton step of the collision terms' multipliers for the state step dX (oracle term_step), same lane = (slot, stage) map.
 __device__ __forceinline__ void update_term_multipliers(real *sm, const LdsMap &L, const SceneIO &io, int N, int K, real mu,
                                                         real tau, real kappa_sigma, double *ybuf) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x; asm volatile("" : "+v"(lane));   // (opaque per phase: nothing derived from the lane is carried between the phases)
     const real *prm = sm + L.prm;
     const real lamw = prm[PRM_W + 24], radius = prm[PRM_RADIUS];
     const int ns = N - 1, per = 64 / ns;
@@ -549,7 +549,7 @@ struct LanePlan {                // the two items + the role of this lane, in re
 };
 
 __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_coef, const int *plan_meta) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x; asm volatile("" : "+v"(lane));   // (opaque per phase: nothing derived from the lane is carried between the phases)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         const int e = lane + 64 * h;
@@ -576,7 +576,7 @@ __device__ __forceinline__ void load_lane_plan(LanePlan &lp, const double *plan_
 // sweep is a chain of dependent fp64 operations (32 cycles each here) and LDS round trips, nothing else.
 __device__ __forceinline__ bool riccati_backward(real *sm, const LdsMap &L, const double *plan_coef,
                                                  const int *plan_meta, int N, real delta, double *gains) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x; asm volatile("" : "+v"(lane));   // (opaque per phase: nothing derived from the lane is carried between the phases)
     // the lane's plan is (re)loaded per sweep -- L2-resident words -- instead of being held for the whole
     // solve: it is dead weight (~90 VGPRs) during the objective evaluation, which sets the register peak
     LanePlan lp;
@@ -721,7 +721,7 @@ __device__ __forceinline__ void riccati_forward(real *sm, const LdsMap &L, int N
 // acc = their complementarity maxima from evaluate<true>).
 __device__ __forceinline__ real box_errors(const real *sm, const LdsMap &L, int nvar, real mu, real s_max, const real *acc,
                                            real *err) {
-    const int lane = threadIdx.x;
+    int lane = threadIdx.x; asm volatile("" : "+v"(lane));   // (opaque per phase: nothing derived from the lane is carried between the phases)
     const real *prm = sm + L.prm;
     real zs = RL(0.0), ed = RL(0.0), ec = RL(0.0), ecm = RL(0.0), lg = RL(0.0);
     for (int e = lane; e < nvar; e += 64) {
@@ -760,6 +760,12 @@ __device__ __forceinline__ real next_mu(real mu, real mu_min, real kappa_mu) {
 // over, and find the same bits (the speculative evaluation of an accepted first trial ran the same code on the same values:
 // Xt = X + a dX is the expression of the update).  A paused-and-resumed solve therefore returns the bits of the uninterrupted
 // one (tests/test_mpc_resume_gpu.py); what it costs is one derivative evaluation per pause.
+#define SC_MU sm[L.red + 3]
+#define SC_PHI0 sm[L.red + 4]
+#define SC_DELTA_LAST sm[L.red + 7]
+#define SC_A sm[L.red + 9]
+#define SC_A_DU sm[L.red + 13]
+#define SC_DPHI sm[L.red + 14]
 __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, int K, const double *prm_g, const SolveOpts &opt,
                             const double *x_init, const double *target, const SceneIO &io, const double *w0,
                             double *w_out, int *info, const double *plan_coef, const int *plan_meta, double *ybuf,
@@ -835,22 +841,27 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         }
     }
     const real mu_min = o_tol * (real)opt.mu_min_fac;
-    real mu = resume ? (real)rec[2 * nvar + 0] : o_mu_init, phi0 = RL(0.0);
-    real err[2] = {RL(0.0), RL(0.0)}, acc[2] = {RL(0.0), RL(0.0)};
-    // derivatives, reduced gradient and optimality errors of the iterate under mu (oracle eval_iterate)
+    // The solver's wave-uniform scalars live in LDS BETWEEN the phases (every lane stores the same value and reads its own store
+    // back: no barrier needed), and a phase takes what it needs by value: as ordinary variables they were ~25 registers pinned
+    // across the objective evaluation and the Riccati sweep, the two phases that set the kernel's register count.
+    SC_MU = resume ? (real)rec[2 * nvar + 0] : o_mu_init;
+    SC_PHI0 = RL(0.0);
+    real *err = sm + L.red + 5, *acc = sm + L.red + 11;
+    err[0] = RL(0.0); err[1] = RL(0.0); acc[0] = RL(0.0); acc[1] = RL(0.0);
+    // derivatives, reduced gradient and optimality errors of the iterate under SC_MU (oracle eval_iterate)
     auto eval_iterate = [&](bool derivs_in_lds, real J_known, long long *tclk) -> real {
         const real J = derivs_in_lds ? J_known
-                                     : evaluate<true>(sm, L, io, N, K, sm + L.X, sm + L.U, mu, o_kappa_sigma,
-                                                      o_maj * mu / o_mu_init, ybuf, acc, tclk);
+                                     : evaluate<true>(sm, L, io, N, K, sm + L.X, sm + L.U, SC_MU, o_kappa_sigma,
+                                                      o_maj * SC_MU / o_mu_init, ybuf, acc, tclk);
         __syncthreads();
         #ifdef AMK_ADJOINT_SEQ
         adjoint_sweep_seq(sm, L, N, prm_g);
 #else
         adjoint_sweep(sm, L, N, prm_g);
 #endif
-        return J + box_errors(sm, L, nvar, mu, o_s_max, acc, err);
+        return J + box_errors(sm, L, nvar, SC_MU, o_s_max, acc, err);
     };
-    // starting barrier parameter: the duals start on the central path of whatever mu is chosen, so mu_init is lowered
+    // starting barrier parameter: the duals start on the central path of whatever SC_MU is chosen, so mu_init is lowered
     // level by level while the start already solves that level's barrier problem to the accuracy at which the barrier
     // update below would leave it (a warm start from a previous solution begins several levels down)
 #pragma unroll 1
@@ -859,16 +870,16 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             for (int e = lane; e < nvar; e += 64) {
                 const int i = e % UD;
                 const real u = sm[L.U + e];
-                sm[L.zl + e] = mu / (u - prm[PRM_LB + i]);
-                sm[L.zu + e] = mu / (prm[PRM_UB + i] - u);
+                sm[L.zl + e] = SC_MU / (u - prm[PRM_LB + i]);
+                sm[L.zu + e] = SC_MU / (prm[PRM_UB + i] - u);
             }
             __syncthreads();
         }
-        phi0 = eval_iterate(false, RL(0.0), nullptr);
-        if (resume || !(err[0] <= o_kappa_eps * mu) || mu <= mu_min) break;   // (a resumed solve only needs the evaluation)
-        mu = next_mu(mu, mu_min, o_kappa_mu);
+        SC_PHI0 = eval_iterate(false, RL(0.0), nullptr);
+        if (resume || !(err[0] <= o_kappa_eps * SC_MU) || SC_MU <= mu_min) break;   // (a resumed solve only needs the evaluation)
+        SC_MU = next_mu(SC_MU, mu_min, o_kappa_mu);
     }
-    real delta_last = resume ? (real)rec[2 * nvar + 1] : RL(0.0);
+    SC_DELTA_LAST = resume ? (real)rec[2 * nvar + 1] : RL(0.0);
     const int it_begin = resume ? (int)rec[2 * nvar + 2] : 0;
     int status = 1, n_reg = resume ? (int)rec[2 * nvar + 3] : 0, ls_fail = resume ? (int)rec[2 * nvar + 4] : 0, it = 0;
     bool paused = false;
@@ -877,24 +888,24 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         const long long t0 = AMK_CLK();
         long long tclk[3] = {0, 0, 0};
         if (kTrace && trace && lane == 0) {
-            trace[16 * it + 0] = phi0; trace[16 * it + 1] = err[1]; trace[16 * it + 2] = mu; trace[16 * it + 3] = err[0];
+            trace[16 * it + 0] = SC_PHI0; trace[16 * it + 1] = err[1]; trace[16 * it + 2] = SC_MU; trace[16 * it + 3] = err[0];
         }
-        if (mu <= mu_min && err[0] <= o_tol) { status = 0; break; }  // the last barrier problem is solved to tol
+        if (SC_MU <= mu_min && err[0] <= o_tol) { status = 0; break; }  // the last barrier problem is solved to tol
         if (budget > 0 && it - it_begin >= budget) { paused = true; break; }  // this launch's share is used up: continue later
-        if (it > 0 && err[0] <= o_kappa_eps * mu && mu > mu_min) {   // barrier update (one level per iteration)
-            mu = next_mu(mu, mu_min, o_kappa_mu);
+        if (it > 0 && err[0] <= o_kappa_eps * SC_MU && SC_MU > mu_min) {   // barrier update (one level per iteration)
+            SC_MU = next_mu(SC_MU, mu_min, o_kappa_mu);
             __syncthreads();
-            phi0 = eval_iterate(false, RL(0.0), kTrace ? tclk : nullptr);
+            SC_PHI0 = eval_iterate(false, RL(0.0), kTrace ? tclk : nullptr);
         }
         __syncthreads();
         const long long t1 = AMK_CLK();
-        const real tau = fmax(o_tau_min, RL(1.0) - mu);
+        const real tau = fmax(o_tau_min, RL(1.0) - SC_MU);
         for (int e = lane; e < nvar; e += 64) {
             const int i = e % UD;
             const real u = sm[L.U + e];
             const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
             const real isl = fast_rcp(sl), isu = fast_rcp(su);
-            sm[L.rb + e] = sm[L.r + e] - mu * isl + mu * isu;
+            sm[L.rb + e] = sm[L.r + e] - SC_MU * isl + SC_MU * isu;
             sm[L.Rb + e] = RL(2.0) * prm[PRM_W + 20 + i] + sm[L.zl + e] * isl + sm[L.zu + e] * isu;
         }
         for (int e = lane; e < 56 + 10 + 40; e += 64) sm[L.M + e] = RL(0.0);  // (the line search's trial states lay here)
@@ -904,15 +915,15 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
         bool ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta, gains);
         while (!ok) {
             __syncthreads();
-            if (delta == RL(0.0)) delta = (delta_last == RL(0.0)) ? RL(1.0) : fmax(RL(1e-20), delta_last / RL(3.0));
-            else delta *= (delta_last == RL(0.0)) ? RL(100.0) : RL(8.0);
+            if (delta == RL(0.0)) delta = (SC_DELTA_LAST == RL(0.0)) ? RL(1.0) : fmax(RL(1e-20), SC_DELTA_LAST / RL(3.0));
+            else delta *= (SC_DELTA_LAST == RL(0.0)) ? RL(100.0) : RL(8.0);
             ++reg_now;
             if (delta > (AMK_REAL_F32 ? RL(1e30) : RL(1e40))) break;
             ok = riccati_backward(sm, L, plan_coef, plan_meta, N, delta, gains);
         }
         if (!ok) { status = 2; break; }
         n_reg += reg_now;
-        if (delta > RL(0.0)) delta_last = delta;
+        if (delta > RL(0.0)) SC_DELTA_LAST = delta;
         const long long t2 = AMK_CLK();
         riccati_forward(sm, L, N, prm_g, gains);
         const long long t3 = AMK_CLK();
@@ -923,8 +934,8 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             const real u = sm[L.U + e], zl = sm[L.zl + e], zu = sm[L.zu + e], du = sm[L.dU + e];
             const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
             const real isl = fast_rcp(sl), isu = fast_rcp(su);
-            const real dzl = mu * isl - zl - (zl * isl) * du;
-            const real dzu = mu * isu - zu + (zu * isu) * du;
+            const real dzl = SC_MU * isl - zl - (zl * isl) * du;
+            const real dzu = SC_MU * isu - zu + (zu * isu) * du;
             sm[L.dzl + e] = dzl;
             sm[L.dzu + e] = dzu;
             // fraction to the boundary: one reciprocal per ratio, only the binding side of each bound
@@ -933,66 +944,67 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             if (du > RL(0.0)) a_pr = fmin(a_pr, tau * su * idu);
             if (dzl < RL(0.0)) a_du = fmin(a_du, -tau * zl * fast_rcp(dzl));
             if (dzu < RL(0.0)) a_du = fmin(a_du, -tau * zu * fast_rcp(dzu));
-            dphi += (sm[L.gU + e] - mu * isl + mu * isu) * du;
+            dphi += (sm[L.gU + e] - SC_MU * isl + SC_MU * isu) * du;
         }
-        a_pr = wave_min(a_pr); a_du = wave_min(a_du); dphi = wave_sum(dphi);
+        a_pr = wave_min(a_pr); SC_A_DU = wave_min(a_du); SC_DPHI = wave_sum(dphi);   // (parked: see SC_MU)
         // ... and the multipliers of the collision terms (they do not enter the merit function)
-        update_term_multipliers(sm, L, io, N, K, mu, tau, o_kappa_sigma, ybuf);
+        update_term_multipliers(sm, L, io, N, K, SC_MU, tau, o_kappa_sigma, ybuf);
         // backtracking Armijo line search on the barrier function
         const long long t4 = AMK_CLK();
-        real a = a_pr, phi_t = RL(0.0), J_t = RL(0.0);
+        SC_A = a_pr;
+        real phi_t = RL(0.0), J_t = RL(0.0);
         bool accepted = false, have_derivs = false;
         const bool speculate = it + 1 < opt.max_iter;  // the last iteration has no successor to hand derivatives to
         // a Newton step whose predicted decrease is below the rounding level of phi is taken as it is
-        const bool tiny = -dphi <= RL(100.0) * (AMK_REAL_F32 ? RL(1.1920929e-7) : RL(2.220446049250313e-16)) * (RL(1.0) + fabs(phi0));
+        const bool tiny = -SC_DPHI <= RL(100.0) * (AMK_REAL_F32 ? RL(1.1920929e-7) : RL(2.220446049250313e-16)) * (RL(1.0) + fabs(SC_PHI0));
         for (int ls = 0; ls < opt.max_ls; ++ls) {
             __syncthreads();
-            for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + a * sm[L.dU + e];
-            for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + a * sm[L.dX + e];
+            for (int e = lane; e < nvar; e += 64) sm[L.Ut + e] = sm[L.U + e] + SC_A * sm[L.dU + e];
+            for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.Xt + e] = sm[L.X + e] + SC_A * sm[L.dX + e];
             __syncthreads();
             if (ls == 0 && speculate) {
-                J_t = evaluate<true>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, mu, o_kappa_sigma, o_maj * mu / o_mu_init, ybuf, acc);
+                J_t = evaluate<true>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, SC_MU, o_kappa_sigma, o_maj * SC_MU / o_mu_init, ybuf, acc);
                 have_derivs = true;
             } else {
-                J_t = evaluate<false>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, mu, o_kappa_sigma, RL(0.0), ybuf, nullptr);
+                J_t = evaluate<false>(sm, L, io, N, K, sm + L.Xt, sm + L.Ut, SC_MU, o_kappa_sigma, RL(0.0), ybuf, nullptr);
                 have_derivs = false;  // the iterate moves on to a point that has no derivatives yet
             }
             real lg = RL(0.0);
             for (int e = lane; e < nvar; e += 64) {
                 const int i = e % UD;
                 const real u = sm[L.Ut + e];
-                lg -= mu * real_log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
+                lg -= SC_MU * real_log((u - prm[PRM_LB + i]) * (prm[PRM_UB + i] - u));
             }
             phi_t = J_t + wave_sum(lg);
-            if (tiny || phi_t <= phi0 + o_eta_phi * a * dphi) { accepted = true; break; }
-            if (ls + 1 < opt.max_ls) a *= RL(0.5);
+            if (tiny || phi_t <= SC_PHI0 + o_eta_phi * SC_A * SC_DPHI) { accepted = true; break; }
+            if (ls + 1 < opt.max_ls) SC_A *= RL(0.5);
         }
         if (!accepted) {  // no decrease found (rounding level of phi): stay; the duals still move
             ++ls_fail;
-            a = RL(0.0);
+            SC_A = RL(0.0);
             have_derivs = false;
         }
         if (kTrace && trace && lane == 0) {
-            trace[16 * it + 4] = a; trace[16 * it + 5] = a_pr; trace[16 * it + 6] = a_du; trace[16 * it + 7] = dphi;
+            trace[16 * it + 4] = SC_A; trace[16 * it + 5] = a_pr; trace[16 * it + 6] = SC_A_DU; trace[16 * it + 7] = SC_DPHI;
             trace[16 * it + 8] = (double)(t1 - t0); trace[16 * it + 9] = (double)(t2 - t1);
             trace[16 * it + 10] = (double)(t3 - t2); trace[16 * it + 11] = (double)(t4 - t3);
             trace[16 * it + 12] = (double)(AMK_CLK() - t4); trace[16 * it + 13] = (double)tclk[0]; trace[16 * it + 14] = delta; trace[16 * it + 15] = (double)tclk[2];
         }
         __syncthreads();
-        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] += a * sm[L.dX + e];
+        for (int e = lane; e < (N + 1) * SD; e += 64) sm[L.X + e] += SC_A * sm[L.dX + e];
         for (int e = lane; e < nvar; e += 64) {
             const int i = e % UD;
-            const real u = sm[L.U + e] + a * sm[L.dU + e];
+            const real u = sm[L.U + e] + SC_A * sm[L.dU + e];
             sm[L.U + e] = u;
             const real sl = u - prm[PRM_LB + i], su = prm[PRM_UB + i] - u;
-            real zl = sm[L.zl + e] + a_du * sm[L.dzl + e], zu = sm[L.zu + e] + a_du * sm[L.dzu + e];
-            zl = fmax(fmin(zl, o_kappa_sigma * mu / sl), mu / (o_kappa_sigma * sl));
-            zu = fmax(fmin(zu, o_kappa_sigma * mu / su), mu / (o_kappa_sigma * su));
+            real zl = sm[L.zl + e] + SC_A_DU * sm[L.dzl + e], zu = sm[L.zu + e] + SC_A_DU * sm[L.dzu + e];
+            zl = fmax(fmin(zl, o_kappa_sigma * SC_MU / sl), SC_MU / (o_kappa_sigma * sl));
+            zu = fmax(fmin(zu, o_kappa_sigma * SC_MU / su), SC_MU / (o_kappa_sigma * su));
             sm[L.zl + e] = zl;
             sm[L.zu + e] = zu;
         }
         __syncthreads();
-        if (speculate) phi0 = eval_iterate(have_derivs, J_t, nullptr);
+        if (speculate) SC_PHI0 = eval_iterate(have_derivs, J_t, nullptr);
     }
     __syncthreads();
     for (int e = lane; e < (N + 1) * SD; e += 64) w_out[14 * (e / SD) + (e % SD)] = sm[L.X + e];
@@ -1003,7 +1015,7 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
             rec[nvar + e] = (double)sm[L.zu + e];
         }
         if (lane == 0) {
-            rec[2 * nvar + 0] = (double)mu; rec[2 * nvar + 1] = (double)delta_last; rec[2 * nvar + 2] = (double)it;
+            rec[2 * nvar + 0] = (double)SC_MU; rec[2 * nvar + 1] = (double)SC_DELTA_LAST; rec[2 * nvar + 2] = (double)it;
             rec[2 * nvar + 3] = (double)n_reg; rec[2 * nvar + 4] = (double)ls_fail;
         }
     }
@@ -1020,6 +1032,12 @@ __device__ __forceinline__ void solve_scene(real *sm, const LdsMap &L, int N, in
     }
 }
 
+#undef SC_MU
+#undef SC_PHI0
+#undef SC_DELTA_LAST
+#undef SC_A
+#undef SC_A_DU
+#undef SC_DPHI
 __device__ __forceinline__ int sm_status(const real *sm, const LdsMap &L) { return (int)sm[L.red + 0]; }
 __device__ __forceinline__ int sm_iters(const real *sm, const LdsMap &L) { return (int)sm[L.red + 1]; }
 __device__ __forceinline__ bool sm_paused(const real *sm, const LdsMap &L) { return sm[L.red + 2] != RL(0.0); }
