@@ -917,7 +917,7 @@ def main():
                                  "per VALU instruction, SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU) / (1024 SIMDs x 2.4 GHz): the share of the chip's "
                                  "VALU issue slots the dominant kernel fills while the builds and searches of the other steps share the CUs; "
                                  "frac_valu_issue_at_saturation_solves_only is the same quantity with nothing but solves resident "
-                                 "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (230 VGPRs and 17.8 KB of LDS "
+                                 "(tools/experiments/ms_parts.py).  What stops it below 1: two waves per SIMD (180 VGPRs and 17.8 KB of LDS per scene; a third wave was measured to buy nothing, DESIGN 5: "
                                  "per scene) cannot cover ~32-cycle dependent fp64 issue and LDS round trips "
                                  f"(profiles/{PROFILE_TAG}_pmc_solve_issue.md, DESIGN.md section 5)"},
             "roofline_hbm": roof_solve_hbm,

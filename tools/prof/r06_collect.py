@@ -138,7 +138,7 @@ issue["valu_issue_util_at_saturation"] = issue["valu_instructions_per_wave_solve
 issue["lds_array_util_at_saturation (conflict level of the lone wave)"] = issue["lds_array_busy_cycles_per_wave"] / clk_per_solve_per_cu
 issue["wave_time_stretch_at_saturation"] = 8 * clk_per_solve_per_cu / issue["wave_cycles_per_wave"]
 issue["bound"] = ("dependent-operation latency at limited occupancy: a wave alone issues VALU %.0f %% of its time, LDS %.0f %%, "
-                  "and waits %.0f %%; the register file (230 VGPRs per wave; LDS: 17.8 KB per scene) allows 8 waves per CU = 2 per SIMD, and at that occupancy "
+                  "and waits %.0f %%; the LDS (17.8 KB per scene; 180 VGPRs per wave) allows 8 waves per CU = 2 per SIMD, and at that occupancy "
                   "the VALU pipes are %.0f %% busy and the LDS array %.0f %% -- neither is saturated, a wave just runs %.2fx "
                   "slower than alone because its dependent fp64 operations and LDS round trips interleave with one other "
                   "wave's; HBM and MFMA are not involved" % (
